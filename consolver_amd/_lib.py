@@ -1,0 +1,125 @@
+"""ctypes binding of libconsolver_hip.so (the C ABI in include/consolver_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised.  The product never computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libconsolver_hip.so")
+
+CS_F32, CS_F16, CS_BF16 = 0, 1, 2
+CS_MAX_ORDER = 8
+_DT = {torch.float32: CS_F32, torch.float16: CS_F16, torch.bfloat16: CS_BF16}
+
+
+class CsFactorNet(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("in_dim", C.c_int), ("hidden", C.c_int), ("action_dims", C.c_int), ("num_actions", C.c_int),
+                ("input_scale", C.c_float), ("inv_temperature", C.c_float)]
+
+
+class CsStepArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("eps_text", C.c_void_p), ("eps_uncond", C.c_void_p), ("guidance", C.c_float),
+                ("hist", C.c_void_p * CS_MAX_ORDER), ("m", C.c_int), ("order_dim", C.c_int), ("scaler_dim", C.c_int),
+                ("actions", C.c_void_p), ("actions_stride", C.c_int), ("B", C.c_int), ("elems", C.c_int64),
+                ("io_dtype", C.c_int), ("out_dtype", C.c_int), ("x_out", C.c_void_p), ("eps_out", C.c_void_p),
+                ("sqrt_at", C.c_float), ("sqrt_1mat", C.c_float), ("sqrt_ap", C.c_float), ("sqrt_1map", C.c_float),
+                ("v_prediction", C.c_int), ("dt", C.c_float)]
+
+
+class CsUNetConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("num_heads", C.c_int), ("cross_attention_dim", C.c_int),
+                ("norm_num_groups", C.c_int), ("sample_size", C.c_int), ("ctx_len", C.c_int),
+                ("down_has_attn", C.c_int * 4), ("up_has_attn", C.c_int * 4)]
+
+
+# every symbol declared in include/consolver_hip.h: name -> (restype, argtypes)
+SYMBOLS = {
+    "cs_abi_version": (C.c_int, []),
+    "cs_error_string": (C.c_char_p, [C.c_int]),
+    "cs_last_error": (C.c_char_p, []),
+    "cs_target_arch": (C.c_char_p, []),
+    "cs_factor_probs": (C.c_int, [C.POINTER(CsFactorNet), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_cosine_features": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_gather_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_action_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_step_masks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_stack_history": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_lms_ddim_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
+    "cs_lms_euler_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
+    "cs_unet_create": (C.c_int, [C.POINTER(CsUNetConfig), C.POINTER(C.c_void_p)]),
+    "cs_unet_destroy": (None, [C.c_void_p]),
+    "cs_unet_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "cs_unet_num_weights": (C.c_int, [C.c_void_p]),
+    "cs_unet_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "cs_unet_finalize": (C.c_int, [C.c_void_p]),
+    "cs_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "cs_unet_flops": (C.c_double, [C.c_void_p, C.c_int]),
+    "cs_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "cs_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "cs_unet_profile_entries": (C.c_int, [C.c_void_p]),
+    "cs_unet_profile_entry": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m consolver_amd.build`). There is no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            f = getattr(l, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libconsolver_hip.so does not export {name}") from e
+        f.restype = res
+        f.argtypes = args
+    if l.cs_abi_version() != 1:
+        raise RuntimeError("libconsolver_hip.so ABI version mismatch")
+    _lib = l
+    return l
+
+
+def check(code):
+    if code != 0:
+        l = lib()
+        raise RuntimeError(f"libconsolver_hip: {l.cs_error_string(code).decode()}: {l.cs_last_error().decode()}")
+
+
+def dtype_code(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}; expected float32/float16/bfloat16")
+
+
+def require_cuda(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must be a CUDA (ROCm) tensor: consolver_amd runs only on the MI355X HIP path; "
+            "the CPU restatement lives in oracle/ and is test infrastructure, not a fallback.")
+    return t
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,90 @@
+"""PPO rollout loop (training trajectories) -- mirror of ``denoise_ppo.denoise_diffusion``
+(denoise_ppo.py:6-120): same arguments, same 6-tuple
+``(latents, conds{x, epsilon}, probs, actions, masks, prompt_embeds)`` with records for steps
+``i > 0`` only (:105-111).
+
+Differences in mechanism, not in results: the CFG dual batch is not materialised by
+``torch.cat`` when the denoiser is the HIP UNet (it reads latent ``b % B``), and the CFG
+combine ``u + g (c - u)`` (:96-100) is fused into the solver-update kernel.
+"""
+import torch
+
+from . import _lib as L
+
+
+def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg=3, num_inference_steps=50,
+                      gradient_checkpointing=False, prompt_embeds=None, negative_prompt_embeds=None):
+    if gradient_checkpointing:
+        raise NotImplementedError("inference-only rollout: the denoiser is frozen (train_ppo.py:148-154)")
+    if isinstance(text, str):
+        text = [text]
+    batch_size = len(text)
+    L.require_cuda(noise, "noise")
+    device = noise.device
+
+    if prompt_embeds is None:
+        ids = tokenizer(text, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                        return_tensors="pt").input_ids.to(device)
+        prompt_embeds = text_encoder(ids)[0]
+    prompt_embeds_txt = prompt_embeds
+    do_cfg = cfg > 1.0
+    if do_cfg:
+        if negative_prompt_embeds is None:
+            ids = tokenizer([""] * batch_size, padding="max_length", max_length=tokenizer.model_max_length,
+                            truncation=True, return_tensors="pt").input_ids.to(device)
+            negative_prompt_embeds = text_encoder(ids)[0]
+        prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
+
+    latents = noise.clone()
+    scheduler.set_timesteps(num_inference_steps, device=device)
+    record_prev = scheduler.record_conds
+    scheduler.record_conds = True
+    net = scheduler.factor_net.module if hasattr(scheduler.factor_net, "module") else scheduler.factor_net
+    fused_cfg = do_cfg and not net.use_conv
+    native = getattr(unet, "is_consolver_hip", False)
+    rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
+    try:
+        for i, t in enumerate(scheduler.timesteps):
+            if native:
+                noise_pred = unet(latents, t, encoder_hidden_states=prompt_embeds, return_dict=False,
+                                  dup=2 if do_cfg else 1)[0]
+            else:
+                lat_in = torch.cat([latents] * 2) if do_cfg else latents
+                lat_in = scheduler.scale_model_input(lat_in, t)
+                noise_pred = unet(lat_in, t, encoder_hidden_states=prompt_embeds, return_dict=False)[0]
+            if do_cfg:
+                u, c = noise_pred[:batch_size], noise_pred[batch_size:]
+                if fused_cfg:
+                    out = scheduler.step(c, t, latents, return_dict=False, eps_uncond=u, guidance_scale=cfg)
+                else:
+                    out = scheduler.step(_cfg_combine(u, c, cfg), t, latents, return_dict=False)
+            else:
+                out = scheduler.step(noise_pred, t, latents, return_dict=False)
+            latents, actions, probs, conds, masks = out
+            if i > 0:
+                rec["x"].append(conds["x"].unsqueeze(1))
+                rec["epsilon"].append(conds["epsilon"].unsqueeze(1))
+                rec["probs"].append(probs.unsqueeze(1))
+                rec["actions"].append(actions.unsqueeze(1))
+                rec["masks"].append(masks.unsqueeze(1))
+    finally:
+        scheduler.record_conds = record_prev
+    cat = {k: torch.cat(v, dim=1) for k, v in rec.items()}
+    return latents, {"x": cat["x"], "epsilon": cat["epsilon"]}, cat["probs"], cat["actions"], cat["masks"], prompt_embeds_txt
+
+
+def _cfg_combine(u, c, g):
+    """stand-alone CFG combine through the step kernel's CFG stage is not exposed separately;
+    for the use_conv configuration the combined eps must exist before the policy runs, so it is
+    produced by the Euler kernel with dt = 0 ... x' = x, eps_out = u + g (c - u)."""
+    import ctypes as C
+    out = torch.empty_like(c)
+    a = L.CsStepArgs()
+    a.x, a.eps_text, a.eps_uncond, a.guidance = c.data_ptr(), c.data_ptr(), u.data_ptr(), float(g)
+    a.m, a.order_dim, a.scaler_dim = 1, 2, 0
+    a.B, a.elems = c.shape[0], c.numel() // max(c.shape[0], 1)
+    a.io_dtype = a.out_dtype = L.dtype_code(c.dtype)
+    scratch = torch.empty_like(c)
+    a.x_out, a.eps_out, a.dt = scratch.data_ptr(), out.data_ptr(), 0.0
+    L.check(L.lib().cs_lms_euler_step(C.byref(a), L.stream_ptr(c.device)))
+    return out

@@ -1,0 +1,269 @@
+"""PPOScheduler -- the SD-side ConsistencySolver scheduler, HIP-backed.
+
+Drop-in for the reference's ``PPOScheduler`` (scheduler_ppo.py:48-361): same
+constructor arguments, ``set_timesteps`` / ``timesteps`` / ``init_noise_sigma`` /
+``scale_model_input`` / ``step(...) -> (prev_sample, actions, probs, conds, masks)`` /
+``add_noise`` / ``config`` / ``_compatibles`` / ``order`` and the ``factor_net``
+attribute users reach into (``load_state_dict``, ``.to``).
+
+Per ``step`` the device work is: [cosine features] -> policy MLP+softmax ->
+categorical draw/gather -> ONE fused kernel (coefficient fix-up, linear
+multistep combine over the cached eps history, optional CFG combine and scales,
+DDIM update).  The host only does integer timestep arithmetic and table
+look-ups -- no device->host synchronisation (the reference syncs three times
+per step: scheduler_ppo.py:207,243,288).
+"""
+import ctypes as C
+import inspect
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import tables
+from .factor_net import FactorNetPPO
+
+_KARRAS_COMPATIBLES = [
+    "DDIMScheduler", "DDPMScheduler", "PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler",
+    "HeunDiscreteScheduler", "EulerAncestralDiscreteScheduler", "DPMSolverMultistepScheduler",
+    "DPMSolverSinglestepScheduler", "KDPM2DiscreteScheduler", "KDPM2AncestralDiscreteScheduler",
+    "DEISMultistepScheduler", "UniPCMultistepScheduler", "DPMSolverSDEScheduler", "EDMEulerScheduler",
+]
+
+
+class SolverConfig(dict):
+    """attribute *and* ``.get`` access like diffusers' FrozenDict
+    (edit_ppo/pipeline.py:1013-1016 uses ``scheduler.config.get``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def capture_config(self, init, args, kwargs):
+    sig = inspect.signature(init)
+    bound = sig.bind(self, *args, **kwargs)
+    bound.apply_defaults()
+    self.config = SolverConfig({k: v for k, v in bound.arguments.items() if k != "self"})
+
+
+class SolverOutput(dict):
+    """what ``return_dict=True`` returns (the reference passes extra fields to a
+    single-field diffusers dataclass and would raise, scheduler_ppo.py:299)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class HistoryMixin:
+    """eps history + per-step policy evaluation shared by the SD and FLUX schedulers."""
+
+    record_conds = False     # materialise conds['epsilon'] (needed only by the PPO rollout)
+    verbose = False          # print coefficients like the reference (forces a host sync)
+
+    def _policy(self, cond_row_f32, B, device):
+        """-> probs3 [B,A,K], actions [B,A], action_probs [B,A], idx"""
+        net = self.factor_net.module if hasattr(self.factor_net, "module") else self.factor_net
+        hist = self.ets[::-1]
+        x = cond_row_f32
+        probs3 = net.probs_from(x, hist if net.use_conv else None, len(hist), batch=B)
+        actions, aprobs, idx = net.draw(probs3)
+        return probs3, actions, aprobs, idx
+
+    def _masks(self, B, A, m, device):
+        masks = torch.empty(B, A, dtype=torch.float32, device=device)
+        L.check(L.lib().cs_step_masks(B, A, m, self.config.order_dim, L.ptr(masks), L.stream_ptr(device)))
+        return masks
+
+    def _stack(self, B, elems, like):
+        order = self.config.order_dim
+        hist = [h.contiguous() for h in self.ets[::-1]]
+        out = torch.empty((B, order) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        arr = (C.c_void_p * L.CS_MAX_ORDER)(*[h.data_ptr() for h in hist])
+        L.check(L.lib().cs_stack_history(arr, len(hist), order, B, elems, L.dtype_code(like.dtype), L.ptr(out),
+                                         L.stream_ptr(like.device)))
+        return out
+
+    def _fill_step_args(self, a, sample, eps_text, eps_uncond, guidance, actions, out, eps_out, out_dtype):
+        B = sample.shape[0]
+        hist = self.ets[::-1]  # newest first, hist[0] is the eps just pushed
+        a.x, a.eps_text = sample.data_ptr(), eps_text.data_ptr()
+        a.eps_uncond = eps_uncond.data_ptr() if eps_uncond is not None else None
+        a.guidance = float(guidance)
+        for k in range(L.CS_MAX_ORDER):
+            a.hist[k] = hist[k + 1].data_ptr() if k + 1 < len(hist) else None
+        a.m, a.order_dim, a.scaler_dim = len(hist), self.config.order_dim, self.config.scaler_dim
+        a.actions, a.actions_stride = actions.data_ptr(), actions.shape[1]
+        a.B, a.elems = B, sample.numel() // max(B, 1)
+        a.io_dtype, a.out_dtype = L.dtype_code(sample.dtype), L.dtype_code(out_dtype)
+        a.x_out = out.data_ptr()
+        a.eps_out = eps_out.data_ptr() if eps_out is not None else None
+
+
+class PPOScheduler(HistoryMixin):
+    _compatibles = list(_KARRAS_COMPATIBLES)
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, prediction_type="epsilon", timestep_spacing="leading", steps_offset=0,
+                 order_dim=4, scaler_dim=2, use_conv=False, ppo_type="discrete", factor_net_kwargs=None):
+        capture_config(self, PPOScheduler.__init__,
+                       (num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, prediction_type,
+                        timestep_spacing, steps_offset, order_dim, scaler_dim, use_conv, ppo_type,
+                        factor_net_kwargs), {})
+        if not (1 < order_dim <= L.CS_MAX_ORDER):
+            # order_dim=1 raises IndexError inside the reference (scheduler_ppo.py:166 on an empty list)
+            raise ValueError(f"order_dim must be in [2, {L.CS_MAX_ORDER}]")
+        self._betas = tables.make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps, trained_betas)
+        self._ac = tables.alphas_cumprod(self._betas)
+        self.betas = torch.from_numpy(self._betas)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.from_numpy(self._ac)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self._timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
+        self.timesteps = torch.from_numpy(self._timesteps)
+        self.ets = []
+        kw = dict(factor_net_kwargs) if factor_net_kwargs is not None else {}
+        kw["order_dim"], kw["scaler_dim"], kw["use_conv"] = order_dim, scaler_dim, use_conv
+        kw.setdefault("embedding_dim", 32)
+        kw.setdefault("hidden_dim", 256)
+        if ppo_type != "discrete":
+            # the reference imports a module that does not exist upstream (scheduler_ppo.py:23,138-139)
+            raise NotImplementedError("only ppo_type='discrete' exists in the reference")
+        kw.setdefault("num_actions", 161)
+        self.factor_net = FactorNetPPO(**kw)
+        self._cond_table = None
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        c = dict(config)
+        c.update(kw)
+        return cls(**{k: v for k, v in c.items() if k in inspect.signature(cls.__init__).parameters})
+
+    # ------------------------------------------------------------------ protocol
+    def set_timesteps(self, num_inference_steps, device=None):
+        T = self.config.num_train_timesteps
+        if num_inference_steps > T:
+            raise ValueError(f"`num_inference_steps` ({num_inference_steps}) cannot be larger than "
+                             f"`num_train_timesteps` ({T}).")
+        ts = tables.sd_timestep_grid(num_inference_steps, T, self.config.timestep_spacing, self.config.steps_offset)
+        if ts.min() < 0 or ts.max() >= T:
+            # e.g. trailing with n=61 yields 62 entries ending in -1 in the reference (it would wrap around)
+            raise ValueError(f"timestep grid for n={num_inference_steps} leaves [0, {T}): {ts.min()}..{ts.max()}")
+        self.num_inference_steps = num_inference_steps
+        self._timesteps = ts
+        self.timesteps = torch.from_numpy(ts).to(device)
+        self.ets = []
+        self._cond_table = None
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+    def _resolve_timestep(self, timestep):
+        """integer value of ``timestep`` without a device sync when it is an element of self.timesteps."""
+        if isinstance(timestep, torch.Tensor):
+            if timestep.is_cuda:
+                ts = self.timesteps
+                if ts.is_cuda and ts.device == timestep.device and timestep.dtype == ts.dtype:
+                    off = timestep.data_ptr() - ts.data_ptr()
+                    if 0 <= off < ts.numel() * ts.element_size() and off % ts.element_size() == 0:
+                        return int(self._timesteps[off // ts.element_size()])
+                return int(timestep.item())
+            return int(timestep)
+        return int(timestep)
+
+    def _cond_row(self, t, prev_t, dtype, device):
+        """[1,2] fp32 device row (t, prev_t) rounded through the model dtype like
+        ``torch.tensor([[t, prev_t]], dtype=model_output.dtype)`` (scheduler_ppo.py:207)."""
+        if self._cond_table is None or self._cond_table[0].device != device or self._cond_table[2] != dtype:
+            n = self.num_inference_steps
+            host = np.stack([self._timesteps, self._timesteps - self.config.num_train_timesteps // n], 1)
+            dev = torch.from_numpy(host.astype(np.float32)).to(device).to(dtype).to(torch.float32)
+            self._cond_table = (dev, {int(v): i for i, v in enumerate(self._timesteps)}, dtype)
+        dev, index, _ = self._cond_table
+        i = index.get(int(t))
+        if i is None:
+            return torch.tensor([[t, prev_t]], dtype=dtype).to(torch.float32).to(device)
+        return dev[i:i + 1]
+
+    def _ddim_scalars(self, t, prev_t):
+        a_t = self._ac[t]
+        a_p = self._ac[prev_t] if prev_t >= 0 else self._ac[0]
+        one = np.float32(1.0)
+        return (float(np.sqrt(a_t)), float(np.sqrt(one - a_t)), float(np.sqrt(a_p)), float(np.sqrt(one - a_p)))
+
+    def step(self, model_output, timestep, sample, return_dict=True, *, eps_uncond=None, guidance_scale=1.0,
+             eps_out=None, out=None):
+        """scheduler_ppo.py:178-299.  Extension (keyword-only): pass the two CFG branches as
+        ``model_output`` (text) + ``eps_uncond`` and the combine u + g (c - u) is fused into the
+        update kernel; ``eps_out`` receives the combined eps (the history entry)."""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None'. Call 'set_timesteps' first.")
+        if self.config.prediction_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"Unsupported prediction_type: {self.config.prediction_type}")
+        if self.config.scaler_dim > 2:
+            raise AssertionError("not implemented")     # scheduler_ppo.py:280
+        L.require_cuda(model_output, "model_output")
+        L.require_cuda(sample, "sample")
+        model_output = model_output.contiguous()
+        sample = sample.contiguous()
+        if sample.dtype != model_output.dtype:
+            sample = sample.to(model_output.dtype)
+        dev = model_output.device
+        t = self._resolve_timestep(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        B = model_output.shape[0]
+
+        if eps_uncond is not None:
+            eps_uncond = L.require_cuda(eps_uncond, "eps_uncond").contiguous()
+            if eps_out is None:
+                eps_out = torch.empty_like(model_output)
+            current = eps_out
+        else:
+            current = model_output
+        self.ets.append(current)
+        self.ets = self.ets[-self.config.order_dim:]
+        m = len(self.ets)
+
+        net = self.factor_net.module if hasattr(self.factor_net, "module") else self.factor_net
+        cond_row = self._cond_row(t, prev_t, model_output.dtype, dev)
+        if net.use_conv and eps_uncond is not None:
+            raise NotImplementedError("use_conv=True needs the combined eps before the policy runs; "
+                                      "combine CFG before step() in that configuration")
+        probs3, actions, aprobs, _ = self._policy(cond_row, B, dev)
+        masks = self._masks(B, net.action_dims, m, dev)
+
+        prev = out if out is not None else torch.empty_like(sample)
+        a = L.CsStepArgs()
+        self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, actions, prev, eps_out, sample.dtype)
+        a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = self._ddim_scalars(t, prev_t)
+        a.v_prediction = int(self.config.prediction_type == "v_prediction")
+        L.check(L.lib().cs_lms_ddim_step(C.byref(a), L.stream_ptr(dev)))
+
+        conds = {"x": cond_row.to(model_output.dtype).repeat(B, 1),
+                 "epsilon": self._stack(B, a.elems, current) if (self.record_conds or net.use_conv) else None}
+        if self.verbose:
+            print(f"T={t} -> {prev_t} | actions: {actions[0].tolist()} | Prob: {aprobs[0].tolist()}")
+        if not return_dict:
+            return (prev, actions, aprobs, conds, masks)
+        return SolverOutput(prev_sample=prev, actions=actions, probs=aprobs, conds=conds, masks=masks)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """scheduler_ppo.py:336-358 (forward process; not on the sampling path)."""
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        timesteps = timesteps.to(original_samples.device)
+        sa = (ac[timesteps] ** 0.5).flatten()
+        sb = ((1 - ac[timesteps]) ** 0.5).flatten()
+        while len(sa.shape) < len(original_samples.shape):
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original_samples + sb * noise

@@ -1,0 +1,188 @@
+/*
+ * consolver_hip.h -- C ABI of libconsolver_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the ConsistencySolver sampling hot path of
+ * G-U-N/consolver.  The reference is pure Python on top of torch/diffusers and
+ * has no FFI of its own; the entry points below are what a Python (ctypes),
+ * C++ or cgo/JNI host would bind to replace, one for one, the arithmetic inside
+ *
+ *   scheduler_ppo.py:178-299      PPOScheduler.step            -> cs_lms_ddim_step
+ *   scheduler_ppo.py:306-332      PPOScheduler._get_prev_sample   (fused into the above)
+ *   scheduler_ppo.py:165-175      set_default_coefficients        (fused into the above)
+ *   denoise_ppo.py:96-100         CFG combine u + g (c - u)       (fused into the above)
+ *   edit_ppo/scheduler_fmppo.py:306-455  FMPPOScheduler.step   -> cs_lms_euler_step
+ *   factor_net_ppo.py:137-157     FactorNetPPO.forward_        -> cs_factor_probs
+ *   factor_net_ppo.py:108-130     compute_cosine_similarity    -> cs_cosine_features
+ *   factor_net_ppo.py:159-168     sample_action (gather part)  -> cs_sample_actions / cs_gather_actions
+ *   factor_net_ppo.py:170-184     get_action_probs             -> cs_action_probs
+ *   scheduler_ppo.py:222-232      zero-padded history stack    -> cs_stack_history
+ *   denoise_ppo.py:89-94          unet(latents, t, ctx)[0]     -> cs_unet_forward
+ *                                 (third-party diffusers UNet2DConditionModel, SD1.5 config)
+ *
+ * Conventions
+ *   - every pointer is a BORROWED DEVICE pointer unless its name ends in _host;
+ *   - every call is asynchronous on the hipStream_t passed as `stream`
+ *     (void* so that the header needs no HIP include);
+ *   - no allocation, no host synchronisation, no global state in the compute
+ *     entry points (they are graph-capturable); cs_unet_create/destroy own
+ *     device memory for packed weights;
+ *   - return value: 0 = CS_OK, negative = error (see below);
+ *     cs_last_error() returns a thread-local human readable message.
+ */
+#ifndef CONSOLVER_HIP_H
+#define CONSOLVER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+#define CS_MAX_ORDER 8        /* order_dim <= 8 */
+#define CS_MAX_ACTION_DIMS 16 /* order + scaler + mu - 1 */
+
+enum { CS_OK = 0, CS_E_ARG = -1, CS_E_SHAPE = -2, CS_E_DTYPE = -3, CS_E_HIP = -4, CS_E_STATE = -5, CS_E_UNSUPPORTED = -6 };
+enum { CS_F32 = 0, CS_F16 = 1, CS_BF16 = 2 };
+
+int cs_abi_version(void);
+const char* cs_error_string(int code);
+const char* cs_last_error(void);
+/* name of the device the library was built for ("gfx950") */
+const char* cs_target_arch(void);
+
+/* ------------------------------------------------------------------------
+ * Policy network (FactorNetPPO) : Linear-ReLU-Linear-ReLU-Linear + softmax
+ * ---------------------------------------------------------------------- */
+typedef struct CsFactorNet {
+    const float* w0; const float* b0; /* [hidden, in_dim], [hidden]             */
+    const float* w1; const float* b1; /* [hidden, hidden], [hidden]             */
+    const float* w2; const float* b2; /* [action_dims*num_actions, hidden], [.] */
+    int in_dim;        /* 2 (+ order_dim-1 when use_conv)                        */
+    int hidden;        /* <= 1024                                                */
+    int action_dims;   /* A <= CS_MAX_ACTION_DIMS                                */
+    int num_actions;   /* K <= 1024                                              */
+    float input_scale;     /* 1/999 for SD (factor_net_ppo.py:106), 1 for FLUX  */
+    float inv_temperature; /* 1 for SD, 100 for FLUX (softmax(logits/0.01))     */
+} CsFactorNet;
+
+/* probs[B, A, K] = softmax(MLP(cat(x * input_scale, cos_feat)) * inv_temperature).
+ * x: [B, 2] fp32.  cos_feat: [B, in_dim-2] fp32 or NULL when in_dim == 2.
+ * x_row_stride = 0 broadcasts one conditioning row to all B samples. */
+int cs_factor_probs(const CsFactorNet* net, const float* x, int x_row_stride, const float* cos_feat,
+                    int B, float* probs, void* stream);
+
+/* cos(eps[k], eps[0]) for k = 1..order-1 over the flattened sample; slots k >= m
+ * (zero padded in the reference) give 0.  hist[k]: [B, elems] newest first.
+ * out: [B, order-1] fp32. */
+int cs_cosine_features(const void* const* hist_host, int m, int order, int B, int64_t elems,
+                       int dtype, float* out, void* stream);
+
+/* inverse-CDF categorical sampling from probs[B,A,K] with caller supplied
+ * uniforms[B,A] in [0,1).  Writes idx[B,A] (int64), actions[B,A] = action_values[a, idx],
+ * action_probs[B,A] = probs[b,a,idx].  Any output pointer may be NULL. */
+int cs_sample_actions(const float* probs, const float* uniforms, const float* action_values,
+                      int B, int A, int K, int64_t* idx, float* actions, float* action_probs, void* stream);
+
+/* same gather with caller supplied indices (replay / torch.multinomial output). */
+int cs_gather_actions(const float* probs, const int64_t* idx, const float* action_values,
+                      int B, int A, int K, float* actions, float* action_probs, void* stream);
+
+/* PPO re-evaluation (factor_net_ppo.py:170-184): nearest-bin index of each action,
+ * selected probability and normalised entropy H/ln K.  All [B, A] fp32. */
+int cs_action_probs(const float* probs, const float* actions, const float* action_values,
+                    int B, int A, int K, float* selected, float* entropy, void* stream);
+
+/* masks[B, A] = 1 except columns [m-1, order-1) = 0 (scheduler_ppo.py:248-249). */
+int cs_step_masks(int B, int A, int m, int order, float* masks, void* stream);
+
+/* out[B, order, elems] = stack(hist newest first) zero padded (scheduler_ppo.py:222-232). */
+int cs_stack_history(const void* const* hist_host, int m, int order, int B, int64_t elems,
+                     int dtype, void* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused solver update
+ * ---------------------------------------------------------------------- */
+typedef struct CsStepArgs {
+    const void* x;            /* [B, elems] current sample                          */
+    const void* eps_text;     /* [B, elems] model output (conditional branch)       */
+    const void* eps_uncond;   /* [B, elems] unconditional branch, or NULL (no CFG)  */
+    float guidance;           /* eps = u + guidance * (c - u)                       */
+    const void* hist[CS_MAX_ORDER]; /* hist[k] = eps_{t-1-k}, k < m-1 (newest first) */
+    int m;                    /* history length AFTER pushing the new eps, 1..order */
+    int order_dim, scaler_dim;
+    const float* actions;     /* [B, actions_stride] sampled grid values, device    */
+    int actions_stride;
+    int B;
+    int64_t elems;            /* elements per sample                                */
+    int io_dtype;             /* dtype of x, eps_*, hist, eps_out                   */
+    int out_dtype;            /* dtype of x_out                                     */
+    void* x_out;              /* [B, elems]                                         */
+    void* eps_out;            /* [B, elems] CFG-combined eps (next steps' history)
+                                 required when eps_uncond != NULL, else optional     */
+    /* DDIM scalars (host fp32, scheduler_ppo.py:309-312): sqrt(a_t), sqrt(1-a_t),
+       sqrt(a_prev), sqrt(1-a_prev) */
+    float sqrt_at, sqrt_1mat, sqrt_ap, sqrt_1map;
+    int v_prediction;
+    /* Euler (flow matching): dt = sigma_next - sigma (scheduler_fmppo.py:376) */
+    float dt;
+} CsStepArgs;
+
+int cs_lms_ddim_step(const CsStepArgs* args, void* stream);
+int cs_lms_euler_step(const CsStepArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------
+ * SD1.5 UNet2DConditionModel forward (denoiser).  See DESIGN.md for the
+ * activation layout (NHWC fp16) and the kernels behind it.
+ * ---------------------------------------------------------------------- */
+typedef struct CsUNetConfig {
+    int in_channels, out_channels;     /* 4, 4                        */
+    int block_out_channels[4];         /* 320, 640, 1280, 1280        */
+    int layers_per_block;              /* 2                           */
+    int num_heads;                     /* 8 (attention_head_dim)      */
+    int cross_attention_dim;           /* 768                         */
+    int norm_num_groups;               /* 32                          */
+    int sample_size;                   /* 64 (latent H = W)           */
+    int ctx_len;                       /* 77                          */
+    int down_has_attn[4];              /* 1,1,1,0                     */
+    int up_has_attn[4];                /* 0,1,1,1                     */
+} CsUNetConfig;
+
+typedef struct CsUNet CsUNet;
+
+int cs_unet_create(const CsUNetConfig* cfg, CsUNet** out);
+void cs_unet_destroy(CsUNet* u);
+/* Upload one tensor by its diffusers state-dict name (e.g.
+ * "down_blocks.0.resnets.0.conv1.weight").  data_host: fp32 host memory in the
+ * PyTorch layout.  The library repacks into its own fp16 device layout. */
+int cs_unet_set_weight(CsUNet* u, const char* name, const float* data_host, const int64_t* shape, int ndim);
+/* number of tensors the config expects / names, for manifest checks */
+int cs_unet_num_weights(const CsUNet* u);
+const char* cs_unet_weight_name(const CsUNet* u, int i, int64_t* shape4, int* ndim);
+/* all weights present? pack; must be called once before forward */
+int cs_unet_finalize(CsUNet* u);
+size_t cs_unet_workspace_bytes(const CsUNet* u, int batch);
+/* FLOPs of one forward at `batch` samples (algorithmic, 2*MAC) */
+double cs_unet_flops(const CsUNet* u, int batch);
+
+/* latents: [n_lat, C, H, W] (NCHW, fp16).  The effective batch is
+ * n_lat * dup (dup = 2 for the CFG dual batch, sample b reads latent b % n_lat;
+ * gen_pretrain/pipeline.py:1054).  timesteps: device fp32 [1] or [batch].
+ * ctx: [batch, ctx_len, cross_attention_dim] fp16.  out: [batch, C, H, W] fp16.
+ * kv_cache_valid != 0 reuses the cross-attention K/V computed by a previous
+ * call with the same ctx (they do not depend on latents or t). */
+int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const float* timesteps,
+                    int n_timesteps, const void* ctx, void* out, void* workspace, size_t workspace_bytes,
+                    int kv_cache_valid, void* stream);
+
+/* per-kernel-class profile of the last forward recorded with events
+ * (enable with cs_unet_set_profiling(u, 1); adds synchronisation -- never in a timed run) */
+int cs_unet_set_profiling(CsUNet* u, int on);
+int cs_unet_profile_entries(const CsUNet* u);
+const char* cs_unet_profile_entry(const CsUNet* u, int i, double* ms, double* flops, double* bytes, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONSOLVER_HIP_H */

@@ -1,0 +1,138 @@
+"""CPU-side checks of the product's host logic and of the C-ABI surface (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import consolver_amd
+from consolver_amd import _lib, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "consolver_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    l = _lib.lib()
+    assert l.cs_abi_version() == 1 and l.cs_target_arch() == b"gfx950"
+    assert l.cs_error_string(-6) == b"not implemented"
+
+
+def test_struct_layout_matches_header():
+    # field order / sizes mirrored by hand in _lib.py; a C-side sizeof check guards it
+    assert ctypes.sizeof(_lib.CsFactorNet) == 6 * 8 + 4 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.CsStepArgs) % 8 == 0
+    l = _lib.lib()
+    a = _lib.CsStepArgs()
+    # argument validation happens before any launch -> usable without a GPU
+    assert l.cs_lms_ddim_step(ctypes.byref(a), None) == -1
+    assert b"required" in l.cs_last_error()
+    a.x = a.eps_text = a.x_out = 8
+    a.order_dim, a.m, a.scaler_dim = 4, 5, 0
+    assert l.cs_lms_ddim_step(ctypes.byref(a), None) == -1 and b"history length" in l.cs_last_error()
+    a.m, a.scaler_dim = 1, 3
+    assert l.cs_lms_ddim_step(ctypes.byref(a), None) == -6
+    a.scaler_dim, a.B = 0, 0
+    assert l.cs_lms_ddim_step(ctypes.byref(a), None) == 0     # empty batch is a no-op
+
+
+@pytest.mark.parametrize("spacing,off", [("trailing", 0), ("leading", 0), ("leading", 1), ("linspace", 0)])
+def test_scheduler_timestep_grids_bit_exact(golden, spacing, off):
+    g = golden["sd_tables"]
+    flat, offs = g[f"ts_{spacing}_off{off}"], g[f"ts_{spacing}_off{off}_offsets"]
+    s = consolver_amd.PPOScheduler(timestep_spacing=spacing, steps_offset=off,
+                                   factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+    for n in range(1, 51):
+        want = flat[offs[n - 1]:offs[n]]
+        if want.min() < 0 or want.max() > 999:
+            with pytest.raises(ValueError):
+                s.set_timesteps(n)
+            continue
+        s.set_timesteps(n)
+        assert s.timesteps.dtype == torch.int64 and np.array_equal(s.timesteps.numpy(), want)
+        assert s.ets == [] and s.num_inference_steps == n
+
+
+def test_scheduler_tables_and_protocol(golden):
+    g = golden["sd_tables"]
+    s = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                   timestep_spacing="trailing", order_dim=4, scaler_dim=0,
+                                   factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=11))
+    np.testing.assert_allclose(s.alphas_cumprod.numpy(), g["ac_scaled_linear"], rtol=2e-6)
+    assert s.init_noise_sigma == 1.0 and s.order == 1 and "DDIMScheduler" in s._compatibles and len(s) == 1000
+    assert s.config.order_dim == 4 and s.config.get("scaler_dim") == 0 and s.config["beta_schedule"] == "scaled_linear"
+    x = torch.zeros(1, 4, 8, 8)
+    assert s.scale_model_input(x, 5) is x
+    with pytest.raises(ValueError):
+        s.step(x, 999, x)                      # before set_timesteps (scheduler_ppo.py:199-200)
+    with pytest.raises(ValueError):
+        s.set_timesteps(1001)
+    with pytest.raises(ValueError):
+        s.set_timesteps(61)                    # reference grid would end in -1
+    s.set_timesteps(8)
+    with pytest.raises(RuntimeError, match="no|CUDA|HIP"):
+        s.step(x, 999, x)                      # CPU tensors: fail loudly, never fall back
+    # state dict layout (train_ppo.py:174-190 checkpoints)
+    sd = s.factor_net.state_dict()
+    assert list(sd) == ["action_values", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias",
+                        "mlp.4.weight", "mlp.4.bias"]
+    assert sd["action_values"].shape == (3, 11) and sd["mlp.4.weight"].shape == (33, 256)
+    assert sum(v.numel() for k, v in sd.items() if k != "action_values") == 75041
+    assert float(sd["mlp.4.weight"].abs().max()) == 0.0        # zero-init last layer
+    with pytest.raises(NotImplementedError):
+        consolver_amd.PPOScheduler(beta_schedule="nope")
+    with pytest.raises(ValueError):
+        consolver_amd.PPOScheduler(timestep_spacing="nope", factor_net_kwargs=dict(hidden_dim=8, num_actions=3)).set_timesteps(4)
+
+
+def test_action_value_grids(golden):
+    g = golden["sd_factor_net"]
+    for ci, (o, sc, uc, K, H) in enumerate(g["cases"]):
+        net = consolver_amd.FactorNetPPO(hidden_dim=int(H), num_actions=int(K), order_dim=int(o), scaler_dim=int(sc),
+                                         use_conv=bool(uc))
+        np.testing.assert_allclose(net.action_values.numpy(), g[f"c{ci}_w_action_values"], atol=2e-7, rtol=0)
+        assert net.mlp[0].in_features == 2 + (o - 1 if uc else 0)
+    g = golden["flux"]
+    for ci, (o, sc, mu, uc, K, H) in enumerate(g["fn_cases"]):
+        net = consolver_amd.FluxFactorNetPPO(hidden_dim=int(H), num_actions=int(K), order_dim=int(o),
+                                             scaler_dim=int(sc), mu_dim=int(mu), use_conv=bool(uc))
+        np.testing.assert_allclose(net.action_values.numpy(), g[f"f{ci}_w_action_values"], atol=2e-7, rtol=0)
+        assert net.action_dims == o + sc + mu - 1
+
+
+def test_flux_scheduler_tables(golden):
+    g = golden["flux"]
+    for n in range(2, 9):
+        s = consolver_amd.FMPPOScheduler.from_pretrained("black-forest-labs/FLUX.1-Kontext-dev", subfolder="scheduler",
+                                                         order_dim=2, scaler_dim=0, mu_dim=0,
+                                                         factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+        assert s.config.get("base_image_seq_len", 256) == 256 and s.config.use_dynamic_shifting
+        s.set_timesteps(sigmas=np.linspace(1.0, 1 / n, n), mu=1.15)
+        np.testing.assert_allclose(s.sigmas.numpy(), g[f"sig_dyn_n{n}"], rtol=2e-7)
+        np.testing.assert_allclose(s.timesteps.numpy(), g[f"ts_dyn_n{n}"], rtol=2e-7)
+        assert s.step_index is None and s.begin_index is None
+        s2 = consolver_amd.FMPPOScheduler(shift=3.0, order_dim=2, scaler_dim=0, mu_dim=0,
+                                          factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+        s2.set_timesteps(n)
+        np.testing.assert_allclose(s2.sigmas.numpy(), g[f"sig_static_n{n}"], rtol=2e-7)
+    s = consolver_amd.FMPPOScheduler(use_dynamic_shifting=True, order_dim=2, scaler_dim=0, mu_dim=0,
+                                     factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+    with pytest.raises(ValueError):
+        s.set_timesteps(sigmas=[1.0, 0.5])                      # mu missing
+    with pytest.raises(ValueError):
+        s.set_timesteps(3, sigmas=[1.0, 0.5], mu=1.0)           # length mismatch
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1, 4, 4), 1.0, torch.zeros(1, 4, 4))  # before set_timesteps
+    s.set_timesteps(sigmas=[1.0, 0.5], mu=1.0)
+    with pytest.raises(ValueError):
+        s.step(torch.zeros(1, 4, 4), 3, torch.zeros(1, 4, 4))    # integer timestep
+    assert abs(tables.calculate_shift(4096) - 1.15) < 1e-12
