@@ -18,9 +18,14 @@ ARCH = "gfx950"
 SOURCES = {
     "api.cpp": [],
     "solver.hip": ["-ffp-contract=off"],   # torch-like separate mul/add roundings
+    "igemm.hip": [],
+    "attention.hip": [],
+    "norm.hip": [],
+    "misc.hip": [],
     "unet.cpp": [],
+    "ops_api.cpp": [],
 }
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(os.path.dirname(PKG), "include")]
 
 

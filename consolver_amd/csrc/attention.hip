@@ -1,0 +1,272 @@
+// Fused (flash-style) attention forward for the SD1.5 head sizes 40 / 80 / 160 on gfx950.
+//
+//   out[b, q, h, :] = softmax(scale * Q K^T) V        (no mask; self and cross attention)
+//
+// Design (wave64 / MFMA 16x16x32 f16, not a warp-shaped port):
+//   * workgroup = 4 waves; each wave owns QT*16 query rows of one (batch, head) and walks the keys in
+//     tiles of 64; K/V tiles are shared through LDS (register-staged, double buffered, one barrier
+//     per tile: loads for tile t+1 are issued before tile t's MFMAs and written after them);
+//   * scores are computed TRANSPOSED, S^T = K Q^T (K = MFMA A operand, Q = B operand), so every lane
+//     owns one query column: the online-softmax max/sum are register reductions + 2 shuffles, and the
+//     exponentiated tile is already laid out as the B operand of the second product
+//     O^T = V^T P^T  -- P never touches LDS;
+//   * V^T fragments come from the row-major V tile with the gfx950 transposing LDS read
+//     (ds_read_b64_tr_b16); row strides are chosen so that both the ds_read_b128 K reads
+//     (stride = 16 B mod 32 B) and the transposed V reads (odd multiple of 32 B) are conflict free;
+//   * the MFMA k-index <-> key permutation induced by reusing the accumulator layout as an operand
+//     (keys 4g..4g+3 and 16+4g..16+4g+3 per lane group g) is applied identically to the V reads;
+//   * head dims are zero-padded in registers/LDS only (40 -> 64 for Q K^T, 40 -> 48 for P V);
+//   * O^T leaves each lane with 4 consecutive channels of one query row -> 8-byte stores.
+#include "ops.h"
+#include <stdlib.h>
+
+namespace {
+
+struct AttnParams {
+    const f16* q; const f16* k; const f16* v; f16* out;
+    int q_stride, k_stride, v_stride, out_stride;
+    int H, Nq, Nk;
+    float c;   // scale * log2(e)
+};
+
+typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) hf4* lds_hf4_ptr;
+
+__device__ __forceinline__ f16x4 tr_read(const char* lds_addr) {
+    hf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf4_ptr)lds_addr);
+    union { hf4 a; f16x4 b; } u; u.a = r;
+    return u.b;
+}
+
+template <int DH, int QT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+    constexpr int DK = (DH + 31) / 32 * 32;
+    constexpr int KSTEPS = DK / 32;
+    constexpr int DVT = (DH + 15) / 16;
+    constexpr int DVP = DVT * 16;
+    constexpr int KS = DK * 2 + 16;                                   // bytes per K row in LDS
+    constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;  // odd multiple of 32 B
+    constexpr int CPR = DH / 8;                                       // 16-byte chunks per K/V row
+    constexpr int NCH = (64 * CPR + 255) / 256;
+    constexpr int KBUF = 64 * KS, VBUF = 64 * VS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const lK = smem;               // [2][KBUF]
+    char* const lV = smem + 2 * KBUF;    // [2][VBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (4 * QT * 16) + w * (QT * 16);
+
+    // zero both buffers once: pad columns stay zero, tails are rewritten with zeros explicitly
+    for (int o = tid * 16; o < 2 * KBUF + 2 * VBUF; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
+
+    // ---- Q fragments (B operand: lane = query column i16, k = 8g + j) ---------------------------
+    f16x8 qf[QT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qrow = q0 + t * 16 + i16;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int d = ks * 32 + 8 * g;
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qrow < p.Nq && d < DH)
+                v = *reinterpret_cast<const f16x8*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+            qf[t][ks] = v;
+        }
+    }
+
+    f32x4 o_acc[DVT][QT];
+#pragma unroll
+    for (int a = 0; a < DVT; ++a)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) o_acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { m_run[t] = -1e30f; l_run[t] = 0.f; }
+
+    const int ntiles = (p.Nk + 63) / 64;
+    const f16* kbase = p.k + (size_t)b * p.Nk * p.k_stride + h * DH;
+    const f16* vbase = p.v + (size_t)b * p.Nk * p.v_stride + h * DH;
+
+    u32x4 kreg[NCH], vreg[NCH];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int id = tid + c * 256;
+            const int row = id / CPR, ch = id - row * CPR;
+            const int key = tile * 64 + row;
+            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+            if (id < 64 * CPR && key < p.Nk) {
+                kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * p.k_stride + ch * 8);
+                vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * p.v_stride + ch * 8);
+            }
+            kreg[c] = kv; vreg[c] = vv;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int id = tid + c * 256;
+            const int row = id / CPR, ch = id - row * CPR;
+            if (id < 64 * CPR) {
+                *reinterpret_cast<u32x4*>(lK + buf * KBUF + row * KS + ch * 16) = kreg[c];
+                *reinterpret_cast<u32x4*>(lV + buf * VBUF + row * VS + ch * 16) = vreg[c];
+            }
+        }
+    };
+
+    load_tile(0);
+    __syncthreads();            // zero fill complete
+    store_tile(0);
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < ntiles) load_tile(tile + 1);
+        const char* tk = lK + buf * KBUF;
+        const char* tv = lV + buf * VBUF;
+
+        // ---- S^T = K Q^T : s[kt][t] holds keys kt*16 + 4g + r, query column i16 -------------------
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(tk + (kt * 16 + i16) * KS + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[kt][t], 0, 0, 0);
+            }
+        }
+        if (tile * 64 + 64 > p.Nk) {   // ragged last tile: mask keys >= Nk
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tile * 64 + kt * 16 + 4 * g + r >= p.Nk) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) s[kt][t][r] = -INFINITY;
+                    }
+        }
+
+        // ---- online softmax per query column ------------------------------------------------------
+        f16x8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mx = s[0][t][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const float alpha = exp2f(p.c * (m_run[t] - m_new));
+            const float cm = p.c * m_new;
+            m_run[t] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(s[kt][t][r] * p.c - cm);
+                    s[kt][t][r] = e;
+                    ps += e;
+                }
+            l_run[t] = l_run[t] * alpha + ps;
+#pragma unroll
+            for (int a = 0; a < DVT; ++a) o_acc[a][t] *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f16x8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f[r] = (f16)s[2 * t2][t][r]; f[4 + r] = (f16)s[2 * t2 + 1][t][r]; }
+                pf[t][t2] = f;
+            }
+        }
+
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int a = 0; a < DVT; ++a) {
+                const char* addr = tv + (32 * t2 + 4 * g + (i16 >> 2)) * VS + (a * 16 + 4 * (i16 & 3)) * 2;
+                const f16x4 lo = tr_read(addr);
+                const f16x4 hi = tr_read(addr + 16 * VS);
+                const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o_acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][t2], o_acc[a][t], 0, 0, 0);
+            }
+        }
+
+        if (tile + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + t * 16 + i16;
+        if (qrow >= p.Nq) continue;
+        f16* orow = p.out + (size_t)(b * p.Nq + qrow) * p.out_stride + h * DH;
+#pragma unroll
+        for (int a = 0; a < DVT; ++a) {
+            const int d = a * 16 + 4 * g;
+            if (d + 4 <= DH) {
+                f16x4 o = {(f16)(o_acc[a][t][0] * inv), (f16)(o_acc[a][t][1] * inv), (f16)(o_acc[a][t][2] * inv), (f16)(o_acc[a][t][3] * inv)};
+                *reinterpret_cast<f16x4*>(orow + d) = o;
+            }
+        }
+    }
+}
+
+template <int DH, int QT>
+int launch_attn(const AttnParams& p, int B, hipStream_t s) {
+    constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
+    constexpr int KS = DK * 2 + 16;
+    constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
+    constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
+    auto kfn = attn_kernel<DH, QT>;
+    static bool configured = false;
+    if (!configured) {
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    dim3 grid((p.Nq + 4 * QT * 16 - 1) / (4 * QT * 16), p.H, B);
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+}  // namespace
+
+int launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (!a.q || !a.k || !a.v || !a.out) CS_FAIL(CS_E_ARG, "attention: null pointer");
+    if (a.B <= 0 || a.Nq <= 0) return a.B < 0 ? CS_E_SHAPE : CS_OK;
+    if (a.Nk <= 0) CS_FAIL(CS_E_SHAPE, "attention: Nk must be positive");
+    if ((a.q_stride | a.k_stride | a.v_stride | a.out_stride) & 7) CS_FAIL(CS_E_SHAPE, "attention: strides must be multiples of 8 halfs");
+    AttnParams p;
+    p.q = a.q; p.k = a.k; p.v = a.v; p.out = a.out;
+    p.q_stride = a.q_stride; p.k_stride = a.k_stride; p.v_stride = a.v_stride; p.out_stride = a.out_stride;
+    p.H = a.H; p.Nq = a.Nq; p.Nk = a.Nk;
+    p.c = a.scale * 1.4426950408889634f;
+    switch (a.dh) {
+        case 40: {
+            static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 2;   // tuning knob
+            if (qt == 4) return launch_attn<40, 4>(p, a.B, s);
+            if (qt == 3) return launch_attn<40, 3>(p, a.B, s);
+            return launch_attn<40, 2>(p, a.B, s);
+        }
+        case 80: return launch_attn<80, 2>(p, a.B, s);
+        case 160: return launch_attn<160, 1>(p, a.B, s);
+        default: CS_FAIL(CS_E_UNSUPPORTED, "attention: head dim %d not built (40/80/160)", a.dh);
+    }
+}

@@ -1,0 +1,167 @@
+// Small ops at the edges of the denoiser: timestep embedding MLP, tiny-M linear (time_emb_proj),
+// conv_in (NCHW latents, 4 channels -> NHWC) and conv_out (NHWC -> NCHW, 4 channels).
+// None of them is on the FLOP-critical path (<0.1 % of the forward); they are written to be
+// coalesced and launch-light, not MFMA-shaped.
+#include "ops.h"
+
+namespace {
+
+// emb[b][0:half] = cos(t * f_i), emb[b][half:] = sin(t * f_i), f_i = exp(-ln(10000) * i / half)
+// (diffusers Timesteps(320, flip_sin_to_cos=True, downscale_freq_shift=0); cast to fp16 like t_emb.to(dtype))
+__global__ void sinusoid_kernel(const float* __restrict__ t, int Bt, int C0, f16* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = C0 / 2;
+    if (i >= Bt * half) return;
+    const int b = i / half, k = i - b * half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[b] * f;
+    out[(size_t)b * C0 + k] = (f16)cosf(a);
+    out[(size_t)b * C0 + half + k] = (f16)sinf(a);
+}
+
+// out[r][n] = act(sum_k x[r][k] w[n][k] + b[n]) ; one wave per output column n, rows looped (R small)
+__global__ __launch_bounds__(256) void rowvec_linear_kernel(const f16* __restrict__ x, int R, int K, const f16* __restrict__ w,
+                                                            const f16* __restrict__ bias, int N, f16* __restrict__ out, int act_silu) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int KV = K >> 3;
+    for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+        for (int kv = lane; kv < KV; kv += 64) {
+            const f16x8 wv = *reinterpret_cast<const f16x8*>(w + (size_t)n * K + kv * 8);
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + (size_t)r * K + kv * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (float)wv[k] * (float)xv[k];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc + (bias ? (float)bias[n] : 0.f);
+            if (act_silu) v = v / (1.0f + __expf(-v));
+            out[(size_t)r * N + n] = (f16)v;
+        }
+    }
+}
+
+// conv_in: thread = (pixel, 8 output channels).  weights [Cout][9][Cin] staged in LDS as [9*Cin][Cout].
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ lat, int n_lat, int B, int H, int W,
+                                                      const f16* __restrict__ w, const f16* __restrict__ bias, int Cout,
+                                                      f16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) f16 ws[];   // [9*CIN][Cout]
+    constexpr int KK = 9 * CIN;
+    for (int i = threadIdx.x; i < KK * Cout; i += blockDim.x) {
+        const int n = i / KK, k = i - n * KK;
+        ws[k * Cout + n] = w[i];
+    }
+    __syncthreads();
+    const int NG = Cout >> 3;
+    const long total = (long)B * H * W * NG;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ng = (int)(i % NG);
+        const long m = i / NG;
+        const int xo = (int)(m % W), yo = (int)((m / W) % H), b = (int)(m / ((long)W * H));
+        const f16* src = lat + (size_t)(b % n_lat) * CIN * H * W;
+        float acc[8];
+        const f16x8 bv = *reinterpret_cast<const f16x8*>(bias + ng * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = (float)bv[k];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yi = yo + tap / 3 - 1, xi = xo + tap % 3 - 1;
+            if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float v = (float)src[((size_t)c * H + yi) * W + xi];
+                const f16x8 wv = *reinterpret_cast<const f16x8*>(ws + (tap * CIN + c) * Cout + ng * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v * (float)wv[k];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+        *reinterpret_cast<f16x8*>(out + (size_t)m * Cout + ng * 8) = o;
+    }
+}
+
+// conv_out: one wave per output pixel, lanes over 8-channel vectors of the NHWC input
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x, int B, int Cin, int H, int W,
+                                                       const f16* __restrict__ w, const f16* __restrict__ bias, f16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (long)B * H * W) return;
+    const int xo = (int)(m % W), yo = (int)((m / W) % H), b = (int)(m / ((long)W * H));
+    const int CV = Cin >> 3;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yi = yo + tap / 3 - 1, xi = xo + tap % 3 - 1;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;      // wave-uniform
+        const f16* px = x + (((size_t)b * H + yi) * W + xi) * Cin;
+        for (int cv = lane; cv < CV; cv += 64) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(px + cv * 8);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const f16x8 wv = *reinterpret_cast<const f16x8*>(w + ((size_t)o * 9 + tap) * Cin + cv * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[o] += (float)v[k] * (float)wv[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane < COUT) {
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) if (lane == o) v = acc[o];
+        out[(((size_t)b * COUT + lane) * H + yo) * W + xo] = (f16)(v + (float)bias[lane]);
+    }
+}
+
+}  // namespace
+
+int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16* b, int N, f16* out, int act_silu, hipStream_t s) {
+    if (!x || !w || !out) CS_FAIL(CS_E_ARG, "rowvec_linear: null pointer");
+    if (K % 8) CS_FAIL(CS_E_SHAPE, "rowvec_linear: K=%d must be a multiple of 8", K);
+    if (R <= 0 || N <= 0) return CS_OK;
+    hipLaunchKernelGGL(rowvec_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, R, K, w, b, N, out, act_silu);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, const f16* b1, const f16* w2, const f16* b2,
+                          f16* scratch, f16* out_silu, hipStream_t s) {
+    if (!t || !scratch || !out_silu) CS_FAIL(CS_E_ARG, "time_embedding: null pointer");
+    f16* emb = scratch;                      // [Bt][C0]
+    f16* h1 = scratch + (size_t)Bt * C0;     // [Bt][D]
+    const int n = Bt * (C0 / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, Bt, C0, emb);
+    CS_CHECK_LAUNCH();
+    int rc = launch_rowvec_linear(emb, Bt, C0, w1, b1, D, h1, 1, s);           // linear_1 + SiLU
+    if (rc) return rc;
+    return launch_rowvec_linear(h1, Bt, D, w2, b2, D, out_silu, 1, s);         // linear_2, then the resnets' SiLU
+}
+
+int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s) {
+    if (!lat || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_in: null pointer");
+    if (Cin != 4 || Cout % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_in: built for 4 input channels (got %d)", Cin);
+    if (B <= 0) return CS_OK;
+    const long total = (long)B * H * W * (Cout / 8);
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(conv_in_kernel<4>, dim3(grid), dim3(256), (size_t)36 * Cout * sizeof(f16), s, lat, n_lat, B, H, W, w, bias, Cout, out);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s) {
+    if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out: null pointer");
+    if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
+    if (B <= 0) return CS_OK;
+    const long M = (long)B * H * W;
+    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

@@ -1,0 +1,194 @@
+// HBM-bound glue of the denoiser: GroupNorm(+SiLU) over NHWC (two-source concat aware),
+// LayerNorm over token rows.  All loads/stores are 16 bytes per lane; reductions are
+// wave-shuffle + LDS, deterministic (no atomics).
+#include "ops.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- GroupNorm
+// pass 1: per (sample, row split) per-channel partial sums.  blockDim = (C/8) * R with R rows in
+// flight, so a thread's 8-channel vector index is fixed while it strides over rows.
+__global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_off, int Ctot, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [R][C/8][16]
+    const int CV = C >> 3;
+    const int cv = threadIdx.x % CV, rr = threadIdx.x / CV, R = blockDim.x / CV;
+    const int s = blockIdx.x, b = blockIdx.y, S = gridDim.x;
+    const int rows = HW / S, r0 = s * rows;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sum[k] = 0.f; sq[k] = 0.f; }
+    const f16* base = x + ((size_t)b * HW + r0) * C + cv * 8;
+    for (int r = rr; r < rows; r += R) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)r * C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; sum[k] += f; sq[k] += f * f; }
+    }
+    float* mine = red + ((size_t)rr * CV + cv) * 16;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mine[k] = sum[k]; mine[8 + k] = sq[k]; }
+    __syncthreads();
+    if (rr == 0) {
+        for (int j = 1; j < R; ++j) {
+            const float* o = red + ((size_t)j * CV + cv) * 16;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sum[k] += o[k]; sq[k] += o[8 + k]; }
+        }
+        float* dst = partial + (((size_t)b * S + s) * Ctot + c_off + cv * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dst[2 * k] = sum[k]; dst[2 * k + 1] = sq[k]; }
+    }
+}
+
+// pass 2: one block per sample: reduce the splits, group statistics, per-channel scale/shift
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
+                                   const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];    // [2*Ctot] channel sums, then [2*groups]
+    float* chs = sm; float* chq = sm + Ctot; float* gm = sm + 2 * Ctot; float* gr = gm + groups;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
+        float a = 0.f, q = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float* p = partial + (((size_t)b * S + s) * Ctot + c) * 2;
+            a += p[0]; q += p[1];
+        }
+        chs[c] = a; chq[c] = q;
+    }
+    __syncthreads();
+    const int cpg = Ctot / groups;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        float a = 0.f, q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; q += chq[c]; }
+        const float n = (float)cpg * (float)HW;
+        const float mean = a / n;
+        const float var = fmaxf(q / n - mean * mean, 0.f);
+        gm[g] = mean; gr[g] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = (float)gamma[c] * gr[g];
+        scale_shift[((size_t)b * Ctot + c) * 2] = sc;
+        scale_shift[((size_t)b * Ctot + c) * 2 + 1] = (float)beta[c] - gm[g] * sc;
+    }
+}
+
+// pass 3: y = [silu](x * scale + shift), two-source read, single [B][HW][Ctot] output
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
+                                                       int HW, const float* __restrict__ scale_shift, f16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float ss[];    // [Ctot][2]
+    const int Ctot = c0 + c1, CV = Ctot >> 3;
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * Ctot; i += blockDim.x) ss[i] = scale_shift[(size_t)b * Ctot * 2 + i];
+    __syncthreads();
+    const int rows_per_blk = (HW + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_blk;
+    const int r1 = min(HW, r0 + rows_per_blk);
+    const long nvec = (long)(r1 - r0) * CV;
+    for (long i = threadIdx.x; i < nvec; i += blockDim.x) {
+        const int r = r0 + (int)(i / CV), cv = (int)(i % CV);
+        const int c = cv * 8;
+        const f16* src = (c < c0) ? x0 + ((size_t)b * HW + r) * c0 + c : x1 + ((size_t)b * HW + r) * c1 + (c - c0);
+        const f16x8 v = *reinterpret_cast<const f16x8*>(src);
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float y = (float)v[k] * ss[2 * (c + k)] + ss[2 * (c + k) + 1];
+            if (SILU) y = y / (1.0f + __expf(-y));
+            o[k] = (f16)y;
+        }
+        *reinterpret_cast<f16x8*>(out + ((size_t)b * HW + r) * Ctot + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------- LayerNorm
+// one wave per token row, row kept in registers (C <= 8 * 64 * MAXV), two-pass variance
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                 f16* __restrict__ out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= M) return;
+    const int CV = C >> 3;
+    float v[MAXV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + cv * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[j][k] = (float)t[k]; sum += v[j][k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (lane + 64 * j < CV) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const f16x8 gv = *reinterpret_cast<const f16x8*>(gamma + cv * 8);
+            const f16x8 bv = *reinterpret_cast<const f16x8*>(beta + cv * 8);
+            f16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (f16)((v[j][k] - mean) * rstd * (float)gv[k] + (float)bv[k]);
+            *reinterpret_cast<f16x8*>(out + (size_t)row * C + cv * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
+    const int Ctot = a.c0 + a.c1;
+    if (!a.x0 || !a.out || !a.partial || !a.gamma || !a.beta) CS_FAIL(CS_E_ARG, "group_norm: null pointer");
+    if (a.c0 % 8 || a.c1 % 8 || Ctot % a.groups) CS_FAIL(CS_E_SHAPE, "group_norm: channels (%d,%d) groups %d", a.c0, a.c1, a.groups);
+    if (a.B <= 0 || a.HW <= 0) return a.B < 0 ? CS_E_SHAPE : CS_OK;
+    int S = GN_SPLITS;
+    while (S > 1 && (a.HW % S)) S >>= 1;
+    float* scale_shift = a.partial + (size_t)a.B * GN_SPLITS * Ctot * 2;
+    for (int src = 0; src < 2; ++src) {
+        const f16* x = src ? a.x1 : a.x0;
+        const int C = src ? a.c1 : a.c0;
+        if (!C) continue;
+        const int CV = C / 8;
+        int R = 256 / CV; if (R < 1) R = 1;
+        const int T = CV * R;
+        if (T > 1024) CS_FAIL(CS_E_SHAPE, "group_norm: C=%d too wide", C);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(S, a.B), dim3(T), (size_t)T * 16 * sizeof(float), s, x, C, a.HW, src ? a.c0 : 0, Ctot, a.partial);
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), (size_t)(2 * Ctot + 2 * a.groups) * sizeof(float), s,
+                       a.partial, S, Ctot, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
+    int chunks = (a.HW * (Ctot / 8) + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
+    if (chunks < 1) chunks = 1;
+    if (chunks > a.HW) chunks = a.HW;
+    const size_t lds = (size_t)2 * Ctot * sizeof(float);
+    if (a.silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s) {
+    if (!x || !gamma || !beta || !out) CS_FAIL(CS_E_ARG, "layer_norm: null pointer");
+    if (C % 8 || C > 8 * 64 * 4) CS_FAIL(CS_E_SHAPE, "layer_norm: C=%d unsupported", C);
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    const dim3 grid((M + 3) / 4), block(256);
+    const int nv = (C / 8 + 63) / 64;
+    if (nv <= 1) hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
+    else if (nv == 2) hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
+    else if (nv == 3) hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
+    else hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

@@ -1,0 +1,62 @@
+// C ABI wrappers of the op-level launchers (include/consolver_hip_ops.h)
+#include "ops.h"
+#include "../../include/consolver_hip_ops.h"
+#include <cstring>
+
+extern "C" {
+
+int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
+                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out, void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x0; a.a1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi;
+    if (stride != 1 && stride != 2) CS_FAIL(CS_E_ARG, "conv2d: stride must be 1 or 2");
+    a.Ho = upsample ? 2 * Hi : (stride == 2 ? Hi / 2 : Hi);
+    a.Wo = upsample ? 2 * Wi : (stride == 2 ? Wi / 2 : Wi);
+    a.taps = taps; a.stride = stride; a.upsample = upsample; a.N = N; a.w = (const f16*)w; a.bias = (const f16*)bias;
+    a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_linear(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, void* out, int geglu, void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
+    a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out; a.geglu = geglu;
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_geglu_pack(const void* w_host, const void* b_host, int Hd, int K, void* w_out_host, void* b_out_host) {
+    if (!w_host || !w_out_host || Hd % 16) CS_FAIL(CS_E_ARG, "geglu_pack: bad arguments");
+    const f16* w = (const f16*)w_host; const f16* b = (const f16*)b_host; f16* wo = (f16*)w_out_host; f16* bo = (f16*)b_out_host;
+    for (int P = 0; P < Hd / 16; ++P)
+        for (int i = 0; i < 16; ++i) {
+            memcpy(wo + (size_t)(32 * P + i) * K, w + (size_t)(16 * P + i) * K, (size_t)K * sizeof(f16));
+            memcpy(wo + (size_t)(32 * P + 16 + i) * K, w + (size_t)(Hd + 16 * P + i) * K, (size_t)K * sizeof(f16));
+            if (b && bo) { bo[32 * P + i] = b[16 * P + i]; bo[32 * P + 16 + i] = b[Hd + 16 * P + i]; }
+        }
+    return CS_OK;
+}
+
+int cs_op_attention(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                    int B, int H, int Nq, int Nk, int dh, float scale, void* stream) {
+    AttnArgs a{};
+    a.q = (const f16*)q; a.q_stride = q_stride; a.k = (const f16*)k; a.k_stride = k_stride; a.v = (const f16*)v; a.v_stride = v_stride;
+    a.out = (f16*)out; a.out_stride = out_stride; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh; a.scale = scale;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
+size_t cs_op_group_norm_workspace(int B, int C) { return (size_t)B * (GN_SPLITS + 1) * C * 2 * sizeof(float); }
+
+int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,
+                     const void* gamma, const void* beta, void* workspace, void* out, void* stream) {
+    GroupNormArgs a{};
+    a.x0 = (const f16*)x0; a.x1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
+    a.gamma = (const f16*)gamma; a.beta = (const f16*)beta; a.partial = (float*)workspace; a.out = (f16*)out;
+    return launch_group_norm(a, (hipStream_t)stream);
+}
+
+int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream) {
+    return launch_layer_norm((const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)out, M, C, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -172,17 +172,18 @@ __global__ __launch_bounds__(256) void lms_step_kernel(StepParams p) {
 template <bool EULER>
 int launch_step(const CsStepArgs* a, void* stream) {
     if (!a) CS_FAIL(CS_E_ARG, "args is NULL");
-    if (!a->x || !a->eps_text || !a->x_out) CS_FAIL(CS_E_ARG, "x, eps_text and x_out are required");
+    if (a->B < 0 || a->elems < 0) CS_FAIL(CS_E_SHAPE, "negative shape");
+    const bool empty = (a->B == 0 || a->elems == 0);
+    if (!empty && (!a->x || !a->eps_text || !a->x_out)) CS_FAIL(CS_E_ARG, "x, eps_text and x_out are required");
     if (a->order_dim < 1 || a->order_dim > CS_MAX_ORDER) CS_FAIL(CS_E_ARG, "order_dim %d out of range [1,%d]", a->order_dim, CS_MAX_ORDER);
     if (a->scaler_dim < 0 || a->scaler_dim > 2) CS_FAIL(CS_E_UNSUPPORTED, "scaler_dim %d > 2 is not implemented (scheduler_ppo.py:280)", a->scaler_dim);
     if (a->m < 1 || a->m > a->order_dim) CS_FAIL(CS_E_ARG, "history length m=%d not in [1, order_dim=%d]", a->m, a->order_dim);
-    if (a->B < 0 || a->elems < 0) CS_FAIL(CS_E_SHAPE, "negative shape");
+    if (empty) return CS_OK;
     if ((a->m > 1 || a->scaler_dim > 0) && !a->actions) CS_FAIL(CS_E_ARG, "actions required when m > 1 or scaler_dim > 0");
     if (a->actions && a->actions_stride < a->order_dim + a->scaler_dim - 1) CS_FAIL(CS_E_SHAPE, "actions_stride %d < order+scaler-1", a->actions_stride);
     if (a->eps_uncond && !a->eps_out) CS_FAIL(CS_E_ARG, "eps_out is required with CFG (the combined eps is the history entry)");
     for (int k = 0; k < a->m - 1; ++k)
         if (!a->hist[k]) CS_FAIL(CS_E_ARG, "hist[%d] is NULL but m=%d", k, a->m);
-    if (a->B == 0 || a->elems == 0) return CS_OK;
     StepParams p;
     p.x = a->x; p.ec = a->eps_text; p.eu = a->eps_uncond; p.g = a->guidance;
     for (int k = 0; k < CS_MAX_ORDER; ++k) p.hist[k] = a->hist[k];
@@ -373,15 +374,16 @@ int cs_lms_ddim_step(const CsStepArgs* args, void* stream) { return launch_step<
 int cs_lms_euler_step(const CsStepArgs* args, void* stream) { return launch_step<true>(args, stream); }
 
 int cs_factor_probs(const CsFactorNet* n, const float* x, int x_row_stride, const float* cos_feat, int B, float* probs, void* stream) {
-    if (!n || !x || !probs) CS_FAIL(CS_E_ARG, "net, x and probs are required");
+    if (!n) CS_FAIL(CS_E_ARG, "net is NULL");
+    if (B < 0) CS_FAIL(CS_E_SHAPE, "negative batch");
+    if (B == 0) return CS_OK;
+    if (!x || !probs) CS_FAIL(CS_E_ARG, "x and probs are required");
     if (!n->w0 || !n->b0 || !n->w1 || !n->b1 || !n->w2 || !n->b2) CS_FAIL(CS_E_ARG, "missing weight pointer");
     if (n->in_dim < 2 || n->in_dim > 16) CS_FAIL(CS_E_SHAPE, "in_dim %d not in [2,16]", n->in_dim);
     if (n->hidden < 1 || n->hidden > 1024) CS_FAIL(CS_E_SHAPE, "hidden %d not in [1,1024]", n->hidden);
     if (n->action_dims < 1 || n->action_dims > CS_MAX_ACTION_DIMS) CS_FAIL(CS_E_SHAPE, "action_dims %d out of range", n->action_dims);
     if (n->num_actions < 1 || n->num_actions > 1024) CS_FAIL(CS_E_SHAPE, "num_actions %d out of range", n->num_actions);
     if (n->in_dim > 2 && !cos_feat) CS_FAIL(CS_E_ARG, "use_conv=True requires epsilon (factor_net_ppo.py:109-110)");
-    if (B < 0) CS_FAIL(CS_E_SHAPE, "negative batch");
-    if (B == 0) return CS_OK;
     size_t lds = (16 + 2 * (size_t)n->hidden + (size_t)n->action_dims * n->num_actions) * sizeof(float);
     if (lds > 64 * 1024) CS_FAIL(CS_E_SHAPE, "policy net too large for one workgroup (%zu B LDS)", lds);
     hipLaunchKernelGGL(factor_probs_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, *n, x, x_row_stride, cos_feat, probs);
@@ -390,9 +392,9 @@ int cs_factor_probs(const CsFactorNet* n, const float* x, int x_row_stride, cons
 }
 
 int cs_cosine_features(const void* const* hist, int m, int order, int B, int64_t elems, int dtype, float* out, void* stream) {
+    if (B <= 0 || elems <= 0) return B < 0 || elems < 0 ? CS_E_SHAPE : CS_OK;
     if (!hist || !out) CS_FAIL(CS_E_ARG, "use_conv=True requires epsilon (factor_net_ppo.py:109-110)");
     if (order < 2 || order > CS_MAX_ORDER || m < 1 || m > order) CS_FAIL(CS_E_ARG, "bad order/m (%d,%d)", order, m);
-    if (B <= 0 || elems <= 0) return B < 0 || elems < 0 ? CS_E_SHAPE : CS_OK;
     HistPtrs h;
     for (int k = 0; k < CS_MAX_ORDER; ++k) h.p[k] = (k < m) ? hist[k] : nullptr;
     for (int k = 0; k < m; ++k) if (!h.p[k]) CS_FAIL(CS_E_ARG, "hist[%d] is NULL", k);
@@ -408,9 +410,9 @@ int cs_cosine_features(const void* const* hist, int m, int order, int B, int64_t
 
 static int launch_sample(const float* probs, const float* uni, const int64_t* idx_in, const float* av, int B, int A, int K,
                          int64_t* idx, float* actions, float* aprobs, void* stream) {
-    if (!probs || !av) CS_FAIL(CS_E_ARG, "probs and action_values are required");
     if (B < 0 || A < 1 || K < 1) CS_FAIL(CS_E_SHAPE, "bad shape B=%d A=%d K=%d", B, A, K);
     if (B == 0) return CS_OK;
+    if (!probs || !av) CS_FAIL(CS_E_ARG, "probs and action_values are required");
     int n = B * A;
     hipLaunchKernelGGL(sample_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, probs, uni, idx_in, av, B, A, K, idx, actions, aprobs);
     CS_CHECK_LAUNCH();
@@ -419,21 +421,21 @@ static int launch_sample(const float* probs, const float* uni, const int64_t* id
 
 int cs_sample_actions(const float* probs, const float* uniforms, const float* action_values, int B, int A, int K,
                       int64_t* idx, float* actions, float* action_probs, void* stream) {
-    if (!uniforms) CS_FAIL(CS_E_ARG, "uniforms is NULL");
+    if (B > 0 && !uniforms) CS_FAIL(CS_E_ARG, "uniforms is NULL");
     return launch_sample(probs, uniforms, nullptr, action_values, B, A, K, idx, actions, action_probs, stream);
 }
 
 int cs_gather_actions(const float* probs, const int64_t* idx, const float* action_values, int B, int A, int K,
                       float* actions, float* action_probs, void* stream) {
-    if (!idx) CS_FAIL(CS_E_ARG, "idx is NULL");
+    if (B > 0 && !idx) CS_FAIL(CS_E_ARG, "idx is NULL");
     return launch_sample(probs, nullptr, idx, action_values, B, A, K, nullptr, actions, action_probs, stream);
 }
 
 int cs_action_probs(const float* probs, const float* actions, const float* action_values, int B, int A, int K,
                     float* selected, float* entropy, void* stream) {
-    if (!probs || !actions || !action_values) CS_FAIL(CS_E_ARG, "probs, actions and action_values are required");
     if (B < 0 || A < 1 || K < 1) CS_FAIL(CS_E_SHAPE, "bad shape");
     if (B == 0) return CS_OK;
+    if (!probs || !actions || !action_values) CS_FAIL(CS_E_ARG, "probs, actions and action_values are required");
     int n = B * A;
     hipLaunchKernelGGL(action_probs_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, probs, actions, action_values, B, A, K, selected, entropy);
     CS_CHECK_LAUNCH();
@@ -441,9 +443,9 @@ int cs_action_probs(const float* probs, const float* actions, const float* actio
 }
 
 int cs_step_masks(int B, int A, int m, int order, float* masks, void* stream) {
-    if (!masks) CS_FAIL(CS_E_ARG, "masks is NULL");
     if (B < 0 || A < 1) CS_FAIL(CS_E_SHAPE, "bad shape");
     if (B == 0) return CS_OK;
+    if (!masks) CS_FAIL(CS_E_ARG, "masks is NULL");
     int n = B * A;
     hipLaunchKernelGGL(masks_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, B, A, m, order, masks);
     CS_CHECK_LAUNCH();
@@ -451,9 +453,9 @@ int cs_step_masks(int B, int A, int m, int order, float* masks, void* stream) {
 }
 
 int cs_stack_history(const void* const* hist, int m, int order, int B, int64_t elems, int dtype, void* out, void* stream) {
+    if (B <= 0 || elems <= 0) return B < 0 || elems < 0 ? CS_E_SHAPE : CS_OK;
     if (!hist || !out) CS_FAIL(CS_E_ARG, "hist and out are required");
     if (order < 1 || order > CS_MAX_ORDER || m < 0 || m > order) CS_FAIL(CS_E_ARG, "bad order/m");
-    if (B <= 0 || elems <= 0) return B < 0 || elems < 0 ? CS_E_SHAPE : CS_OK;
     HistPtrs h;
     for (int k = 0; k < CS_MAX_ORDER; ++k) h.p[k] = (k < m) ? hist[k] : nullptr;
     const int vec = dtype == CS_F32 ? 4 : 8;

@@ -1,0 +1,125 @@
+"""Device-resident ConsistencySolver sampling loop for SD1.5 (the body of the hot path).
+
+Equivalent of the loop ``StableDiffusionPipeline.__call__`` runs around ``PPOScheduler``
+(in-tree copy: gen_pretrain/pipeline.py:1045-1098) and of ``gen_ppo.generate_batch_images``
+(gen_ppo.py:237-330) minus prompt encoding / VAE / PNG I/O:
+
+    for t in timesteps:  eps = unet(cat([x]*2), t, ctx)          # CFG dual batch
+                         eps = u + g (c - u)
+                         x   = scheduler.step(eps, t, x)[0]
+
+MI355X-first choices: the dual batch is never materialised (conv_in reads latent b % B), the CFG
+combine is fused into the solver kernel, eps history lives in a pre-allocated ring that the
+solver kernel writes directly, latents ping-pong between two buffers, cross-attention K/V of the
+prompt are computed once per batch, and nothing in the loop synchronises with the host -- so a
+whole N-step generation can also be captured into one hipGraph (``use_graph=True``).
+"""
+import torch
+
+from . import _lib as L
+
+
+class SDSamplingEngine:
+    def __init__(self, unet, scheduler, guidance_scale=3.0):
+        self.unet = unet
+        self.scheduler = scheduler
+        self.guidance_scale = float(guidance_scale)
+        self._bufs = None
+        self._graph = None
+        self._graph_key = None
+        self.forward_events = None      # optional list collecting (start, stop) events around UNet forwards
+
+    def _buffers(self, B, shape, device):
+        key = (B, tuple(shape), str(device))
+        if self._bufs is None or self._bufs["key"] != key:
+            order = self.scheduler.config.order_dim
+            C, H, W = shape
+            self._bufs = dict(
+                key=key,
+                lat=[torch.empty(B, C, H, W, dtype=torch.float16, device=device) for _ in range(2)],
+                ring=[torch.empty(B, C, H, W, dtype=torch.float16, device=device) for _ in range(order)],
+                eps=torch.empty(2 * B, C, H, W, dtype=torch.float16, device=device))
+        return self._bufs
+
+    def _loop(self, ctx, bufs, n, B, do_cfg):
+        sch, unet = self.scheduler, self.unet
+        x = bufs["lat"][0]
+        cur = 0
+        t_dev = self._t_dev
+        for i in range(n):
+            if self.forward_events is not None:
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                a.record()
+            eps = unet(x, t_dev[i:i + 1], encoder_hidden_states=ctx, dup=2 if do_cfg else 1, reuse_kv=(i > 0),
+                       out=bufs["eps"] if do_cfg else bufs["eps"][:B])[0]
+            if self.forward_events is not None:
+                b.record()
+                self.forward_events.append((a, b))
+            nxt = bufs["lat"][cur ^ 1]
+            if do_cfg:
+                sch.step(eps[B:], sch.timesteps[i], x, return_dict=False, eps_uncond=eps[:B],
+                         guidance_scale=self.guidance_scale, eps_out=bufs["ring"][i % len(bufs["ring"])], out=nxt)
+            else:
+                # the history keeps a reference to the model output: copy it out of the reused buffer
+                slot = bufs["ring"][i % len(bufs["ring"])]
+                slot.copy_(eps)
+                sch.step(slot, sch.timesteps[i], x, return_dict=False, out=nxt)
+            x = nxt
+            cur ^= 1
+        return x
+
+    @torch.no_grad()
+    def generate(self, prompt_embeds, negative_prompt_embeds=None, latents=None, num_inference_steps=8, generator=None,
+                 use_graph=False):
+        """prompt_embeds [B,77,768]; latents [B,4,64,64] initial noise (already scaled by
+        init_noise_sigma = 1).  Returns the final latents [B,4,H,W] fp16 (a view of an internal buffer
+        that the next call overwrites -- clone to keep)."""
+        L.require_cuda(prompt_embeds, "prompt_embeds")
+        dev = prompt_embeds.device
+        B = prompt_embeds.shape[0]
+        do_cfg = self.guidance_scale > 1.0            # denoise_ppo.py:37
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("negative_prompt_embeds required when guidance_scale > 1")
+            ctx = torch.cat([negative_prompt_embeds, prompt_embeds]).to(torch.float16).contiguous()
+        else:
+            ctx = prompt_embeds.to(torch.float16).contiguous()
+        S = self.unet.config["sample_size"]
+        shape = (self.unet.config["in_channels"], S, S)
+        bufs = self._buffers(B, shape, dev)
+        if latents is None:
+            latents = torch.randn((B,) + shape, generator=generator, device=dev, dtype=torch.float16)
+        bufs["lat"][0].copy_(latents.to(torch.float16) * self.scheduler.init_noise_sigma)
+        n = num_inference_steps
+
+        if not use_graph:
+            self.scheduler.set_timesteps(n, device=dev)
+            self._t_dev = self.scheduler.timesteps.to(torch.float32)
+            return self._loop(ctx, bufs, n, B, do_cfg)
+
+        # ---- whole-generation hipGraph: capture once per (B, n, cfg), replay afterwards ------------------
+        key = (B, n, do_cfg, self.guidance_scale)
+        if self._graph is None or self._graph_key != key:
+            net = self.scheduler.factor_net
+            if getattr(net, "sampler", None) == "multinomial" and net.forced_action_idx is None:
+                net.sampler = "inverse_cdf"          # graph-capturable RNG consumer
+            self._ctx_static = torch.empty_like(ctx)
+            self._ctx_static.copy_(ctx)
+            self.scheduler.set_timesteps(n, device=dev)
+            self._t_dev = self.scheduler.timesteps.to(torch.float32)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):             # warm-up outside capture (lazy inits, func attributes)
+                self._loop(self._ctx_static, bufs, n, B, do_cfg)
+                self.scheduler.set_timesteps(n, device=dev)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            bufs["lat"][0].copy_(latents.to(torch.float16) * self.scheduler.init_noise_sigma)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_out = self._loop(self._ctx_static, bufs, n, B, do_cfg)
+            self._graph, self._graph_key = g, key
+            bufs["lat"][0].copy_(latents.to(torch.float16) * self.scheduler.init_noise_sigma)
+        else:
+            self._ctx_static.copy_(ctx)
+        self._graph.replay()
+        return self._graph_out

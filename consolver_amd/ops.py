@@ -1,0 +1,94 @@
+"""Thin torch-tensor wrappers over the op-level C ABI (include/consolver_hip_ops.h).
+
+Used by the kernel parity tests and available to callers that want the individual HIP ops.
+Activations are NHWC fp16 CUDA tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _f16(t, name):
+    L.require_cuda(t, name)
+    if t.dtype != torch.float16 or not t.is_contiguous():
+        raise TypeError(f"{name} must be a contiguous float16 tensor")
+    return t
+
+
+def pack_conv_weight(w):
+    """[Cout, Cin, kh, kw] -> [Cout, kh*kw, Cin] fp16 (tap-major, channel-minor)."""
+    co, ci = w.shape[0], w.shape[1]
+    return w.reshape(co, ci, -1).permute(0, 2, 1).contiguous().to(torch.float16)
+
+
+def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None):
+    _f16(x0, "x0")
+    B, Hi, Wi, c0 = x0.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    N = w_packed.shape[0]
+    Ho = 2 * Hi if upsample else (Hi // 2 if stride == 2 else Hi)
+    Wo = 2 * Wi if upsample else (Wi // 2 if stride == 2 else Wi)
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float16, device=x0.device)
+    tstride = 0 if (temb is None or temb.shape[0] == 1) else temb.shape[1]
+    L.check(L.lib().cs_op_conv2d(L.ptr(x0), c0, L.ptr(x1), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
+                                 L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(out), L.stream_ptr(x0.device)))
+    return out
+
+
+def linear(x, w, bias=None, res=None, geglu=False, out=None):
+    _f16(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=x.device)
+    L.check(L.lib().cs_op_linear(L.ptr(x), M, K, L.ptr(w), L.ptr(bias), N, L.ptr(res), L.ptr(out), int(geglu),
+                                 L.stream_ptr(x.device)))
+    return out
+
+
+def geglu_pack(w, b):
+    """host-side permutation of a [2*Hd, K] GEGLU projection into (16 value | 16 gate) row blocks."""
+    w = w.detach().to("cpu", torch.float16).contiguous()
+    b = b.detach().to("cpu", torch.float16).contiguous()
+    wo, bo = torch.empty_like(w), torch.empty_like(b)
+    L.check(L.lib().cs_op_geglu_pack(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), w.shape[0] // 2, w.shape[1],
+                                     C.c_void_p(wo.data_ptr()), C.c_void_p(bo.data_ptr())))
+    return wo, bo
+
+
+def attention(q, k, v, heads, scale=None, q_stride=None, k_stride=None, v_stride=None):
+    """q: [B, Nq, H*dh], k/v: [B, Nk, H*dh] (or strided views described by *_stride in halfs)."""
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    C_ = q.shape[2] if q_stride is None else None
+    dh = (C_ or 0) // heads if C_ else None
+    if dh is None:
+        raise ValueError("pass dense q")
+    out = torch.empty(B, Nq, heads * dh, dtype=torch.float16, device=q.device)
+    L.check(L.lib().cs_op_attention(L.ptr(q), q_stride or q.stride(1), L.ptr(k), k_stride or k.stride(1), L.ptr(v),
+                                    v_stride or v.stride(1), L.ptr(out), heads * dh, B, heads, Nq, Nk, dh,
+                                    float(scale if scale is not None else dh ** -0.5), L.stream_ptr(q.device)))
+    return out
+
+
+def group_norm(x0, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None):
+    _f16(x0, "x0")
+    B = x0.shape[0]
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x0.numel() // (B * c0)
+    ws = torch.empty(int(L.lib().cs_op_group_norm_workspace(B, c0 + c1)), dtype=torch.uint8, device=x0.device)
+    out = torch.empty(x0.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x0.device)
+    L.check(L.lib().cs_op_group_norm(L.ptr(x0), c0, L.ptr(x1), c1, B, HW, groups, float(eps), int(silu), L.ptr(gamma),
+                                     L.ptr(beta), L.ptr(ws), L.ptr(out), L.stream_ptr(x0.device)))
+    return out
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    _f16(x, "x")
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().cs_op_layer_norm(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), M, Cc, float(eps), L.stream_ptr(x.device)))
+    return out

@@ -1,0 +1,29 @@
+"""Seeded synthetic weights of the exact SD1.5 shapes (no checkpoints exist offline).
+
+conv / linear weights ~ N(0, 1/fan_in), norm gamma = 1 + small noise, beta small noise, biases small:
+activations stay O(1) through the GroupNorms so fp16 neither overflows nor underflows.
+"""
+import torch
+
+
+def synthetic_unet_state_dict(manifest, seed=20251226):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in manifest:
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            w = torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+        elif ("norm" in name) and name.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            w = 0.05 * torch.randn(shape, generator=g)
+        sd[name] = w
+    return sd
+
+
+def synthetic_prompt_embeds(batch, ctx_len=77, dim=768, seed=1001):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, ctx_len, dim, generator=g)
+    return torch.nn.functional.layer_norm(x, (dim,))

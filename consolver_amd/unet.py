@@ -1,0 +1,140 @@
+"""HIP-backed SD1.5 ``UNet2DConditionModel`` stand-in.
+
+Call-compatible with the denoiser the reference drives
+(``unet(latent_in, t, encoder_hidden_states=ctx, return_dict=False)[0]``, denoise_ppo.py:89-94;
+gen_pretrain/pipeline.py:1058-1066): NCHW fp16 latents in, NCHW fp16 eps out.  Weights are loaded
+by their diffusers state-dict names (``load_state_dict``) and packed once by the library.
+
+Extension used by the native sampling engine: ``dup=2`` runs the CFG dual batch without
+``torch.cat([latents] * 2)`` (sample b reads latent ``b % B``).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+SD15_CONFIG = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                   num_heads=8, cross_attention_dim=768, norm_num_groups=32, sample_size=64, ctx_len=77,
+                   down_has_attn=(1, 1, 1, 0), up_has_attn=(0, 1, 1, 1))
+
+
+class HipUNet2DConditionModel:
+    is_consolver_hip = True
+    dtype = torch.float16
+
+    def __init__(self, config=None, device="cuda:0"):
+        cfg = dict(SD15_CONFIG)
+        cfg.update(config or {})
+        self.config = cfg
+        self.device = torch.device(device)
+        c = L.CsUNetConfig()
+        c.in_channels, c.out_channels = cfg["in_channels"], cfg["out_channels"]
+        for i in range(4):
+            c.block_out_channels[i] = cfg["block_out_channels"][i]
+            c.down_has_attn[i] = cfg["down_has_attn"][i]
+            c.up_has_attn[i] = cfg["up_has_attn"][i]
+        c.layers_per_block, c.num_heads = cfg["layers_per_block"], cfg["num_heads"]
+        c.cross_attention_dim, c.norm_num_groups = cfg["cross_attention_dim"], cfg["norm_num_groups"]
+        c.sample_size, c.ctx_len = cfg["sample_size"], cfg["ctx_len"]
+        h = C.c_void_p()
+        L.check(L.lib().cs_unet_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._ws = None
+        self._ws_batch = 0
+        self._kv_ctx_key = None
+        self._finalized = False
+        self._t_buf = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().cs_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def manifest(self):
+        """[(name, shape)] in diffusers state-dict naming."""
+        lib = L.lib()
+        out = []
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(lib.cs_unet_num_weights(self._h)):
+            name = lib.cs_unet_weight_name(self._h, i, shape, C.byref(nd)).decode()
+            out.append((name, tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        lib = L.lib()
+        want = dict(self.manifest())
+        missing = [k for k in want if k not in sd]
+        if missing and strict:
+            raise KeyError(f"missing {len(missing)} tensors, e.g. {missing[:3]}")
+        for name, shape in want.items():
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {shape}")
+            sh = (C.c_int64 * len(shape))(*shape)
+            L.check(lib.cs_unet_set_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), sh, len(shape)))
+        torch.cuda.set_device(self.device)
+        L.check(lib.cs_unet_finalize(self._h))
+        self._finalized = True
+        return self
+
+    # ------------------------------------------------------------------ run
+    def flops(self, batch):
+        return float(L.lib().cs_unet_flops(self._h, batch))
+
+    def _workspace(self, batch):
+        if self._ws is None or batch > self._ws_batch:
+            n = int(L.lib().cs_unet_workspace_bytes(self._h, batch))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+            self._kv_ctx_key = None
+        return self._ws
+
+    def set_profiling(self, on):
+        L.check(L.lib().cs_unet_set_profiling(self._h, int(on)))
+
+    def profile(self):
+        lib = L.lib()
+        out = {}
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        for i in range(lib.cs_unet_profile_entries(self._h)):
+            name = lib.cs_unet_profile_entry(self._h, i, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)).decode()
+            out[name] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+        return out
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=False, dup=1, reuse_kv=None, out=None,
+                 **_ignored):
+        if not self._finalized:
+            raise RuntimeError("weights not loaded")
+        L.require_cuda(sample, "sample")
+        ctx = L.require_cuda(encoder_hidden_states, "encoder_hidden_states")
+        sample = sample.to(torch.float16).contiguous()
+        ctx = ctx.to(torch.float16).contiguous()
+        n_lat = sample.shape[0]
+        B = n_lat * dup
+        if ctx.shape[0] != B:
+            raise ValueError(f"encoder_hidden_states batch {ctx.shape[0]} != {B}")
+        if isinstance(timestep, torch.Tensor) and timestep.is_cuda:
+            t = timestep.to(torch.float32).reshape(-1)
+        else:
+            # host scalar -> tiny pinned-free H2D through a cached device buffer (no sync)
+            t = torch.tensor([float(timestep)], dtype=torch.float32).to(sample.device, non_blocking=True)
+        if t.numel() not in (1, B):
+            raise ValueError("timestep must be a scalar or one value per sample")
+        ws = self._workspace(B)
+        key = (ctx.data_ptr(), ctx._version, B)
+        kv_valid = (self._kv_ctx_key == key) if reuse_kv is None else bool(reuse_kv)
+        if out is None:
+            out = torch.empty(B, self.config["out_channels"], sample.shape[2], sample.shape[3], dtype=torch.float16,
+                              device=sample.device)
+        L.check(L.lib().cs_unet_forward(self._h, L.ptr(sample), n_lat, dup, L.ptr(t), t.numel(), L.ptr(ctx), L.ptr(out),
+                                        L.ptr(ws), ws.numel(), int(kv_valid), L.stream_ptr(sample.device)))
+        self._kv_ctx_key = key
+        if return_dict:
+            return {"sample": out}
+        return (out,)

@@ -1,0 +1,54 @@
+/*
+ * consolver_hip_ops.h -- op-level entry points of libconsolver_hip.so.
+ *
+ * These are the building blocks the UNet executor (cs_unet_forward) is made of, exported so
+ * that each HIP kernel can be parity-tested on its own against a plain fp32 reference
+ * (tests/test_ops_gpu.py).  They replace, one for one, the third-party torch/diffusers ops the
+ * reference's denoiser call (denoise_ppo.py:89-94) runs: F.conv2d / nn.Linear (+bias, +time
+ * embedding, +residual, GEGLU), F.scaled_dot_product_attention (xformers in the reference,
+ * gen_ppo.py:197-198), nn.GroupNorm(+SiLU), nn.LayerNorm.
+ *
+ * Layout: activations are NHWC fp16 ([B, H, W, C] == [B, HW, C]); weights are fp16,
+ * [Cout][kh*kw][Cin] for convolutions and [N][K] for linear layers.  All pointers are borrowed
+ * device pointers; calls are asynchronous on `stream`; return codes as in consolver_hip.h.
+ */
+#ifndef CONSOLVER_HIP_OPS_H
+#define CONSOLVER_HIP_OPS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* conv (taps = 9: 3x3 pad 1, stride 1|2, optional fused nearest-x2 upsample of the input; taps = 1: 1x1)
+ * over the channel concatenation of x0 [B,Hi,Wi,c0] and x1 [B,Hi,Wi,c1] (x1 may be NULL, c1 = 0).
+ * out[B,Ho,Wo,N] = conv + bias[N] + temb[b*temb_stride + n] + res[B,Ho,Wo,N]  (each optional). */
+int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
+                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out, void* stream);
+
+/* out[M,N] = x[M,K] w[N,K]^T + bias + res ; geglu != 0: w rows pre-permuted in (16 value | 16 gate)
+ * blocks (see cs_op_geglu_pack) and out[M,N/2] = value * gelu(gate). */
+int cs_op_linear(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, void* out, int geglu, void* stream);
+
+/* host helper: permute a [2*Hd, K] GEGLU projection (rows [0,Hd) value, [Hd,2Hd) gate; fp16) and its
+ * bias into the blocked order cs_op_linear(geglu=1) expects.  Pure host memory. */
+int cs_op_geglu_pack(const void* w_host, const void* b_host, int Hd, int K, void* w_out_host, void* b_out_host);
+
+/* softmax(scale * q k^T) v per (batch, head); rows are token-major with the heads interleaved,
+ * q/k/v/out row strides in halfs (so fused qkv buffers work).  dh in {40, 80, 160}. */
+int cs_op_attention(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                    int B, int H, int Nq, int Nk, int dh, float scale, void* stream);
+
+/* GroupNorm(groups) [+ SiLU] over the channel concatenation of x0/x1 ([B,HW,c0], [B,HW,c1]) -> out [B,HW,c0+c1].
+ * workspace: cs_op_group_norm_workspace(B, c0 + c1) bytes. */
+size_t cs_op_group_norm_workspace(int B, int C);
+int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,
+                     const void* gamma, const void* beta, void* workspace, void* out, void* stream);
+
+/* LayerNorm over the last dim of x[M,C] */
+int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

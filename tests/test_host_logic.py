@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "consolver_hip.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 20
@@ -33,6 +33,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.CsStepArgs) % 8 == 0
     l = _lib.lib()
     a = _lib.CsStepArgs()
+    a.B, a.elems = 1, 8
     # argument validation happens before any launch -> usable without a GPU
     assert l.cs_lms_ddim_step(ctypes.byref(a), None) == -1
     assert b"required" in l.cs_last_error()

@@ -1,0 +1,164 @@
+"""Per-kernel parity of the HIP ops (through the C ABI) against plain torch fp32 references of
+the same op evaluated on the same fp16-rounded inputs.  Tolerances: outputs are stored in fp16
+(eps 9.8e-4) with fp32 accumulation -> relative L2 <= 1e-3, max abs error a few fp16 ulps of the
+output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from consolver_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().to(DEV)
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).float()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # B, H, W, c0, c1, N, taps, stride, up, bias, temb, res
+    (2, 16, 16, 64, 0, 128, 9, 1, False, True, False, False),
+    (1, 8, 8, 320, 0, 320, 9, 1, False, True, True, True),      # BN=160 path, temb per sample
+    (3, 8, 8, 128, 0, 160, 9, 1, False, False, False, False),
+    (2, 16, 16, 128, 0, 128, 9, 2, False, True, False, False),  # downsample
+    (2, 8, 8, 64, 0, 256, 9, 1, True, True, False, False),      # fused nearest x2 upsample
+    (2, 8, 8, 128, 64, 320, 1, 1, False, True, False, False),   # 1x1 over a skip concat
+    (2, 8, 8, 64, 64, 128, 9, 1, False, True, False, True),     # 3x3 over a concat + residual
+    (1, 4, 4, 640, 0, 640, 9, 1, False, True, True, True),      # M = 16 << tile (tail rows)
+    (5, 8, 8, 192, 0, 128, 1, 1, False, True, False, True),     # M = 320, ragged m tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    B, H, W, c0, c1, N, taps, stride, up, use_b, use_t, use_r = case
+    k = 3 if taps == 9 else 1
+    x0 = rnd(B, H, W, c0, seed=1)
+    x1 = rnd(B, H, W, c1, seed=2) if c1 else None
+    w = rnd(N, c0 + c1, k, k, seed=3, scale=(1.0 / ((c0 + c1) * taps)) ** 0.5)
+    bias = rnd(N, seed=4, scale=0.1) if use_b else None
+    temb = rnd(B, N + 64, seed=5, scale=0.5) if use_t else None
+    Ho = 2 * H if up else (H // 2 if stride == 2 else H)
+    res = rnd(B, Ho, Ho * W // H, N, seed=6) if use_r else None
+    out = ops.conv2d(x0, ops.pack_conv_weight(w), bias, x1=x1, taps=taps, stride=stride, upsample=up,
+                     temb=temb[:, 32:32 + N].contiguous() if use_t else None, res=res)
+    xin = nchw(torch.cat([x0, x1], -1) if c1 else x0)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias.float() if use_b else None, stride=stride, padding=k // 2)
+    if use_t:
+        ref = ref + temb[:, 32:32 + N].float()[:, :, None, None]
+    if use_r:
+        ref = ref + nchw(res)
+    assert out.shape == (B, Ho, ref.shape[3], N)
+    assert rel_l2(nchw(out), ref) < 1e-3
+    assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+
+
+def test_conv2d_temb_broadcast_and_inplace_residual():
+    x = rnd(2, 8, 8, 64, seed=1)
+    w = rnd(128, 64, 3, 3, seed=2, scale=0.05)
+    temb = rnd(1, 128, seed=3)
+    res = rnd(2, 8, 8, 128, seed=4)
+    want = F.conv2d(nchw(x), w.float(), padding=1) + temb.float()[0][None, :, None, None] + nchw(res)
+    out = ops.conv2d(x, ops.pack_conv_weight(w), None, temb=temb, res=res)
+    assert rel_l2(nchw(out), want) < 1e-3
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 64, 128), (100, 320, 960), (4096, 1280, 320), (77 * 3, 768, 640), (1, 64, 160)])
+def test_linear(M, K, N):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    out = ops.linear(x, w, b, res=r)
+    ref = F.linear(x.float(), w.float(), b.float()) + r.float()
+    assert rel_l2(out.float(), ref) < 1e-3
+    # in-place residual (out aliases res), as the UNet executor uses it
+    r2 = r.clone()
+    ops.linear(x, w, b, res=r2, out=r2)
+    assert torch.equal(r2, out)
+
+
+@pytest.mark.parametrize("M,C", [(128, 64), (300, 320), (64, 1280)])
+def test_linear_geglu(M, C):
+    x = rnd(M, C, seed=1)
+    w, b = rnd(8 * C, C, seed=2, scale=C ** -0.5), rnd(8 * C, seed=3, scale=0.2)
+    wp, bp = ops.geglu_pack(w, b)
+    out = ops.linear(x, wp.to(DEV), bp.to(DEV), geglu=True)
+    pr = F.linear(x.float(), w.float(), b.float())
+    val, gate = pr.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    assert out.shape == (M, 4 * C)
+    assert rel_l2(out.float(), ref) < 1.5e-3
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,dh", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 40), (2, 8, 128, 77, 40), (2, 8, 256, 256, 80),
+                                           (1, 8, 64, 77, 80), (2, 8, 64, 64, 160), (1, 8, 256, 77, 160), (1, 2, 100, 130, 40),
+                                           (1, 3, 16, 5, 80)])
+def test_attention(B, H, Nq, Nk, dh):
+    C = H * dh
+    q, k, v = rnd(B, Nq, C, seed=1), rnd(B, Nk, C, seed=2), rnd(B, Nk, C, seed=3)
+    out = ops.attention(q, k, v, H)
+    qf, kf, vf = (t.float().view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * dh ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, Nq, C)
+    assert rel_l2(out.float(), ref) < 2e-3
+    assert float((out.float() - ref).abs().max()) < 1e-2
+
+
+def test_attention_fused_qkv_strides_and_peaky_softmax():
+    B, H, N, dh = 2, 8, 192, 40
+    C = H * dh
+    qkv = rnd(B, N, 3 * C, seed=7, scale=3.0)      # large logits: exercises the running-max rescale
+    out = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], H, q_stride=None) if False else None
+    from consolver_amd import _lib as L
+    out = torch.empty(B, N, C, dtype=torch.float16, device=DEV)
+    L.check(L.lib().cs_op_attention(qkv.data_ptr(), 3 * C, qkv.data_ptr() + 2 * C, 3 * C, qkv.data_ptr() + 4 * C, 3 * C,
+                                    out.data_ptr(), C, B, H, N, N, dh, dh ** -0.5, L.stream_ptr(qkv.device)))
+    q, k, v = (t.float().reshape(B, N, H, dh).transpose(1, 2) for t in qkv.split(C, dim=-1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    assert rel_l2(out.float(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("B,HW,c0,c1,silu,eps", [(2, 256, 320, 0, True, 1e-5), (3, 64, 640, 320, True, 1e-5), (1, 1024, 320, 0, False, 1e-6),
+                                                  (2, 64, 1280, 1280, True, 1e-5), (2, 16, 1280, 640, True, 1e-5), (1, 4, 640, 0, True, 1e-5)])
+def test_group_norm(B, HW, c0, c1, silu, eps):
+    x0 = rnd(B, HW, c0, seed=1) * 2 + 0.5
+    x1 = (rnd(B, HW, c1, seed=2) - 0.3) if c1 else None
+    C = c0 + c1
+    g, b = (1 + 0.2 * rnd(C, seed=3)), 0.1 * rnd(C, seed=4)
+    out = ops.group_norm(x0, g, b, 32, eps, silu, x1=x1)
+    xin = torch.cat([x0, x1], -1) if c1 else x0
+    ref = F.group_norm(xin.float().transpose(1, 2), 32, g.float(), b.float(), eps)
+    ref = (F.silu(ref) if silu else ref).transpose(1, 2)
+    assert rel_l2(out.float(), ref) < 1e-3
+    assert float((out.float() - ref).abs().max()) < 6e-3
+
+
+@pytest.mark.parametrize("M,C", [(7, 320), (256, 640), (1000, 1280)])
+def test_layer_norm(M, C):
+    x = rnd(M, C, seed=1) * 3 + 1
+    g, b = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    out = ops.layer_norm(x, g, b)
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float())
+    assert rel_l2(out.float(), ref) < 1e-3
+
+
+def test_ops_are_deterministic():
+    x, w = rnd(512, 320, seed=1), rnd(640, 320, seed=2, scale=0.05)
+    assert torch.equal(ops.linear(x, w), ops.linear(x, w))
+    q = rnd(1, 512, 320, seed=3)
+    assert torch.equal(ops.attention(q, q, q, 8), ops.attention(q, q, q, 8))

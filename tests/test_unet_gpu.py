@@ -1,0 +1,106 @@
+"""HIP UNet forward (cs_unet_forward through the C ABI) vs the torch-fp32 oracle restatement.
+
+The oracle is "parity unpinned" w.r.t. diffusers (see oracle/unet_oracle.py); what is pinned here is
+that the HIP kernels compute the same function as the fp32 restatement on identical seeded weights.
+Tolerance: activations are stored in fp16 between ~400 kernels -> relative L2 of the eps output
+<= 5e-3 (measured ~1e-3), stated here because it is looser than the solver's 1e-3 gate.
+"""
+import pytest
+import torch
+
+from consolver_amd.unet import HipUNet2DConditionModel, SD15_CONFIG
+from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds
+from oracle.unet_oracle import UNetOracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def build(cfg_over):
+    u = HipUNet2DConditionModel(cfg_over, device=DEV)
+    sd = synthetic_unet_state_dict(u.manifest(), seed=7)
+    u.load_state_dict(sd)
+    return u, UNetOracle(sd, u.config)
+
+
+def test_reduced_unet_matches_oracle():
+    # full SD1.5 widths and head dims, one layer per block, 16x16 latents: every kernel shape class
+    # (BN 128/160, stride 2, upsample, concat, dh 40/80/160, Nk=77) in a forward the CPU oracle runs in seconds
+    u, orc = build(dict(layers_per_block=1, sample_size=16))
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(2, 4, 16, 16, generator=g)
+    ctx = synthetic_prompt_embeds(4, seed=11)
+    t = 749
+    got = u(lat.half().to(DEV), t, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
+    want = orc(torch.cat([lat.half().float()] * 2), t, ctx.half().float())
+    assert got.shape == (4, 4, 16, 16) and got.dtype == torch.float16
+    err = rel_l2(got, want)
+    assert err < 5e-3, err
+    # cached cross-attention K/V (second step, same ctx) and per-sample timesteps give the same function
+    got2 = u(lat.half().to(DEV), torch.full((4,), float(t), device=DEV), encoder_hidden_states=ctx.half().to(DEV), dup=2, reuse_kv=True)[0]
+    assert rel_l2(got2, want) < 5e-3
+    # un-duplicated batch path == dual batch path on the conditional half
+    got3 = u(lat.half().to(DEV), t, encoder_hidden_states=ctx[2:].half().to(DEV), dup=1, reuse_kv=False)[0]
+    assert torch.equal(got3, got[2:])
+    assert abs(u.flops(1) / 1e9 - orc_flops_estimate(u.config)) / orc_flops_estimate(u.config) < 0.02
+
+
+def orc_flops_estimate(cfg):
+    """independent MAC count of the restated graph (conv/linear/attention only), GFLOP per sample"""
+    c = cfg["block_out_channels"]; S = cfg["sample_size"]; L = cfg["ctx_len"]; cd = cfg["cross_attention_dim"]
+    mac = 0
+    def res(cin, cout, hw):
+        return hw * 9 * cin * cout + hw * 9 * cout * cout + (hw * cin * cout if cin != cout else 0) + 4 * c[0] * cout
+    def xf(C, hw):
+        return (2 * hw * C * C + 4 * hw * C * C + 2 * hw * hw * C + hw * C * C + 2 * L * cd * C + 2 * hw * L * C + hw * C * C
+                + hw * C * 8 * C + hw * 4 * C * C)
+    hw = S * S
+    mac += hw * 9 * 4 * c[0] + c[0] * 4 * c[0] + 16 * c[0] * c[0]
+    ch = c[0]; skips = [ch]
+    for i in range(4):
+        for j in range(cfg["layers_per_block"]):
+            mac += res(ch, c[i], hw); ch = c[i]
+            if cfg["down_has_attn"][i]:
+                mac += xf(ch, hw)
+            skips.append(ch)
+        if i < 3:
+            hw //= 4; mac += hw * 9 * ch * ch; skips.append(ch)
+    mac += 2 * res(ch, ch, hw) + xf(ch, hw)
+    for i in range(4):
+        co = c[3 - i]
+        for j in range(cfg["layers_per_block"] + 1):
+            mac += res(ch + skips.pop(), co, hw); ch = co
+            if cfg["up_has_attn"][i]:
+                mac += xf(ch, hw)
+        if i < 3:
+            hw *= 4; mac += hw * 9 * ch * ch
+    mac += hw * 9 * ch * 4
+    return 2 * mac / 1e9
+
+
+def test_sd15_flops_match_survey():
+    u = HipUNet2DConditionModel(device=DEV)
+    assert abs(orc_flops_estimate(u.config) - 803.27) / 803.27 < 0.01        # SURVEY 2c / BASELINE.md: 803.27 GFLOP
+
+
+@pytest.mark.timeout(900)
+def test_full_sd15_unet_matches_oracle_cfg_batch():
+    u, orc = build({})
+    assert abs(u.flops(1) / 1e9 - 803.27) / 803.27 < 0.01
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    ctx = synthetic_prompt_embeds(2, seed=13)
+    got = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    want = orc(torch.cat([lat.half().float()] * 2), 499, ctx.half().float())
+    err = rel_l2(got, want)
+    assert err < 5e-3, err
+    assert torch.isfinite(got).all()
+    # determinism
+    again = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
+    assert torch.equal(got, again)
