@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of 8-step ConsistencySolver sampling at 512x512 on MI355X.
+
+Workload (BASELINE.json configs[1]): SD1.5 UNet fp16 + PPOScheduler (order 4, CFG 3), batch 16
+prompts per GPU, 8 solver steps, synthetic seeded weights / prompt embeddings / noise (no
+checkpoints exist offline).  A "step" of this bench = one full 8-step generation of one batch
+(8 CFG dual-batch UNet forwards at effective batch 32 + 8 fused solver updates); the unit of the
+metric is one image's final latents (VAE decode is the step after the path and not timed).
+
+Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
+Multi-GPU: one process per GPU (torch.distributed/RCCL only for the barrier and the max-over-ranks
+time); prompts are sharded with no data-path collective (gen_ppo.py:349-357) -> weak scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0):
+    """The oracle (CPU restatement, 'port') timed on the host cores for a bounded sample:
+    ONE solver step of config[0] (B=1, CFG -> 2 UNet sample-forwards fp32 + 1 solver update),
+    scaled to the 8-step image."""
+    import numpy as np
+    from oracle.unet_oracle import UNetOracle
+    from oracle import solver_oracle as so
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = UNetOracle(sd, cfg, round_weights_to_f16=False)
+    g = torch.Generator().manual_seed(43)
+    S = cfg["sample_size"]
+    lat = torch.randn(1, 4, S, S, generator=g)
+    from consolver_amd.synth import synthetic_prompt_embeds
+    ctx = torch.cat([synthetic_prompt_embeds(1, seed=1002), synthetic_prompt_embeds(1, seed=1001)])
+    sch = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                timestep_spacing="trailing", order_dim=4, scaler_dim=0, num_actions=11,
+                                weights=None)
+    # untrained policy == uniform; the combine cost does not depend on the weights
+    w = {"mlp.0.weight": np.zeros((8, 2), np.float32), "mlp.0.bias": np.zeros(8, np.float32),
+         "mlp.2.weight": np.zeros((8, 8), np.float32), "mlp.2.bias": np.zeros(8, np.float32),
+         "mlp.4.weight": np.zeros((33, 8), np.float32), "mlp.4.bias": np.zeros(33, np.float32)}
+    sch.weights = w
+    sch.set_timesteps(steps_total)
+    t0 = time.perf_counter()
+    e = orc(torch.cat([lat, lat]), int(sch.timesteps[0]), ctx).numpy()
+    eps = so.cfg_combine(e[:1], e[1:], guidance)
+    sch.step(eps, int(sch.timesteps[0]), lat.numpy(), np.zeros((1, 3), np.int64))
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * steps_total), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 of {steps_total} solver steps of configs[0] (B=1, CFG dual forward fp32 + solver update) = {dt:.2f} s, scaled x{steps_total}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per generation")
+    ap.add_argument("--num-inference-steps", type=int, default=8)
+    ap.add_argument("--guidance", type=float, default=3.0)
+    ap.add_argument("--graph", type=int, default=0, help="capture the whole generation in one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import consolver_amd
+    from consolver_amd.unet import HipUNet2DConditionModel
+    from consolver_amd.engine import SDSamplingEngine
+    from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds
+    from consolver_amd.launch import shard_bounds
+
+    unet = HipUNet2DConditionModel(device=dev)
+    sd = synthetic_unet_state_dict(unet.manifest(), seed=20251226)
+    unet.load_state_dict(sd)
+    sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                     timestep_spacing="trailing", order_dim=4, scaler_dim=0,
+                                     factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=11))
+    g = torch.Generator().manual_seed(20251226)
+    with torch.no_grad():
+        for p in sch.factor_net.parameters():      # seeded N(0, 0.5) policy (zero-init = uniform sampling), SURVEY 8(d)
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sch.factor_net.to(dev)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=args.guidance)
+
+    # prompts: global list sharded contiguously over ranks (gen_ppo.py:349-357); every rank gets `batch` per generation
+    B, n = args.batch, args.num_inference_steps
+    total_prompts = B * world
+    lo, hi = shard_bounds(total_prompts, world, rank)
+    pe = synthetic_prompt_embeds(total_prompts, seed=1001)[lo:hi].half().to(dev)
+    ne = synthetic_prompt_embeds(total_prompts, seed=1002)[lo:hi].half().to(dev)
+    gen = torch.Generator().manual_seed(43)                 # readme seed; same noise on every rank like gen_ppo.py:258-260
+    noise = torch.randn(B, 4, 64, 64, generator=gen).half().to(dev)
+
+    def one():
+        return eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=bool(args.graph))
+
+    for _ in range(args.warmup):
+        one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.forward_events = [] if not args.graph else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    # ---- roofline of the dominant unit: the UNet forward (MFMA bound), HIP events on the launch stream -------
+    eff_batch = 2 * B if args.guidance > 1 else B
+    flops_fwd = unet.flops(eff_batch)
+    if eng.forward_events:
+        fwd_ms = sum(a.elapsed_time(b) for a, b in eng.forward_events) / len(eng.forward_events)
+    else:
+        fwd_ms = elapsed * 1e3 / (args.steps * n)
+    eng.forward_events = None
+    achieved = flops_fwd / (fwd_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
+                "traffic": None, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
+                "launch_ms": fwd_ms, "flops_per_launch": flops_fwd}
+
+    kernels = None
+    if args.profile_kernels and rank == 0:
+        unet.set_profiling(True)
+        unet(noise, torch.tensor([499.0], device=dev), encoder_hidden_states=torch.cat([ne, pe]), dup=2, reuse_kv=False)
+        prof = unet.profile()
+        unet.set_profiling(False)
+        kernels = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
+                       "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None} for k, v in prof.items()}
+
+    if rank == 0:
+        images = B * world * args.steps
+        rec = {
+            "metric": "images/sec at 8-step ConsistencySolver 512x512 (final latents; SD1.5 UNet fp16 + PPOScheduler, CFG 3)",
+            "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic (seeded weights, prompt embeddings and noise of the SD1.5 shapes)",
+            "config": {"workload": "configs[1]: SD1.5 + PPOScheduler 8-step fp16, batch 16, 512x512 on 1 MI355X",
+                       "batch_per_gpu": B, "num_inference_steps": n, "guidance_scale": args.guidance, "order_dim": 4,
+                       "parallelism": f"dp{world} (prompt shards, no data-path collective)", "hipgraph": bool(args.graph)},
+            "roofline": roofline,
+        }
+        if kernels:
+            rec["roofline_kernels"] = kernels
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance)
+        elif world == 1:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -565,7 +565,7 @@ int cs_unet_finalize(CsUNet* u) {
 size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || batch <= 0) return 0;
-    run_forward(u, true, nullptr, batch, 1, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+    run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + u->arena.peak + 4096;
 }
 
