@@ -25,36 +25,54 @@ sys.path.insert(0, ROOT)
 PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0):
-    """The oracle (CPU restatement, 'port') timed on the host cores for a bounded sample:
-    ONE solver step of config[0] (B=1, CFG -> 2 UNet sample-forwards fp32 + 1 solver update),
-    scaled to the 8-step image."""
+def usable_cores():
+    """host cores this process may actually use: min(affinity, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0):
+    """The oracle (CPU restatement of the same path, kind 'port') timed on the host cores:
+    configs[0] = B=1, 8 steps, CFG 3, fp32 (2 UNet sample-forwards + 1 solver update per step).
+    Runs all steps when they fit the time budget, otherwise the steps done are scaled up."""
     import numpy as np
     from oracle.unet_oracle import UNetOracle
     from oracle import solver_oracle as so
-    torch.set_num_threads(os.cpu_count() or 1)
+    from consolver_amd.synth import synthetic_prompt_embeds
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     orc = UNetOracle(sd, cfg, round_weights_to_f16=False)
     g = torch.Generator().manual_seed(43)
     S = cfg["sample_size"]
-    lat = torch.randn(1, 4, S, S, generator=g)
-    from consolver_amd.synth import synthetic_prompt_embeds
+    lat = torch.randn(1, 4, S, S, generator=g).numpy()
     ctx = torch.cat([synthetic_prompt_embeds(1, seed=1002), synthetic_prompt_embeds(1, seed=1001)])
+    gw = torch.Generator().manual_seed(20251226)
+    w = {}
+    for k, shp in (("mlp.0.weight", (256, 2)), ("mlp.0.bias", (256,)), ("mlp.2.weight", (256, 256)), ("mlp.2.bias", (256,)),
+                   ("mlp.4.weight", (33, 256)), ("mlp.4.bias", (33,))):
+        w[k] = (torch.randn(shp, generator=gw) * 0.5).numpy()
     sch = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                                timestep_spacing="trailing", order_dim=4, scaler_dim=0, num_actions=11,
-                                weights=None)
-    # untrained policy == uniform; the combine cost does not depend on the weights
-    w = {"mlp.0.weight": np.zeros((8, 2), np.float32), "mlp.0.bias": np.zeros(8, np.float32),
-         "mlp.2.weight": np.zeros((8, 8), np.float32), "mlp.2.bias": np.zeros(8, np.float32),
-         "mlp.4.weight": np.zeros((33, 8), np.float32), "mlp.4.bias": np.zeros(33, np.float32)}
-    sch.weights = w
+                                timestep_spacing="trailing", order_dim=4, scaler_dim=0, num_actions=11, weights=w)
     sch.set_timesteps(steps_total)
-    t0 = time.perf_counter()
-    e = orc(torch.cat([lat, lat]), int(sch.timesteps[0]), ctx).numpy()
-    eps = so.cfg_combine(e[:1], e[1:], guidance)
-    sch.step(eps, int(sch.timesteps[0]), lat.numpy(), np.zeros((1, 3), np.int64))
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt * steps_total), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 of {steps_total} solver steps of configs[0] (B=1, CFG dual forward fp32 + solver update) = {dt:.2f} s, scaled x{steps_total}"}
+    rng = np.random.default_rng(0)
+    done, t0 = 0, time.perf_counter()
+    for i, t in enumerate(sch.timesteps):
+        e = orc(torch.from_numpy(np.concatenate([lat, lat])), int(t), ctx).numpy()
+        lat = sch.step(so.cfg_combine(e[:1], e[1:], guidance), int(t), lat, rng.integers(0, 11, size=(1, 3)))["prev_sample"]
+        done += 1
+        el = time.perf_counter() - t0
+        if el / done * (done + 1) > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": done / (el * steps_total), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{done} of {steps_total} solver steps of configs[0] (B=1, CFG dual UNet forward fp32 + solver update per step) "
+                      f"in {el:.1f} s on {cores} threads" + ("" if done == steps_total else f", scaled x{steps_total}/{done}")}
 
 
 def main():

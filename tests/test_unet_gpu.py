@@ -97,7 +97,7 @@ def test_full_sd15_unet_matches_oracle_cfg_batch():
     lat = torch.randn(1, 4, 64, 64, generator=g)
     ctx = synthetic_prompt_embeds(2, seed=13)
     got = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
-    torch.set_num_threads(max(1, torch.get_num_threads()))
+    torch.set_num_threads(16)
     want = orc(torch.cat([lat.half().float()] * 2), 499, ctx.half().float())
     err = rel_l2(got, want)
     print('sd15 unet rel l2', err)
