@@ -21,6 +21,9 @@
 //     current tile's MFMAs; blockIdx is remapped so that each XCD (private L2) owns a contiguous
 //     run of tiles and the n-tiles of one pixel tile run back to back on it.
 #include "ops.h"
+#include <stdlib.h>
+
+extern int g_tune_halo;
 
 namespace {
 
@@ -46,7 +49,276 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (diffusers GEGLU uses F.gelu, approximate='none').  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the fp16 output rounding) = 1 v_rcp + 1 v_exp + 7 FMAs instead of
+// ocml erff's branchy ~40 instructions; the GEGLU epilogue evaluates it 168 M times per L0 layer.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = 1.0f - poly * __expf(-z * z);          // erf(|x|/sqrt2)
+    return 0.5f * x + 0.5f * fabsf(x) * e;                  // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+}
+
+
+// lane holds, per (nt, mt) tile, pixel m = ..+(lane&15), channels 4*(lane>>4)..+3
+template <bool GEGLU, int NT, int MT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int lane) {
+    const int g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m_base + j * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const f16* trow = nullptr;
+        if (p.temb) trow = p.temb + (size_t)(m / p.HoWo) * p.temb_stride;
+        if (GEGLU) {
+            const int No = p.N >> 1;
+#pragma unroll
+            for (int i = 0; i < NT; i += 2) {
+                const int nrow = n_base + i * 16 + g4;        // row of the permuted weight (value half)
+                const int nout = ((n_base + i * 16) >> 1) + g4;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r], g = acc[i + 1 < NT ? i + 1 : i][j][r];
+                    if (p.bias) { v += (float)p.bias[nrow + r]; g += (float)p.bias[nrow + 16 + r]; }
+                    o[r] = (f16)(v * gelu_erf(g));
+                }
+                *reinterpret_cast<f16x4*>(p.out + (size_t)m * No + nout) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n_base + i * 16 + g4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (p.bias) {
+                    const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+                }
+                if (trow) {
+                    const f16x4 tv = *reinterpret_cast<const f16x4*>(trow + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)tv[r];
+                }
+                if (p.res) {
+                    const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.N + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.N + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Halo-resident 3x3 convolution (stride 1, pad 1): the generic implicit GEMM re-stages the input
+// pixels of a tile once per tap (9x) and is bound by L2->LDS bandwidth, not by MFMA.  Here a
+// workgroup owns 256 consecutive output pixels (whole image rows) x 160 channels; per 64-channel
+// chunk the (rows+2) x (W+2) input HALO is staged into LDS ONCE (zero page for the padding ring)
+// and all nine taps multiply out of it with shifted row addresses, while only the 160x64 weight
+// tile streams per tap.  Bytes staged per k-step drop from 36.9 KB (128x160 tile) to 25.6 KB for 2x
+// the FLOPs (205 vs 71 FLOP/B); glds issues per MFMA drop 2.8x.
+//   * 8 wave64 (4 pixel groups x 2 channel groups), wave tile 64 x 80, one workgroup per CU;
+//   * halo rows are 128 B, chunk index XOR-swizzled with (row & 7): conflict-free ds_read_b128 for
+//     ANY run of 16 consecutive rows, which is what a shifted tap reads;
+//   * k order is chunk-major / tap-minor; the next chunk's halo is prefetched in nine slices (one per
+//     tap) into the second halo buffer, the next tap's weights into the second weight buffer.
+// ------------------------------------------------------------------------------------------------
+struct HaloParams {
+    IgemmParams e;          // epilogue view (M, N, HoWo, bias, temb, res, out, tiles_n, nblk)
+    const f16* x; const f16* w;
+    int Cin, H, W, B, NC;   // INPUT geometry; NC = Cin / 64
+    int Wo;                 // output width (2 W when the nearest-x2 upsample is fused)
+    int TRW;                // output pixels per image inside one tile (min(256, Ho*Wo))
+    int HALO_W, HALO_IMG;   // W + 2 ; halo rows per image * (W + 2)
+    int NHALO, NQ;          // halo rows per tile ; DMA instructions (8 rows each) per halo
+    int splits;             // split-K over channel chunks (gridDim.y); > 1 -> fp32 partials to `partial`
+    float* partial;         // [splits][M][N]
+};
+
+constexpr int HALO_ROWS_MAX = 400;
+
+template <bool UP>
+__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
+    constexpr int BN = 160, NT = 5, MT = 4;
+    constexpr int A_BYTES = HALO_ROWS_MAX * 128, B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const lA = smem;                    // [2][A_BYTES]
+    char* const lB = smem + 2 * A_BYTES;      // [2][B_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.e.nblk >> 3, r = p.e.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.e.tiles_n, tn = id - tm * p.e.tiles_n;
+    const int m_blk = tm * 256, n_blk = tn * BN;
+    const int HWo = p.e.HoWo;
+    const int b0 = m_blk / HWo, y0 = (m_blk - b0 * HWo) / p.Wo;          // first output row of the tile
+    const int iy_base = (UP ? (y0 >> 1) : y0) - 1;                        // input row of halo row 0
+    const int c_per = p.NC / p.splits, c_begin = blockIdx.y * c_per, c_end = c_begin + c_per;
+
+    // ---- halo staging: at tap t this wave issues DMA instruction q = t + 9 w (rows 8q .. 8q+7).  The lane's
+    // halo row walks hr = 72 w + (lane>>3) + 8 t; its (image, y, x) coordinates are advanced incrementally
+    // (HALO_W >= 10 > 8: at most one wrap per step), so no per-tap divisions and no per-tap register table.
+    const int pch = lane & 7;
+    int hi0, hy0, hx0;
+    {
+        const int hr = 72 * w + (lane >> 3);
+        hi0 = hr / p.HALO_IMG; const int rem = hr - hi0 * p.HALO_IMG;
+        hy0 = rem / p.HALO_W; hx0 = rem - hy0 * p.HALO_W;
+    }
+    const int halo_rows = p.HALO_IMG / p.HALO_W;
+    const int a_sw = (pch ^ ((lane >> 3) & 7)) * 8;      // halo row index & 7 == (lane>>3): 8q is a multiple of 8
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
+    int hi = hi0, hy = hy0, hx = hx0;
+    auto halo_pix = [&]() -> int {      // input pixel index of the current halo row, or -1 (padding / out of tile)
+        const int b = b0 + hi, y = iy_base + hy, x = hx - 1;
+        const bool ok = (b < p.B) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W) & (hi * p.HALO_IMG + hy * p.HALO_W + hx < p.NHALO);
+        return ok ? (b * p.H + y) * p.W + x : -1;
+    };
+    auto halo_advance = [&]() {
+        hx += 8;
+        const bool wrapx = hx >= p.HALO_W;
+        hx -= wrapx ? p.HALO_W : 0; hy += wrapx ? 1 : 0;
+        const bool wrapy = hy >= halo_rows;
+        hy = wrapy ? 0 : hy; hi += wrapy ? 1 : 0;
+    };
+    // weight tile: 20 DMA instructions, wave w issues q = w, w + 8 (, w + 16 when w < 4)
+    const f16* b_src[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = w + 8 * j;
+        const int r = 8 * q + (lane >> 3);
+        b_src[j] = p.w + (size_t)(n_blk + (q < 20 ? r : 0)) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+    }
+
+    auto stage_a = [&](int c, int t, int buf) {          // one ninth of chunk c's halo
+        if (t + 9 * w < p.NQ) {
+            const int pix = halo_pix();
+            const uintptr_t real = (uintptr_t)(p.x + ((long)(pix < 0 ? 0 : pix) * p.Cin + c * BK + a_sw));
+            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)(pix >= 0);
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), lA + buf * A_BYTES + (t + 9 * w) * 1024);
+        }
+    };
+    auto stage_w = [&](int c, int t, int buf) {
+        const size_t koff = (size_t)t * p.Cin + c * BK;
+        char* lb = lB + buf * B_BYTES;
+        glds16(b_src[0] + koff, lb + w * 1024);
+        glds16(b_src[1] + koff, lb + (w + 8) * 1024);
+        if (w < 4) glds16(b_src[2] + koff, lb + (w + 16) * 1024);
+    };
+
+    // ---- fragment addressing: output pixel -> (image offset, row in tile, column) ------------------------
+    int fi[MT], fy[MT], fx[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int o = wm * 64 + j * 16 + (lane & 15);
+        const int img = o / p.TRW, rem = o - img * p.TRW;
+        fy[j] = rem / p.Wo; fx[j] = rem - fy[j] * p.Wo; fi[j] = img * p.HALO_IMG;
+    }
+    const int g = lane >> 4;
+    const int swz = (lane >> 1) & 7;
+    const int wfrag0 = (lane & 15) * 128 + ((g) ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + g) ^ swz) * 16;
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < 9; ++t) { stage_a(c_begin, t, 0); halo_advance(); }
+    stage_w(c_begin, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int it = 0, ab = 0;
+    for (int c = c_begin; c < c_end; ++c, ab ^= 1) {
+        const char* ha = lA + ab * A_BYTES;
+        hi = hi0; hy = hy0; hx = hx0;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t, ++it) {
+            const int wb = it & 1;
+            if (t < 8) stage_w(c, t + 1, wb ^ 1);
+            else if (c + 1 < c_end) stage_w(c + 1, 0, wb ^ 1);
+            if (c + 1 < c_end) { stage_a(c + 1, t, ab ^ 1); halo_advance(); }
+            const int dy = t / 3, dx = t - 3 * dy;
+            const char* tb = lB + wb * B_BYTES + (wn * 80) * 128;
+            int arow[MT], asw[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int hyv = UP ? ((fy[j] + dy - 1) >> 1) + 1 : fy[j] + dy;
+                const int hxv = UP ? ((fx[j] + dx - 1) >> 1) + 1 : fx[j] + dx;
+                const int hr = fi[j] + hyv * p.HALO_W + hxv;
+                arow[j] = hr * 128; asw[j] = (g ^ (hr & 7)) * 16;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 fa[MT], fw[NT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ha + arow[j] + (asw[j] ^ (ks * 64)));
+#pragma unroll
+                for (int i = 0; i < NT; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? wfrag1 : wfrag0));
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (p.splits == 1) {
+        igemm_epilogue<false, NT, MT>(p.e, acc, m_blk + wm * 64, n_blk + wn * 80, lane);
+    } else {
+        // split-K: raw fp32 partial sums, 16-byte stores (4 consecutive channels per lane)
+        float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m_blk + wm * 64 + j * 16 + (lane & 15);
+            if (m >= p.e.M) continue;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + wn * 80 + i * 16 + g * 4) = acc[i][j];
+        }
+    }
+}
+
+// out = sum_s partial[s] + bias + temb + res  (8 channels per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const float* __restrict__ partial, int splits) {
+    const int NV = p.N >> 3;
+    const long total = (long)p.M * NV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / NV), n = (int)(i - (long)m * NV) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < splits; ++s) {
+            const float* src = partial + ((size_t)s * p.M + m) * p.N + n;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+        }
+        if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+        if (p.temb) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+        if (p.res) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.N + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
+        *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
+    }
+}
 
 template <int BN, bool CONV3, bool GEGLU>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
@@ -172,54 +444,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, per (nt, mt) tile, pixel m = ..+(lane&15), channels 4*(lane>>4)..+3 ----
-    const int g4 = (lane >> 4) * 4;
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m_blk + wm * 64 + j * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const f16* trow = nullptr;
-        if (p.temb) trow = p.temb + (size_t)(m / p.HoWo) * p.temb_stride;
-        if (GEGLU) {
-            const int No = p.N >> 1;
-#pragma unroll
-            for (int i = 0; i < NT; i += 2) {
-                const int nrow = n_blk + wn * (BN / 2) + i * 16 + g4;        // row of the permuted weight (value half)
-                const int nout = ((n_blk + wn * (BN / 2) + i * 16) >> 1) + g4;
-                f16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r], g = acc[i + 1][j][r];
-                    if (p.bias) { v += (float)p.bias[nrow + r]; g += (float)p.bias[nrow + 16 + r]; }
-                    o[r] = (f16)(v * gelu_erf(g));
-                }
-                *reinterpret_cast<f16x4*>(p.out + (size_t)m * No + nout) = o;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n_blk + wn * (BN / 2) + i * 16 + g4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.bias) {
-                    const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
-                }
-                if (trow) {
-                    const f16x4 tv = *reinterpret_cast<const f16x4*>(trow + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)tv[r];
-                }
-                if (p.res) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.N + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.N + n) = o;
-            }
-        }
-    }
+    igemm_epilogue<GEGLU, NT, MT>(p, acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -237,6 +462,8 @@ int launch_variant(const IgemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int g_tune_halo = 1;
 
 double igemm_flops(const IgemmArgs& a) {
     const double M = (double)a.B * a.Ho * a.Wo;
@@ -264,6 +491,48 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     else CS_FAIL(CS_E_SHAPE, "igemm: N=%d must be a multiple of 128 or 160", a.N);
     p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n;
     const bool conv3 = a.taps == 9;
+    const int use_halo = g_tune_halo;   // 0 = never, 1 = when it pays, 2 = whenever the shape allows (tests)
+    const int Wo = a.upsample ? 2 * a.Wi : a.Wi, HWo = a.Ho * a.Wo;
+    if (use_halo && conv3 && a.stride == 1 && a.c1 == 0 && a.N % 160 == 0 && !a.geglu &&
+        (256 % Wo == 0) && Wo >= 8 && (HWo % 256 == 0 || 256 % HWo == 0) && !(a.upsample && HWo < 256)) {
+        const int tiles_m = (p.M + 255) / 256, tiles_n = a.N / 160;
+        const int NC = cin / BK;
+        int splits = 1;
+        if (tiles_m * tiles_n < 160 && a.splitk_ws) {          // small images: split the channel chunks to fill the chip
+            while (splits < 8 && tiles_m * tiles_n * splits < 192 && NC % (splits * 2) == 0 &&
+                   (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
+        }
+        const bool pays = tiles_m * tiles_n * splits >= 160 && !(cin == 320 && a.N == 320 && !a.upsample);
+        if (pays || use_halo == 2) {
+            HaloParams h;
+            h.e = p; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n;
+            h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Wo = Wo;
+            h.TRW = HWo < 256 ? HWo : 256;
+            const int rows_out = h.TRW / Wo, ipt = 256 / h.TRW;
+            const int rows_in = a.upsample ? rows_out / 2 + 2 : rows_out + 2;
+            h.HALO_W = a.Wi + 2; h.HALO_IMG = rows_in * (a.Wi + 2); h.NHALO = ipt * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
+            h.splits = splits; h.partial = a.splitk_ws;
+            if (h.NHALO <= HALO_ROWS_MAX && (!a.upsample || rows_out % 2 == 0)) {
+                constexpr size_t lds = 2 * (HALO_ROWS_MAX * 128 + 160 * 128);
+                static bool configured = false;
+                if (!configured) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    configured = true;
+                }
+                if (a.upsample) hipLaunchKernelGGL(conv3_halo_kernel<true>, dim3(h.e.nblk, splits), dim3(512), lds, s, h);
+                else hipLaunchKernelGGL(conv3_halo_kernel<false>, dim3(h.e.nblk, splits), dim3(512), lds, s, h);
+                CS_CHECK_LAUNCH();
+                if (splits > 1) {
+                    const long total = (long)p.M * (p.N / 8);
+                    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, h.e, (const float*)a.splitk_ws, splits);
+                    CS_CHECK_LAUNCH();
+                }
+                return CS_OK;
+            }
+        }
+    }
     if (a.geglu) {
         if (conv3) CS_FAIL(CS_E_ARG, "igemm: GEGLU epilogue only for linear layers");
         return launch_variant<128, false, true>(p, s);

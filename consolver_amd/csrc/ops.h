@@ -18,6 +18,7 @@ struct IgemmArgs {
     const f16* res;         // [M][N] residual add or null (may alias out)
     f16* out;               // [M][N] (GEGLU: [M][N/2])
     int geglu;              // rows of w pre-permuted in (value16 | gate16) blocks; out = v * gelu(g)
+    float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch for split-K on small images (may be null)
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);

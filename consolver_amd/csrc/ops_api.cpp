@@ -3,10 +3,19 @@
 #include "../../include/consolver_hip_ops.h"
 #include <cstring>
 
+extern int g_tune_halo;
+
 extern "C" {
 
+int cs_set_tuning(const char* key, int value) {
+    if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
+    if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
+    CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
+}
+
 int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
-                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out, void* stream) {
+                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
+                 void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     IgemmArgs a{};
     a.a0 = (const f16*)x0; a.a1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi;
     if (stride != 1 && stride != 2) CS_FAIL(CS_E_ARG, "conv2d: stride must be 1 or 2");
@@ -14,6 +23,7 @@ int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, 
     a.Wo = upsample ? 2 * Wi : (stride == 2 ? Wi / 2 : Wi);
     a.taps = taps; a.stride = stride; a.upsample = upsample; a.N = N; a.w = (const f16*)w; a.bias = (const f16*)bias;
     a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
     return launch_igemm(a, (hipStream_t)stream);
 }
 

@@ -269,6 +269,7 @@ struct Run {
     CsUNet* u; hipStream_t s; bool dry; int B; int rc = CS_OK;
     const f16* ctx = nullptr; f16* kv = nullptr; const f16* tproj = nullptr; int tstride = 0;
     float* gn_ws = nullptr;
+    float* sk_ws = nullptr; size_t sk_bytes = 0;
 
     f16* alloc(size_t halfs) {
         void* p = u->arena.alloc(halfs * sizeof(f16));
@@ -296,6 +297,7 @@ struct Run {
         IgemmArgs a{};
         a.a0 = a0; a.a1 = a1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.taps = c.taps; a.stride = stride;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res; a.out = out; a.geglu = 0;
+        a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double M = (double)B * Ho * Wo;
         const double bytes = 2.0 * (M * (c0 + c1) * (c.taps == 9 && stride == 1 && !up ? 1.0 : 1.0) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * (res ? 2 : 1));
         launch(c.taps == 9 ? P_CONV3 : P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
@@ -378,6 +380,7 @@ struct Run {
 };
 
 size_t kv_cache_bytes(const CsUNet* u, int B) { return ((u->kv_halfs_per_token * (size_t)B * u->cfg.ctx_len * sizeof(f16)) + 255) & ~(size_t)255; }
+size_t sk_ws_bytes(const CsUNet*, int B) { return ((size_t)B * (8u << 20)) + (16u << 20); }
 size_t gn_ws_bytes(const CsUNet* u, int B) {
     const int cmax = 2 * u->cfg.block_out_channels[3];
     return (((size_t)B * (GN_SPLITS + 1) * cmax * 2 * sizeof(float)) + 255) & ~(size_t)255;
@@ -387,12 +390,13 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
                 char* ws, size_t ws_bytes, int kv_valid, hipStream_t s) {
     const CsUNetConfig& c = u->cfg;
     const int B = n_lat * dup;
-    const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B);
+    const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B) + sk_ws_bytes(u, B);
     if (!dry && ws_bytes < kvb + gnb) CS_FAIL(CS_E_ARG, "unet: workspace too small (%zu < %zu)", ws_bytes, kvb + gnb);
     u->arena.reset(ws + kvb + gnb, dry ? 0 : ws_bytes - kvb - gnb, dry);
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
+    R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
     const int c0 = c.block_out_channels[0], td = 4 * c0, L = c.ctx_len;
     int H = c.sample_size, W = c.sample_size;
 
@@ -566,7 +570,7 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || batch <= 0) return 0;
     run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
-    return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + u->arena.peak + 4096;
+    return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + u->arena.peak + 4096;
 }
 
 double cs_unet_flops(const CsUNet* cu, int batch) {

@@ -23,7 +23,10 @@ def pack_conv_weight(w):
     return w.reshape(co, ci, -1).permute(0, 2, 1).contiguous().to(torch.float16)
 
 
-def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None):
+_SPLITK_WS = {}
+
+
+def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, splitk=True):
     _f16(x0, "x0")
     B, Hi, Wi, c0 = x0.shape
     c1 = x1.shape[-1] if x1 is not None else 0
@@ -32,8 +35,14 @@ def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, t
     Wo = 2 * Wi if upsample else (Wi // 2 if stride == 2 else Wi)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float16, device=x0.device)
     tstride = 0 if (temb is None or temb.shape[0] == 1) else temb.shape[1]
+    ws = None
+    if splitk and taps == 9:
+        ws = _SPLITK_WS.get(x0.device)
+        if ws is None:
+            ws = _SPLITK_WS[x0.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x0.device)
     L.check(L.lib().cs_op_conv2d(L.ptr(x0), c0, L.ptr(x1), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
-                                 L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(out), L.stream_ptr(x0.device)))
+                                 L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(out),
+                                 L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x0.device)))
     return out
 
 
@@ -92,3 +101,8 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     out = torch.empty_like(x)
     L.check(L.lib().cs_op_layer_norm(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), M, Cc, float(eps), L.stream_ptr(x.device)))
     return out
+
+
+def set_tuning(key, value):
+    """kernel-selection knob, e.g. set_tuning("conv_halo", 2) forces the halo-resident conv3x3 kernel."""
+    L.check(L.lib().cs_set_tuning(key.encode(), int(value)))

@@ -22,9 +22,12 @@ extern "C" {
 
 /* conv (taps = 9: 3x3 pad 1, stride 1|2, optional fused nearest-x2 upsample of the input; taps = 1: 1x1)
  * over the channel concatenation of x0 [B,Hi,Wi,c0] and x1 [B,Hi,Wi,c1] (x1 may be NULL, c1 = 0).
- * out[B,Ho,Wo,N] = conv + bias[N] + temb[b*temb_stride + n] + res[B,Ho,Wo,N]  (each optional). */
+ * out[B,Ho,Wo,N] = conv + bias[N] + temb[b*temb_stride + n] + res[B,Ho,Wo,N]  (each optional).
+ * splitk_ws: optional fp32 scratch (device) that lets small-image 3x3 convs split their channel chunks over
+ * more workgroups (needs splits * M * N * 4 bytes; NULL disables). */
 int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
-                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out, void* stream);
+                 const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
+                 void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
 /* out[M,N] = x[M,K] w[N,K]^T + bias + res ; geglu != 0: w rows pre-permuted in (16 value | 16 gate)
  * blocks (see cs_op_geglu_pack) and out[M,N/2] = value * gelu(gate). */
@@ -47,6 +50,9 @@ int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int 
 
 /* LayerNorm over the last dim of x[M,C] */
 int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
+
+/* kernel-selection knobs (tests / tuning): "conv_halo" = 0 never, 1 auto (default), 2 whenever the shape allows */
+int cs_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,62 @@ def test_conv2d(case):
     assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
 
 
+HALO_CASES = [  # B, H, cin, N : halo-resident conv3x3 kernel forced on small shapes (covers every tile geometry)
+    (2, 64, 64, 320), (3, 32, 128, 160), (2, 16, 64, 320), (5, 8, 64, 160), (1, 8, 128, 320), (1, 64, 320, 640)]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv3x3_halo_kernel(case):
+    B, H, cin, N = case
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
+    ops.set_tuning("conv_halo", 2)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    generic = None
+    ops.set_tuning("conv_halo", 0)
+    try:
+        generic = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+    assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+    assert rel_l2(out.float(), generic.float()) < 5e-4      # same math, different k order
+
+
+@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320)])
+def test_conv3x3_halo_kernel_fused_upsample(B, H, cin, N):
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    ops.set_tuning("conv_halo", 2)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, upsample=True)
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    assert out.shape == (B, 2 * H, 2 * H, N)
+    assert rel_l2(nchw(out), ref) < 1e-3
+
+
+@pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160)])
+def test_conv3x3_halo_kernel_split_k(B, H, cin, N):
+    """small images: channel chunks split over workgroups, fp32 partials + fused reduce epilogue"""
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
+    ops.set_tuning("conv_halo", 2)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
+        res2 = res.clone()
+        out2 = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res2)   # deterministic (no atomics)
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+    assert torch.equal(out, out2)
+
+
 def test_conv2d_temb_broadcast_and_inplace_residual():
     x = rnd(2, 8, 8, 64, seed=1)
     w = rnd(128, 64, 3, 3, seed=2, scale=0.05)

@@ -1,0 +1,62 @@
+"""Micro-benchmark of the HIP ops on the SD1.5 UNet shapes (batch 32 = 16 images x CFG)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from consolver_amd import ops
+
+dev = "cuda:0"
+def rnd(*s, scale=1.0): return (torch.randn(*s, device=dev) * scale).half()
+
+def timeit(fn, iters=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+B = 32
+rows = []
+def lin(M, K, N, geglu=False, res=False, tag=""):
+    x, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
+    r = rnd(M, N) if res else None
+    ms = timeit(lambda: ops.linear(x, w, b, res=r, geglu=geglu))
+    fl = 2.0 * M * K * N
+    rows.append((f"linear{'+geglu' if geglu else ''}{'+res' if res else ''} {tag}", M, K, N, ms, fl / ms / 1e9))
+
+def conv(H, cin, cout, taps=9, stride=1, up=False, tag=""):
+    x = rnd(B, H, H, cin); k = 3 if taps == 9 else 1
+    w = ops.pack_conv_weight(rnd(cout, cin, k, k, scale=(cin * taps) ** -0.5)); b = rnd(cout)
+    ms = timeit(lambda: ops.conv2d(x, w, b, taps=taps, stride=stride, upsample=up))
+    Ho = 2 * H if up else H // stride
+    fl = 2.0 * B * Ho * Ho * taps * cin * cout
+    rows.append((f"conv{k}x{k} s{stride}{' up' if up else ''} {tag}", B * Ho * Ho, taps * cin, cout, ms, fl / ms / 1e9))
+
+def attn(N, C, Nk=None, tag=""):
+    Nk = Nk or N
+    q, k, v = rnd(B, N, C), rnd(B, Nk, C), rnd(B, Nk, C)
+    ms = timeit(lambda: ops.attention(q, k, v, 8))
+    rows.append((f"attention dh={C // 8} {tag}", N, Nk, C, ms, 4.0 * B * N * Nk * C / ms / 1e9))
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "gemm"):
+    lin(8192, 8192, 8192, tag="square")
+    lin(131072, 320, 960, tag="qkv L0"); lin(131072, 320, 320, res=True, tag="out L0"); lin(131072, 320, 2560, geglu=True, tag="ff1 L0")
+    lin(131072, 1280, 320, res=True, tag="ff2 L0")
+    lin(32768, 640, 1920, tag="qkv L1"); lin(32768, 640, 5120, geglu=True, tag="ff1 L1"); lin(32768, 2560, 640, res=True, tag="ff2 L1")
+    lin(8192, 1280, 3840, tag="qkv L2"); lin(8192, 1280, 10240, geglu=True, tag="ff1 L2"); lin(8192, 5120, 1280, res=True, tag="ff2 L2")
+    lin(2464, 768, 640, tag="cross kv")
+if which in ("all", "conv"):
+    conv(64, 320, 320, tag="L0"); conv(64, 640, 320, tag="L0 up"); conv(64, 960, 320, tag="L0 up")
+    conv(32, 640, 640, tag="L1"); conv(32, 1280, 640, tag="L1 up"); conv(32, 1920, 640, tag="L1 up")
+    conv(16, 1280, 1280, tag="L2"); conv(16, 2560, 1280, tag="L2 up")
+    conv(8, 1280, 1280, tag="L3"); conv(8, 2560, 1280, tag="L3 up")
+    conv(64, 320, 320, stride=2, tag="down"); conv(32, 640, 640, up=True, tag="upsample")
+    conv(64, 320, 320, taps=1, tag="proj L0"); conv(16, 1280, 1280, taps=1, tag="proj L2")
+if which in ("all", "attn"):
+    attn(4096, 320, tag="self L0"); attn(1024, 640, tag="self L1"); attn(256, 1280, tag="self L2"); attn(64, 1280, tag="self L3")
+    attn(4096, 320, 77, tag="cross L0")
+print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
+for r in rows:
+    print(f"{r[0]:40s} {r[1]:8d} {r[2]:8d} {r[3]:6d} {r[4]:9.3f} {r[5] / 1e3:9.1f}")
