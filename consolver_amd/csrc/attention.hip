@@ -38,14 +38,30 @@ __device__ __forceinline__ f16x4 tr_read(const char* lds_addr) {
     return u.b;
 }
 
+// max over the lanes {l, l^16} / {l, l^32} with the gfx950 permlane swaps (pure VALU, no LDS round trip)
+__device__ __forceinline__ float xor16_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <int DH, int QT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr int DK = (DH + 31) / 32 * 32;
     constexpr int KSTEPS = DK / 32;
     constexpr int DVT = (DH + 15) / 16;
     constexpr int DVP = DVT * 16;
-    constexpr int KS = DK * 2 + 16;                                   // bytes per K row in LDS
+    constexpr bool KSWZ = (DK == 64);                                 // 128-B rows: XOR-swizzled chunks, conflict-free b128 reads
+    constexpr int KS = KSWZ ? 128 : DK * 2 + 16;                      // bytes per K row in LDS
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;  // odd multiple of 32 B
+    // spare padded V column (dh = 40 -> 48): a column of ones makes the P V MFMA also produce the softmax
+    // denominator (row DH of O^T), replacing 16*QT v_add_f32 per tile per lane and the separate l rescale
+    constexpr bool ONES = (DVP > DH);
     constexpr int CPR = DH / 8;                                       // 16-byte chunks per K/V row
     constexpr int NCH = (64 * CPR + 255) / 256;
     constexpr int KBUF = 64 * KS, VBUF = 64 * VS;
@@ -59,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const int q0 = blockIdx.x * (4 * QT * 16) + w * (QT * 16);
 
     // zero both buffers once: pad columns stay zero, tails are rewritten with zeros explicitly
+    // (with the swizzled K layout the pad chunks 5..7 of a row land in permuted slots: still never written)
     for (int o = tid * 16; o < 2 * KBUF + 2 * VBUF; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
 
     // ---- Q fragments (B operand: lane = query column i16, k = 8g + j) ---------------------------
@@ -90,34 +107,55 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const f16* vbase = p.v + (size_t)b * p.Nk * p.v_stride + h * DH;
 
     u32x4 kreg[NCH], vreg[NCH];
-    auto load_tile = [&](int tile) {
+    // per-thread staging slots (loop invariant): chunk id -> (row, 16-byte chunk) of the 64-key tile
+    int st_row[NCH], st_koff[NCH], st_voff[NCH], st_lk[NCH], st_lv[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int id = tid + c * 256;
-            const int row = id / CPR, ch = id - row * CPR;
-            const int key = tile * 64 + row;
-            u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-            if (id < 64 * CPR && key < p.Nk) {
-                kv = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * p.k_stride + ch * 8);
-                vv = *reinterpret_cast<const u32x4*>(vbase + (size_t)key * p.v_stride + ch * 8);
+    for (int c = 0; c < NCH; ++c) {
+        const int id = tid + c * 256;
+        const int row = id / CPR, ch = id - row * CPR;
+        st_row[c] = (id < 64 * CPR) ? row : (1 << 20);            // slots past the tile never pass a bounds test
+        st_koff[c] = (id < 64 * CPR) ? row * p.k_stride + ch * 8 : 0;   // idle slots re-read key 0 (never stored)
+        st_voff[c] = (id < 64 * CPR) ? row * p.v_stride + ch * 8 : 0;
+        st_lk[c] = row * KS + (KSWZ ? (ch ^ (row & 7)) : ch) * 16;
+        st_lv[c] = row * VS + ch * 16;
+    }
+    auto load_tile = [&](int tile) {
+        const f16* kt_base = kbase + (size_t)tile * 64 * p.k_stride;
+        const f16* vt_base = vbase + (size_t)tile * 64 * p.v_stride;
+        const int rows_left = p.Nk - tile * 64;                   // >= 64 for every tile but a ragged last one
+        if (rows_left >= 64) {                                    // wave-uniform fast path: no per-lane guards
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                kreg[c] = *reinterpret_cast<const u32x4*>(kt_base + st_koff[c]);
+                vreg[c] = *reinterpret_cast<const u32x4*>(vt_base + st_voff[c]);
             }
-            kreg[c] = kv; vreg[c] = vv;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+                if (st_row[c] < rows_left) {
+                    kv = *reinterpret_cast<const u32x4*>(kt_base + st_koff[c]);
+                    vv = *reinterpret_cast<const u32x4*>(vt_base + st_voff[c]);
+                }
+                kreg[c] = kv; vreg[c] = vv;
+            }
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int id = tid + c * 256;
-            const int row = id / CPR, ch = id - row * CPR;
-            if (id < 64 * CPR) {
-                *reinterpret_cast<u32x4*>(lK + buf * KBUF + row * KS + ch * 16) = kreg[c];
-                *reinterpret_cast<u32x4*>(lV + buf * VBUF + row * VS + ch * 16) = vreg[c];
+            if (st_row[c] < 64) {
+                *reinterpret_cast<u32x4*>(lK + buf * KBUF + st_lk[c]) = kreg[c];
+                *reinterpret_cast<u32x4*>(lV + buf * VBUF + st_lv[c]) = vreg[c];
             }
         }
     };
 
     load_tile(0);
     __syncthreads();            // zero fill complete
+    if (ONES) {
+        for (int r = tid; r < 128; r += 256) *reinterpret_cast<f16*>(lV + (r >> 6) * VBUF + (r & 63) * VS + DH * 2) = (f16)1.0f;
+    }
     store_tile(0);
     __syncthreads();
 
@@ -130,16 +168,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         // ---- S^T = K Q^T : s[kt][t] holds keys kt*16 + 4g + r, query column i16 -------------------
         f32x4 s[4][QT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int t = 0; t < QT; ++t) s[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(tk + (kt * 16 + i16) * KS + (ks * 32 + 8 * g) * 2);
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(
+                    tk + (kt * 16 + i16) * KS + (KSWZ ? ((ks * 4 + g) ^ (i16 & 7)) * 16 : (ks * 32 + 8 * g) * 2));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], s[kt][t], 0, 0, 0);
+                for (int t = 0; t < QT; ++t)
+                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[kt][t], 0, 0, 0);
             }
         }
         if (tile * 64 + 64 > p.Nk) {   // ragged last tile: mask keys >= Nk
@@ -162,24 +198,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
             const float m_new = fmaxf(m_run[t], mx);
-            const float alpha = exp2f(p.c * (m_run[t] - m_new));
             const float cm = p.c * m_new;
-            m_run[t] = m_new;
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[kt][t][r] * p.c - cm);
+                    const float e = __builtin_amdgcn_exp2f(s[kt][t][r] * p.c - cm);     // raw v_exp_f32 (arg <= 0)
                     s[kt][t][r] = e;
-                    ps += e;
+                    if (!ONES) ps += e;
                 }
-            l_run[t] = l_run[t] * alpha + ps;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[t]) != 0) {   // wave-uniform: some column's max moved
+                const float alpha = __builtin_amdgcn_exp2f(p.c * (m_run[t] - m_new));
+                if (!ONES) l_run[t] *= alpha;
 #pragma unroll
-            for (int a = 0; a < DVT; ++a) o_acc[a][t] *= alpha;
+                for (int a = 0; a < DVT; ++a) o_acc[a][t] *= alpha;
+                m_run[t] = m_new;
+            }
+            if (!ONES) l_run[t] += ps;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 f16x8 f;
@@ -210,9 +249,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        float l = l_run[t];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if (ONES) {
+            // row DH of O^T = sum_k P[k][q]: tile a = DH/16, lane group g = (DH%16)/4, register 0
+            l = __shfl(o_acc[DH / 16][t][(DH % 16) % 4], ((DH % 16) / 4) * 16 + i16, 64);
+        } else {
+            l = l_run[t];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.0f / l;
         const int qrow = q0 + t * 16 + i16;
         if (qrow >= p.Nq) continue;
@@ -231,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 template <int DH, int QT>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
-    constexpr int KS = DK * 2 + 16;
+    constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
     constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
     auto kfn = attn_kernel<DH, QT>;

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 extern int g_tune_halo;
+extern int g_tune_biggemm;
 
 namespace {
 
@@ -61,53 +62,82 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 
-// lane holds, per (nt, mt) tile, pixel m = ..+(lane&15), channels 4*(lane>>4)..+3
-template <bool GEGLU, int NT, int MT>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int lane) {
-    const int g4 = (lane >> 4) * 4;
+// Epilogue.  After the MFMAs a lane holds, per (nt, mt) tile, pixel m = ..+(lane&15) and channels
+// 4*(lane>>4)..+3: storing that directly means 8-byte lanes scattered over 16 rows per instruction and
+// 2-3x more store (and residual-load) instructions than bytes justify -- the short-K layers were
+// store-ISSUE bound.  Instead each wave converts (acc + bias [GEGLU]) to fp16 into its own LDS patch
+// (the k-loop's stage buffers are free by now), then streams the patch out ROW-wise: 16 bytes per lane,
+// whole 128/160-byte row segments per pixel, with the time-embedding and residual adds done on the way
+// (fp16-rounded conv output + fp16 residual, i.e. the same two roundings torch's fp16 graph performs).
+template <bool GEGLU, int NT, int MT, int GROUP>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int lane, char* wave_lds) {
+    static_assert(NT % GROUP == 0, "GROUP must divide NT");
+    constexpr int COLS = GEGLU ? GROUP * 8 : GROUP * 16;      // output columns per pass
+    constexpr int ROWB = (COLS + 8) * 2;                      // padded LDS row (bytes, multiple of 16)
+    constexpr int CH = COLS / 8;                              // 16-byte chunks per row
+    const int g4 = (lane >> 4) * 4, i16 = lane & 15;
+    const int Nout = GEGLU ? (p.N >> 1) : p.N;
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = m_base + j * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const f16* trow = nullptr;
-        if (p.temb) trow = p.temb + (size_t)(m / p.HoWo) * p.temb_stride;
-        if (GEGLU) {
-            const int No = p.N >> 1;
+    for (int grp = 0; grp < NT / GROUP; ++grp) {
+        // ---- phase 1: registers -> LDS patch [64 rows][COLS] fp16 ----------------------------------------
 #pragma unroll
-            for (int i = 0; i < NT; i += 2) {
-                const int nrow = n_base + i * 16 + g4;        // row of the permuted weight (value half)
-                const int nout = ((n_base + i * 16) >> 1) + g4;
+        for (int ii = 0; ii < GROUP; ii += (GEGLU ? 2 : 1)) {
+            const int i = grp * GROUP + ii;
+            const int n = n_base + i * 16 + g4;                // (GEGLU: row of the permuted weight, value half)
+            float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                const f16x4 t = *reinterpret_cast<const f16x4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = (float)t[r];
+                if (GEGLU) {
+                    const f16x4 u = *reinterpret_cast<const f16x4*>(p.bias + n + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bg[r] = (float)u[r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
                 f16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r], g = acc[i + 1 < NT ? i + 1 : i][j][r];
-                    if (p.bias) { v += (float)p.bias[nrow + r]; g += (float)p.bias[nrow + 16 + r]; }
-                    o[r] = (f16)(v * gelu_erf(g));
+                    if (GEGLU) o[r] = (f16)((acc[i][j][r] + bv[r]) * gelu_erf(acc[i + 1 < NT ? i + 1 : i][j][r] + bg[r]));
+                    else o[r] = (f16)(acc[i][j][r] + bv[r]);
                 }
-                *reinterpret_cast<f16x4*>(p.out + (size_t)m * No + nout) = o;
+                const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
+                *reinterpret_cast<f16x4*>(wave_lds + (j * 16 + i16) * ROWB + col * 2) = o;
             }
-        } else {
+        }
+        // ---- phase 2: LDS patch -> global, 16 bytes per lane, + temb + residual ------------------------------
+        const int n0 = GEGLU ? ((n_base + grp * GROUP * 16) >> 1) : n_base + grp * GROUP * 16;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n_base + i * 16 + g4;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (p.bias) {
-                    const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bias + n);
+        for (int k = 0; k < CH; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m_base + row;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
+            if (m < p.M) {
+                const size_t off = (size_t)m * Nout + n0 + ch * 8;
+                if (p.temb || p.res) {
+                    float f[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+                    for (int r = 0; r < 8; ++r) f[r] = (float)v[r];
+                    if (p.temb) {
+                        const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n0 + ch * 8);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
+                    }
+                    if (p.res) {
+                        const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + off);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
+                    }
+                    f16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
+                    *reinterpret_cast<f16x8*>(p.out + off) = o;
+                } else {
+                    *reinterpret_cast<f16x8*>(p.out + off) = v;
                 }
-                if (trow) {
-                    const f16x4 tv = *reinterpret_cast<const f16x4*>(trow + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)tv[r];
-                }
-                if (p.res) {
-                    const f16x4 rv = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.N + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                *reinterpret_cast<f16x4*>(p.out + (size_t)m * p.N + n) = o;
             }
         }
     }
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
         }
     }
     if (p.splits == 1) {
-        igemm_epilogue<false, NT, MT>(p.e, acc, m_blk + wm * 64, n_blk + wn * 80, lane);
+        igemm_epilogue<false, NT, MT, 5>(p.e, acc, m_blk + wm * 64, n_blk + wn * 80, lane, smem + w * 11264);
     } else {
         // split-K: raw fp32 partial sums, 16-byte stores (4 consecutive channels per lane)
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
@@ -318,6 +348,107 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
         for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
         *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-tile GEMM for the linear / 1x1 layers: 256 x 320 x 64 tile, 8 wave64 (4 x 2), wave tile
+// 64 x 160.  Every SD1.5 layer width (320 ... 10240) is a multiple of 320, and the tile stages
+// 72 KB per 10.5 MFLOP k-step = 142 FLOP per LDS-DMA byte, 2x the 128 x {128,160} tile: these
+// layers were bound by L2->LDS traffic (the activation panel was re-staged N/160 times), not MFMA.
+// Two LDS stages (144 KB), one workgroup per CU, 9 DMA issues per wave per 80 MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <bool GEGLU>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
+    constexpr int BMX = 256, BNX = 320, NT = 10, MT = 4;
+    constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    const int m_blk = tm * BMX, n_blk = tn * BNX;
+
+    const int pch = lane & 7;
+    int a_row[4], a_chunk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (w * 4 + j) + (lane >> 3);
+        const int m = m_blk + r;
+        a_chunk[j] = (pch ^ ((r >> 1) & 7)) * 8;
+        a_row[j] = (m < p.M) ? m : -1;
+    }
+    const f16* b_src[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = 8 * (w * 5 + j) + (lane >> 3);
+        b_src[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 7)) * 8;
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
+
+    auto stage = [&](int kt, int buf) {
+        const int cc = kt * BK;
+        const f16* src; int cs, coff;
+        if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
+        char* la = smem + buf * STAGE + (w * 4) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = a_row[j] >= 0;
+            const uintptr_t real = (uintptr_t)(src + ((long)a_row[j] * cs + coff + a_chunk[j]));
+            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)ok;
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), la + j * 1024);
+        }
+        char* lb = smem + buf * STAGE + A_BYTES + (w * 5) * 1024;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int swz = (lane >> 1) & 7;
+    const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
+    const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
+        const char* ta = smem + buf * STAGE + (wm * 64) * 128;
+        const char* tb = smem + buf * STAGE + A_BYTES + (wn * 160) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? frag_off1 : frag_off0;
+            f16x8 fa[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    igemm_epilogue<GEGLU, NT, MT, (GEGLU ? 10 : 5)>(p, acc, m_blk + wm * 64, n_blk + wn * 160, lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -444,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<GEGLU, NT, MT>(p, acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane);
+    igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -464,6 +595,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 int g_tune_halo = 1;
+int g_tune_biggemm = 1;
 
 double igemm_flops(const IgemmArgs& a) {
     const double M = (double)a.B * a.Ho * a.Wo;
@@ -477,7 +609,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (cin % BK || a.c0 % BK || (a.c1 && !a.a1)) CS_FAIL(CS_E_SHAPE, "igemm: channels (%d,%d) must be multiples of %d", a.c0, a.c1, BK);
     if (a.B <= 0 || a.Ho <= 0 || a.Wo <= 0) return (a.B < 0) ? CS_E_SHAPE : CS_OK;
     if (a.taps == 1 && (a.stride != 1 || a.upsample || a.Hi != a.Ho || a.Wi != a.Wo)) CS_FAIL(CS_E_ARG, "igemm: 1x1 needs stride 1, no upsample");
-    if (a.geglu && (a.N % 256)) CS_FAIL(CS_E_SHAPE, "igemm: GEGLU needs N %% 256 == 0 (N=%d)", a.N);
+    if (a.geglu && (a.N % 256) && (a.N % 320)) CS_FAIL(CS_E_SHAPE, "igemm: GEGLU needs N %% 256 == 0 or N %% 320 == 0 (N=%d)", a.N);
     IgemmParams p;
     p.a0 = a.a0; p.a1 = a.a1; p.c0 = a.c0; p.c1 = a.c1;
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo; p.HoWo = a.Ho * a.Wo;
@@ -533,8 +665,25 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
             }
         }
     }
+    if (a.geglu && conv3) CS_FAIL(CS_E_ARG, "igemm: GEGLU epilogue only for linear layers");
+    if (g_tune_biggemm && !conv3 && a.N % 320 == 0) {
+        const int tiles_m = (p.M + 255) / 256, tn = a.N / 320;
+        if (tiles_m * tn >= 192 || g_tune_biggemm == 2) {
+            p.tiles_n = tn; p.nblk = tiles_m * tn;
+            constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
+            static bool configured = false;
+            if (!configured) {
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                configured = true;
+            }
+            if (a.geglu) hipLaunchKernelGGL(gemm_big_kernel<true>, dim3(p.nblk), dim3(512), lds, s, p);
+            else hipLaunchKernelGGL(gemm_big_kernel<false>, dim3(p.nblk), dim3(512), lds, s, p);
+            CS_CHECK_LAUNCH();
+            return CS_OK;
+        }
+    }
     if (a.geglu) {
-        if (conv3) CS_FAIL(CS_E_ARG, "igemm: GEGLU epilogue only for linear layers");
         return launch_variant<128, false, true>(p, s);
     }
     if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s) : launch_variant<128, false, false>(p, s);

@@ -39,36 +39,25 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_
     }
 }
 
-// pass 2: one block per sample: reduce the splits, group statistics, per-channel scale/shift
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
-                                   const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];    // [2*Ctot] channel sums, then [2*groups]
-    float* chs = sm; float* chq = sm + Ctot; float* gm = sm + 2 * Ctot; float* gr = gm + groups;
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
-        float a = 0.f, q = 0.f;
-        for (int s = 0; s < S; ++s) {
-            const float* p = partial + (((size_t)b * S + s) * Ctot + c) * 2;
-            a += p[0]; q += p[1];
-        }
-        chs[c] = a; chq[c] = q;
-    }
-    __syncthreads();
+// pass 2: one wave per (sample, group): reduce the splits, group statistics, per-channel scale/shift
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
+                                                         const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int cpg = Ctot / groups;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        float a = 0.f, q = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; q += chq[c]; }
-        const float n = (float)cpg * (float)HW;
-        const float mean = a / n;
-        const float var = fmaxf(q / n - mean * mean, 0.f);
-        gm[g] = mean; gr[g] = rsqrtf(var + eps);
+    float a = 0.f, q = 0.f;
+    for (int i = lane; i < S * cpg; i += 64) {            // (split, channel) pairs of this group
+        const int s = i / cpg, c = g * cpg + (i - s * cpg);
+        const float* p = partial + (((size_t)b * S + s) * Ctot + c) * 2;
+        a += p[0]; q += p[1];
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
-        const int g = c / cpg;
-        const float sc = (float)gamma[c] * gr[g];
+    a = wave_sum(a); q = wave_sum(q);
+    const float n = (float)cpg * (float)HW;
+    const float mean = a / n;
+    const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float sc = (float)gamma[c] * rstd;
         scale_shift[((size_t)b * Ctot + c) * 2] = sc;
-        scale_shift[((size_t)b * Ctot + c) * 2 + 1] = (float)beta[c] - gm[g] * sc;
+        scale_shift[((size_t)b * Ctot + c) * 2 + 1] = (float)beta[c] - mean * sc;
     }
 }
 
@@ -167,7 +156,7 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
         if (T > 1024) CS_FAIL(CS_E_SHAPE, "group_norm: C=%d too wide", C);
         hipLaunchKernelGGL(gn_stats_kernel, dim3(S, a.B), dim3(T), (size_t)T * 16 * sizeof(float), s, x, C, a.HW, src ? a.c0 : 0, Ctot, a.partial);
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(256), (size_t)(2 * Ctot + 2 * a.groups) * sizeof(float), s,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s,
                        a.partial, S, Ctot, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
     int chunks = (a.HW * (Ctot / 8) + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
     if (chunks < 1) chunks = 1;

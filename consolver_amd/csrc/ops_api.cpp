@@ -4,12 +4,14 @@
 #include <cstring>
 
 extern int g_tune_halo;
+extern int g_tune_biggemm;
 
 extern "C" {
 
 int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
+    if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
 }
 

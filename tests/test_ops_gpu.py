@@ -149,6 +149,26 @@ def test_linear(M, K, N):
     assert torch.equal(r2, out)
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(256, 64, 320, False), (1000, 320, 960, False), (300, 128, 640, True), (513, 64, 2560, True)])
+def test_linear_big_tile_kernel(M, K, N, geglu):
+    """256x320 tile kernel forced on small shapes (ragged M tiles, GEGLU pairs, residual)"""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.2)
+    ops.set_tuning("gemm_big", 2)
+    try:
+        if geglu:
+            wp, bp = ops.geglu_pack(w, b)
+            out = ops.linear(x, wp.to(DEV), bp.to(DEV), geglu=True)
+            val, gate = F.linear(x.float(), w.float(), b.float()).chunk(2, dim=-1)
+            ref = val * F.gelu(gate)
+        else:
+            r = rnd(M, N, seed=4)
+            out = ops.linear(x, w, b, res=r)
+            ref = F.linear(x.float(), w.float(), b.float()) + r.float()
+    finally:
+        ops.set_tuning("gemm_big", 1)
+    assert rel_l2(out.float(), ref) < 1.5e-3
+
+
 @pytest.mark.parametrize("M,C", [(128, 64), (300, 320), (64, 1280)])
 def test_linear_geglu(M, C):
     x = rnd(M, C, seed=1)
