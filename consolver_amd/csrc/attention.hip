@@ -19,6 +19,7 @@
 //   * O^T leaves each lane with 4 consecutive channels of one query row -> 8-byte stores.
 #include "ops.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -87,8 +88,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d = ks * 32 + 8 * g;
             f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qrow < p.Nq && d < DH)
+            if (qrow < p.Nq && d < DH) {
                 v = *reinterpret_cast<const f16x8*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * p.c);      // fold scale*log2(e) into Q
+            }
             qf[t][ks] = v;
         }
     }
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         for (int t = 0; t < QT; ++t) o_acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) { m_run[t] = -1e30f; l_run[t] = 0.f; }
+    for (int t = 0; t < QT; ++t) { m_run[t] = 0.f; l_run[t] = 0.f; }
 
     const int ntiles = (p.Nk + 63) / 64;
     const f16* kbase = p.k + (size_t)b * p.Nk * p.k_stride + h * DH;
@@ -159,14 +163,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     store_tile(0);
     __syncthreads();
 
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // Online softmax with the running reference max folded into the MFMA accumulator: Q is pre-scaled by
+    // c = scale*log2(e), and the score MFMA chain starts from C = -m_ref[q] (one register quad per query
+    // tile, constant along the key rows), so the accumulator already holds the exponent S' = c q.k - m_ref.
+    // m_ref is only moved when some column's tile maximum exceeds it by more than THR (= 2^8 headroom in the
+    // fp16 P values; exactness is unaffected because P and the denominator share the same reference), which
+    // is a rare, wave-uniform slow path: the steady state is max3 / v_exp / cvt only.
+    constexpr float THR = 8.0f;
+    auto do_tile = [&](int tile, auto ragged_tag, auto first_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int buf = tile & 1;
         if (tile + 1 < ntiles) load_tile(tile + 1);
         const char* tk = lK + buf * KBUF;
         const char* tv = lV + buf * VBUF;
 
-        // ---- S^T = K Q^T : s[kt][t] holds keys kt*16 + 4g + r, query column i16 -------------------
+        // ---- S' = c K Q^T - m_ref : s[kt][t] holds keys kt*16 + 4g + r, query column i16 -------------
         f32x4 s[4][QT];
+        f32x4 negm[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { const float v = FIRST ? 0.f : -m_run[t]; negm[t] = f32x4{v, v, v, v}; }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
@@ -175,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                     tk + (kt * 16 + i16) * KS + (KSWZ ? ((ks * 4 + g) ^ (i16 & 7)) * 16 : (ks * 32 + 8 * g) * 2));
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[kt][t], 0, 0, 0);
+                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t], 0, 0, 0);
             }
         }
-        if (tile * 64 + 64 > p.Nk) {   // ragged last tile: mask keys >= Nk
+        if (RAGGED) {   // ragged last tile: mask keys >= Nk (compiled only into the peeled last iteration)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -189,8 +205,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                     }
         }
 
-        // ---- online softmax per query column ------------------------------------------------------
-        f16x8 pf[QT][2];
+        // ---- per-lane tile maxima; move the reference only when needed (wave-uniform decision) ---------
+        float mxl[QT];
+        bool over = false;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = s[0][t][0];
@@ -198,26 +215,41 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
-            mx = xor16_max(mx);
-            mx = xor32_max(mx);
-            const float m_new = fmaxf(m_run[t], mx);
-            const float cm = p.c * m_new;
+            mxl[t] = mx;
+            over |= mx > THR;
+        }
+        if (FIRST || __builtin_amdgcn_ballot_w64(over) != 0) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const float mx = xor32_max(xor16_max(mxl[t]));         // column maximum over all 64 keys
+                const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+                m_run[t] = FIRST ? delta : m_run[t] + delta;
+                if (!FIRST) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    if (!ONES) l_run[t] *= alpha;
+#pragma unroll
+                    for (int a = 0; a < DVT; ++a) o_acc[a][t] *= alpha;
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][t][r] -= delta;
+            }
+        }
+
+        // ---- P = exp2(S') -> fp16 fragments of the second product ------------------------------------------
+        f16x8 pf[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
             float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[kt][t][r] * p.c - cm);     // raw v_exp_f32 (arg <= 0)
+                    const float e = __builtin_amdgcn_exp2f(s[kt][t][r]);     // raw v_exp_f32
                     s[kt][t][r] = e;
                     if (!ONES) ps += e;
                 }
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[t]) != 0) {   // wave-uniform: some column's max moved
-                const float alpha = __builtin_amdgcn_exp2f(p.c * (m_run[t] - m_new));
-                if (!ONES) l_run[t] *= alpha;
-#pragma unroll
-                for (int a = 0; a < DVT; ++a) o_acc[a][t] *= alpha;
-                m_run[t] = m_new;
-            }
             if (!ONES) l_run[t] += ps;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
@@ -244,7 +276,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
         if (tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
-    }
+    };
+    const int full_tiles = p.Nk / 64;
+    if (full_tiles > 0) do_tile(0, std::false_type{}, std::true_type{});
+    else do_tile(0, std::true_type{}, std::true_type{});
+    for (int tile = 1; tile < full_tiles; ++tile) do_tile(tile, std::false_type{}, std::false_type{});
+    if (full_tiles > 0 && full_tiles < ntiles) do_tile(full_tiles, std::true_type{}, std::false_type{});
 
     // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll
@@ -305,7 +342,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     p.c = a.scale * 1.4426950408889634f;
     switch (a.dh) {
         case 40: {
-            static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 2;   // tuning knob
+            static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 4;   // tuning knob
             if (qt == 4) return launch_attn<40, 4>(p, a.B, s);
             if (qt == 3) return launch_attn<40, 3>(p, a.B, s);
             return launch_attn<40, 2>(p, a.B, s);

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 extern int g_tune_halo;
+extern int g_tune_debug;
 extern int g_tune_biggemm;
 
 namespace {
@@ -41,6 +42,7 @@ struct IgemmParams {
     int Ktot;            // row length of w
     const f16* w; const f16* bias; const f16* temb; int temb_stride; const f16* res; f16* out;
     int tiles_n, nblk;
+    int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -422,7 +424,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int kt = 0; kt < p.KT; ++kt) {
+    const int KTX = (p.debug & 2) ? 0 : p.KT;
+    for (int kt = 0; kt < KTX; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
@@ -448,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
     igemm_epilogue<GEGLU, NT, MT, (GEGLU ? 10 : 5)>(p, acc, m_blk + wm * 64, n_blk + wn * 160, lane, smem + w * 11264);
 }
 
@@ -594,6 +598,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+int g_tune_debug = 0;
 int g_tune_halo = 1;
 int g_tune_biggemm = 1;
 
@@ -616,6 +621,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     p.stride = a.stride; p.upsample = a.upsample;
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
+    p.debug = g_tune_debug;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
     if (a.N % 128 == 0) bn = 128;

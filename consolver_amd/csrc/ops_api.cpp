@@ -4,6 +4,7 @@
 #include <cstring>
 
 extern int g_tune_halo;
+extern int g_tune_debug;
 extern int g_tune_biggemm;
 
 extern "C" {
@@ -12,6 +13,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
+    if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
 }
 

@@ -40,6 +40,9 @@ def attn(N, C, Nk=None, tag=""):
     rows.append((f"attention dh={C // 8} {tag}", N, Nk, C, ms, 4.0 * B * N * Nk * C / ms / 1e9))
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+for kv in os.environ.get("CS_TUNE", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("="); ops.set_tuning(k, int(v))
 if which in ("all", "gemm"):
     lin(8192, 8192, 8192, tag="square")
     lin(131072, 320, 960, tag="qkv L0"); lin(131072, 320, 320, res=True, tag="out L0"); lin(131072, 320, 2560, geglu=True, tag="ff1 L0")
