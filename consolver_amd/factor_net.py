@@ -164,7 +164,12 @@ class FactorNetPPO(nn.Module):
         aprobs = torch.empty_like(actions)
         lib, st = L.lib(), L.stream_ptr(probs.device)
         if self.forced_action_idx is not None:
-            idx = self.forced_action_idx.to(device=probs.device, dtype=torch.int64).reshape(B, A).contiguous()
+            forced = self.forced_action_idx
+            if isinstance(forced, list):                      # a replay queue: one [B, A] index tensor per step
+                if not forced:
+                    raise RuntimeError("forced_action_idx queue is empty")
+                forced = forced.pop(0)
+            idx = forced.to(device=probs.device, dtype=torch.int64).reshape(B, A).contiguous()
             L.check(lib.cs_gather_actions(L.ptr(probs), L.ptr(idx), L.ptr(av), B, A, K, L.ptr(actions), L.ptr(aprobs), st))
         elif self.sampler == "multinomial":
             idx = torch.multinomial(probs.view(-1, K), num_samples=1).view(B, A)

@@ -159,9 +159,12 @@ class PPOScheduler(HistoryMixin):
             raise ValueError(f"timestep grid for n={num_inference_steps} leaves [0, {T}): {ts.min()}..{ts.max()}")
         self.num_inference_steps = num_inference_steps
         self._timesteps = ts
-        self.timesteps = torch.from_numpy(ts).to(device)
+        same = (self._cond_table is not None and self._cond_table[3] == num_inference_steps and device is not None
+                and self.timesteps.device == torch.device(device))
+        if not same:
+            self.timesteps = torch.from_numpy(ts).to(device)
+            self._cond_table = None            # (kept across calls with the same n/device: no H2D, graph-capture safe)
         self.ets = []
-        self._cond_table = None
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -185,12 +188,13 @@ class PPOScheduler(HistoryMixin):
     def _cond_row(self, t, prev_t, dtype, device):
         """[1,2] fp32 device row (t, prev_t) rounded through the model dtype like
         ``torch.tensor([[t, prev_t]], dtype=model_output.dtype)`` (scheduler_ppo.py:207)."""
-        if self._cond_table is None or self._cond_table[0].device != device or self._cond_table[2] != dtype:
+        if (self._cond_table is None or self._cond_table[0].device != device or self._cond_table[2] != dtype
+                or self._cond_table[3] != self.num_inference_steps):
             n = self.num_inference_steps
             host = np.stack([self._timesteps, self._timesteps - self.config.num_train_timesteps // n], 1)
             dev = torch.from_numpy(host.astype(np.float32)).to(device).to(dtype).to(torch.float32)
-            self._cond_table = (dev, {int(v): i for i, v in enumerate(self._timesteps)}, dtype)
-        dev, index, _ = self._cond_table
+            self._cond_table = (dev, {int(v): i for i, v in enumerate(self._timesteps)}, dtype, n)
+        dev, index, _, _ = self._cond_table
         i = index.get(int(t))
         if i is None:
             return torch.tensor([[t, prev_t]], dtype=dtype).to(torch.float32).to(device)
