@@ -32,6 +32,12 @@ class CsStepArgs(C.Structure):
                 ("v_prediction", C.c_int), ("dt", C.c_float)]
 
 
+class CsFluxConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("num_layers", C.c_int), ("num_single_layers", C.c_int), ("num_heads", C.c_int),
+                ("head_dim", C.c_int), ("joint_attention_dim", C.c_int), ("pooled_projection_dim", C.c_int),
+                ("guidance_embeds", C.c_int), ("axes_dims_rope", C.c_int * 3), ("dtype", C.c_int)]
+
+
 class CsUNetConfig(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
                 ("layers_per_block", C.c_int), ("num_heads", C.c_int), ("cross_attention_dim", C.c_int),
@@ -68,7 +74,21 @@ SYMBOLS = {
     "cs_unet_profile_entries": (C.c_int, [C.c_void_p]),
     "cs_unet_profile_entry": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "cs_flux_create": (C.c_int, [C.POINTER(CsFluxConfig), C.POINTER(C.c_void_p)]),
+    "cs_flux_destroy": (None, [C.c_void_p]),
+    "cs_flux_num_weights": (C.c_int, [C.c_void_p]),
+    "cs_flux_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "cs_flux_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
+    "cs_flux_finalize": (C.c_int, [C.c_void_p]),
+    "cs_flux_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cs_flux_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cs_flux_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     # include/consolver_hip_ops.h
+    "cs_op_gemm2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
+                              C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "cs_op_attention_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "cs_op_conv2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]),

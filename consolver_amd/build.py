@@ -22,6 +22,9 @@ SOURCES = {
     "attention.hip": [],
     "norm.hip": [],
     "misc.hip": [],
+    "gemm2.hip": [],
+    "flux_ops.hip": [],
+    "flux.cpp": [],
     "unet.cpp": [],
     "ops_api.cpp": [],
 }

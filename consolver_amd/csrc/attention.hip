@@ -18,6 +18,7 @@
 //   * head dims are zero-padded in registers/LDS only (40 -> 64 for Q K^T, 40 -> 48 for P V);
 //   * O^T leaves each lane with 4 consecutive channels of one query row -> 8-byte stores.
 #include "ops.h"
+#include "el.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -33,9 +34,9 @@ struct AttnParams {
 typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) hf4* lds_hf4_ptr;
 
-__device__ __forceinline__ f16x4 tr_read(const char* lds_addr) {
+__device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {      // 4 x 16-bit, type agnostic
     hf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf4_ptr)lds_addr);
-    union { hf4 a; f16x4 b; } u; u.a = r;
+    union { hf4 a; u32x2 b; } u; u.a = r;
     return u.b;
 }
 
@@ -51,8 +52,9 @@ __device__ __forceinline__ float xor32_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <int DH, int QT>
+template <typename T, int DH, int QT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+    typedef typename El<T>::frag frag;
     constexpr int DK = (DH + 31) / 32 * 32;
     constexpr int KSTEPS = DK / 32;
     constexpr int DVT = (DH + 15) / 16;
@@ -80,20 +82,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     for (int o = tid * 16; o < 2 * KBUF + 2 * VBUF; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
 
     // ---- Q fragments (B operand: lane = query column i16, k = 8g + j) ---------------------------
-    f16x8 qf[QT][KSTEPS];
+    frag qf[QT][KSTEPS];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qrow = q0 + t * 16 + i16;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int d = ks * 32 + 8 * g;
-            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            u32x4 v = {0, 0, 0, 0};
             if (qrow < p.Nq && d < DH) {
-                v = *reinterpret_cast<const f16x8*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+                v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] * p.c);      // fold scale*log2(e) into Q
+                for (int e = 0; e < 4; ++e)      // fold scale*log2(e) into Q
+                    v[e] = pack2<T>(El<T>::tof((u16)(v[e] & 0xffff)) * p.c, El<T>::tof((u16)(v[e] >> 16)) * p.c);
             }
-            qf[t][ks] = v;
+            qf[t][ks] = as_frag<T>(v);
         }
     }
 
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     load_tile(0);
     __syncthreads();            // zero fill complete
     if (ONES) {
-        for (int r = tid; r < 128; r += 256) *reinterpret_cast<f16*>(lV + (r >> 6) * VBUF + (r & 63) * VS + DH * 2) = (f16)1.0f;
+        for (int r = tid; r < 128; r += 256) *reinterpret_cast<u16*>(lV + (r >> 6) * VBUF + (r & 63) * VS + DH * 2) = El<T>::fromf(1.0f);
     }
     store_tile(0);
     __syncthreads();
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(
+                const frag kf = *reinterpret_cast<const frag*>(
                     tk + (kt * 16 + i16) * KS + (KSWZ ? ((ks * 4 + g) ^ (i16 & 7)) * 16 : (ks * 32 + 8 * g) * 2));
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    s[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t], 0, 0, 0);
+                    s[kt][t] = El<T>::mfma(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t]);
             }
         }
         if (RAGGED) {   // ragged last tile: mask keys >= Nk (compiled only into the peeled last iteration)
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         }
 
         // ---- P = exp2(S') -> fp16 fragments of the second product ------------------------------------------
-        f16x8 pf[QT][2];
+        frag pf[QT][2];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float ps = 0.f;
@@ -253,10 +256,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             if (!ONES) l_run[t] += ps;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
-                f16x8 f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { f[r] = (f16)s[2 * t2][t][r]; f[4 + r] = (f16)s[2 * t2 + 1][t][r]; }
-                pf[t][t2] = f;
+                u32x4 f;
+                f[0] = pack2<T>(s[2 * t2][t][0], s[2 * t2][t][1]); f[1] = pack2<T>(s[2 * t2][t][2], s[2 * t2][t][3]);
+                f[2] = pack2<T>(s[2 * t2 + 1][t][0], s[2 * t2 + 1][t][1]); f[3] = pack2<T>(s[2 * t2 + 1][t][2], s[2 * t2 + 1][t][3]);
+                pf[t][t2] = as_frag<T>(f);
             }
         }
 
@@ -266,11 +269,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
             for (int a = 0; a < DVT; ++a) {
                 const char* addr = tv + (32 * t2 + 4 * g + (i16 >> 2)) * VS + (a * 16 + 4 * (i16 & 3)) * 2;
-                const f16x4 lo = tr_read(addr);
-                const f16x4 hi = tr_read(addr + 16 * VS);
-                const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const u32x2 lo = tr_read(addr);
+                const u32x2 hi = tr_read(addr + 16 * VS);
+                const frag vf = as_frag<T>(u32x4{lo[0], lo[1], hi[0], hi[1]});
 #pragma unroll
-                for (int t = 0; t < QT; ++t) o_acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[t][t2], o_acc[a][t], 0, 0, 0);
+                for (int t = 0; t < QT; ++t) o_acc[a][t] = El<T>::mfma(vf, pf[t][t2], o_acc[a][t]);
             }
         }
 
@@ -303,20 +306,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         for (int a = 0; a < DVT; ++a) {
             const int d = a * 16 + 4 * g;
             if (d + 4 <= DH) {
-                f16x4 o = {(f16)(o_acc[a][t][0] * inv), (f16)(o_acc[a][t][1] * inv), (f16)(o_acc[a][t][2] * inv), (f16)(o_acc[a][t][3] * inv)};
-                *reinterpret_cast<f16x4*>(orow + d) = o;
+                const u32x2 o = {pack2<T>(o_acc[a][t][0] * inv, o_acc[a][t][1] * inv), pack2<T>(o_acc[a][t][2] * inv, o_acc[a][t][3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + d) = o;
             }
         }
     }
 }
 
-template <int DH, int QT>
+template <typename T, int DH, int QT>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
     constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
     constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
-    auto kfn = attn_kernel<DH, QT>;
+    auto kfn = attn_kernel<T, DH, QT>;
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -343,12 +346,16 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     switch (a.dh) {
         case 40: {
             static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 4;   // tuning knob
-            if (qt == 4) return launch_attn<40, 4>(p, a.B, s);
-            if (qt == 3) return launch_attn<40, 3>(p, a.B, s);
-            return launch_attn<40, 2>(p, a.B, s);
+            if (a.dtype == CS_BF16) CS_FAIL(CS_E_UNSUPPORTED, "attention: bf16 is built for head dim 128 only");
+            if (qt == 4) return launch_attn<f16, 40, 4>(p, a.B, s);
+            return launch_attn<f16, 40, 2>(p, a.B, s);
         }
-        case 80: return launch_attn<80, 2>(p, a.B, s);
-        case 160: return launch_attn<160, 1>(p, a.B, s);
-        default: CS_FAIL(CS_E_UNSUPPORTED, "attention: head dim %d not built (40/80/160)", a.dh);
+        case 80: if (a.dtype == CS_BF16) break; return launch_attn<f16, 80, 2>(p, a.B, s);
+        case 160: if (a.dtype == CS_BF16) break; return launch_attn<f16, 160, 1>(p, a.B, s);
+        case 128:
+            if (a.dtype == CS_BF16) return launch_attn<bf16_el, 128, 2>(p, a.B, s);
+            return launch_attn<f16, 128, 2>(p, a.B, s);
+        default: break;
     }
+    CS_FAIL(CS_E_UNSUPPORTED, "attention: head dim %d / dtype %d not built (f16: 40/80/160/128, bf16: 128)", a.dh, a.dtype);
 }

@@ -1,0 +1,193 @@
+// HBM-bound glue of the FLUX DiT: adaLN-modulated LayerNorm, per-head q/k RMSNorm + rotary embedding
+// (in place on the fused qkv buffer), timestep sinusoids and small fp32 helpers.  16 bytes per lane,
+// wave-shuffle reductions, f16 or bf16 storage with fp32 math.
+#include "ops.h"
+#include "el.h"
+
+namespace {
+
+// y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; one wave per token row, row kept in registers
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict__ x, u16* __restrict__ y, int M, int C, int rows_per_sample,
+                                                          const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= M) return;
+    const int CV = C >> 3;
+    float v[MAXV][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(x + (size_t)row * C + cv * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[j][2 * k] = El<T>::tof((u16)(t[k] & 0xffff)); v[j][2 * k + 1] = El<T>::tof((u16)(t[k] >> 16)); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[j][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (lane + 64 * j < CV) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const float* sh = shift + (size_t)(row / rows_per_sample) * mod_stride;
+    const float* sc = scale + (size_t)(row / rows_per_sample) * mod_stride;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc + cv * 8), s1 = *reinterpret_cast<const f32x4*>(sc + cv * 8 + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sh + cv * 8), h1 = *reinterpret_cast<const f32x4*>(sh + cv * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = (v[j][k] - mean) * rstd * (1.0f + s0[k]) + h0[k];
+                o[4 + k] = (v[j][4 + k] - mean) * rstd * (1.0f + s1[k]) + h1[k];
+            }
+            const u32x4 pk = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(y + (size_t)row * C + cv * 8) = pk;
+        }
+    }
+}
+
+// one wave per (token row, head): lanes 0..dh/8-1 hold 8 dims each of q (and k); RMS over the head, * weight,
+// then rotate the (2i, 2i+1) pairs with cos/sin[pos][i]
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16* __restrict__ qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col,
+                                                           const u16* __restrict__ wq, const u16* __restrict__ wk, const u16* __restrict__ wq_ctx,
+                                                           const u16* __restrict__ wk_ctx, int ctx_rows, const float* __restrict__ cosv,
+                                                           const float* __restrict__ sinv, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)rows * heads) return;
+    const int row = (int)(item / heads), h = (int)(item - (long)row * heads);
+    const int pos = row % seq;
+    const bool is_ctx = pos < ctx_rows;
+    const int nv = dh >> 3;                      // lanes in use per tensor (dh = 128 -> 16)
+    const int which = lane / nv;                 // 0 = q, 1 = k ; lanes >= 2 nv idle
+    const int li = lane - which * nv;
+    const bool active = which < 2;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u16* ptr = qkv + (size_t)row * ld + (which == 0 ? q_col : k_col) + h * dh + li * 8;
+    if (active) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(ptr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = El<T>::tof((u16)(t[k] & 0xffff)); v[2 * k + 1] = El<T>::tof((u16)(t[k] >> 16)); }
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sq += v[k] * v[k];
+    // reduce within the nv-lane group (nv is a power of two <= 32)
+    for (int o = nv >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (!active) return;
+    const float r = rsqrtf(sq / (float)dh + eps);
+    const u16* wsel = (which == 0) ? (is_ctx && wq_ctx ? wq_ctx : wq) : (is_ctx && wk_ctx ? wk_ctx : wk);
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(wsel + li * 8);
+    float nrm[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // torch RMSNorm: (x * rsqrt(var + eps)) cast to the weight dtype, then * weight
+        nrm[2 * k] = El<T>::tof(El<T>::fromf(v[2 * k] * r)) * El<T>::tof((u16)(wv[k] & 0xffff));
+        nrm[2 * k + 1] = El<T>::tof(El<T>::fromf(v[2 * k + 1] * r)) * El<T>::tof((u16)(wv[k] >> 16));
+    }
+    const float* cp = cosv + (size_t)pos * (dh >> 1) + li * 4;
+    const float* sp = sinv + (size_t)pos * (dh >> 1) + li * 4;
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp), s4 = *reinterpret_cast<const f32x4*>(sp);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = El<T>::tof(El<T>::fromf(nrm[2 * k])), b = El<T>::tof(El<T>::fromf(nrm[2 * k + 1]));
+        o[2 * k] = a * c4[k] - b * s4[k];
+        o[2 * k + 1] = b * c4[k] + a * s4[k];
+    }
+    const u32x4 pk = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(ptr) = pk;
+}
+
+__global__ void sinusoid_f32_kernel(const float* __restrict__ t, float mult, int R, int C, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = C / 2;
+    if (i >= R * half) return;
+    const int r = i / half, k = i - r * half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[r] * mult * f;
+    out[(size_t)r * C + k] = cosf(a);
+    out[(size_t)r * C + half + k] = sinf(a);
+}
+
+__global__ void add3_kernel(const float* a, const float* b, const float* c, float* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
+}
+
+template <typename T> __global__ void cast_kernel(const float* x, u16* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = El<T>::fromf(x[i]);
+}
+
+}  // namespace
+
+int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
+                       float eps, int dtype, hipStream_t s) {
+    if (!x || !y || !shift || !scale) CS_FAIL(CS_E_ARG, "ln_modulate: null pointer");
+    if (C % 8 || C > 8 * 64 * 8) CS_FAIL(CS_E_SHAPE, "ln_modulate: C=%d unsupported", C);
+    if (M <= 0) return CS_OK;
+    const dim3 grid((M + 3) / 4), block(256);
+    const int nv = (C / 8 + 63) / 64;
+#define LNM(T, V) hipLaunchKernelGGL((ln_modulate_kernel<T, V>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps)
+    if (dtype == CS_BF16) { if (nv <= 1) LNM(bf16_el, 1); else if (nv <= 2) LNM(bf16_el, 2); else if (nv <= 4) LNM(bf16_el, 4); else if (nv <= 6) LNM(bf16_el, 6); else LNM(bf16_el, 8); }
+    else if (dtype == CS_F16) { if (nv <= 1) LNM(f16, 1); else if (nv <= 2) LNM(f16, 2); else if (nv <= 4) LNM(f16, 4); else if (nv <= 6) LNM(f16, 6); else LNM(f16, 8); }
+    else CS_FAIL(CS_E_DTYPE, "ln_modulate: dtype");
+#undef LNM
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col, const void* wq, const void* wk,
+                        const void* wq_ctx, const void* wk_ctx, int ctx_rows, const float* cosv, const float* sinv, float eps, int dtype,
+                        hipStream_t s) {
+    if (!qkv || !wq || !wk || !cosv || !sinv) CS_FAIL(CS_E_ARG, "qk_norm_rope: null pointer");
+    if (dh % 8 || (dh / 8) > 32 || ((dh / 8) & (dh / 8 - 1))) CS_FAIL(CS_E_SHAPE, "qk_norm_rope: head dim %d unsupported", dh);
+    if (rows <= 0) return CS_OK;
+    const long items = (long)rows * heads;
+    const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+    if (dtype == CS_BF16) hipLaunchKernelGGL(qk_norm_rope_kernel<bf16_el>, grid, block, 0, s, (u16*)qkv, ld, rows, seq, heads, dh, q_col, k_col, (const u16*)wq, (const u16*)wk, (const u16*)wq_ctx, (const u16*)wk_ctx, ctx_rows, cosv, sinv, eps);
+    else if (dtype == CS_F16) hipLaunchKernelGGL(qk_norm_rope_kernel<f16>, grid, block, 0, s, (u16*)qkv, ld, rows, seq, heads, dh, q_col, k_col, (const u16*)wq, (const u16*)wk, (const u16*)wq_ctx, (const u16*)wk_ctx, ctx_rows, cosv, sinv, eps);
+    else CS_FAIL(CS_E_DTYPE, "qk_norm_rope: dtype");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_sinusoid_f32(const float* t, float mult, int R, int C, float* out, hipStream_t s) {
+    const int n = R * (C / 2);
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(sinusoid_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, mult, R, C, out);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_add3_f32(const float* a, const float* b, const float* c, float* out, long n, hipStream_t s) {
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, c, out, n);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_cast_f32(const float* x, void* out, long n, int dtype, hipStream_t s) {
+    if (n <= 0) return CS_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == CS_BF16) hipLaunchKernelGGL(cast_kernel<bf16_el>, grid, block, 0, s, x, (u16*)out, n);
+    else if (dtype == CS_F16) hipLaunchKernelGGL(cast_kernel<f16>, grid, block, 0, s, x, (u16*)out, n);
+    else CS_FAIL(CS_E_DTYPE, "cast: dtype");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

@@ -1,0 +1,270 @@
+// General dense GEMM for the transformer (FLUX DiT) linears, f16 or bf16:
+//
+//   out[rowmap_c(m)][c_col_off + n] = epi( sum_k A[rowmap_a(m)][k] * W[n][k] + bias[n] )
+//   epi(v) = act(v)                         (act: none | GELU-tanh)
+//          = res + gate[sample(m)][n] * v   (adaLN-Zero gated residual, when gate != null)
+//          = res + v                        (plain residual)
+//
+// Same machine mapping as gemm_big_kernel in igemm.hip (LDS-DMA staged operands, XOR-swizzled
+// 128-byte LDS rows, swapped MFMA operands, LDS-staged row-wise epilogue) with a 256 x 256 x 64 tile
+// (8 wave64 as 4 x 2, wave tile 64 x 128): the FLUX widths (3072 = 12 x 256, 9216, 12288, 21504)
+// are multiples of 256, not of 320.  Row segment maps let a GEMM read / write the [context | image]
+// token ranges of the joint sequence without concat/split copies; ldc + column offset let the
+// single-stream block write attention output and MLP activation side by side.
+#include "ops.h"
+#include "el.h"
+
+namespace {
+
+constexpr int BK = 64;
+__device__ __attribute__((aligned(256))) unsigned g_zero_page2[64];
+
+struct G2Params {
+    const u16* a; long lda; int a_seg, a_stride; long a_off;
+    const u16* w; const u16* bias;
+    int M, N, K, KT;
+    u16* out; const u16* res; long ldc; int c_col; int c_seg, c_stride; long c_off;
+    const float* gate; long gate_stride; int rows_per_sample;   // fp32 adaLN gate [B][gate_stride]
+    int act;
+    int tiles_n, nblk;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ long rowmap(int r, int seg, int stride, long off) {
+    return seg ? (long)(r / seg) * stride + (r % seg) + off : (long)r + off;
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  ==  x * sigmoid(2 u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Params p) {
+    constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
+    constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
+    typedef typename El<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    const int m_blk = tm * BMX, n_blk = tn * BNX;
+
+    const int pch = lane & 7;
+    const u16* a_src[4]; bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (w * 4 + j) + (lane >> 3);
+        const int m = m_blk + r;
+        a_ok[j] = m < p.M;
+        a_src[j] = p.a + rowmap(a_ok[j] ? m : 0, p.a_seg, p.a_stride, p.a_off) * p.lda + (pch ^ ((r >> 1) & 7)) * 8;
+    }
+    const u16* b_src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (w * 4 + j) + (lane >> 3);
+        b_src[j] = p.w + (size_t)(n_blk + r) * p.K + (pch ^ ((r >> 1) & 7)) * 8;
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page2) + pch * 16;
+
+    auto stage = [&](int kt, int buf) {
+        char* la = smem + buf * STAGE + (w * 4) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uintptr_t real = (uintptr_t)(a_src[j] + (size_t)kt * BK);
+            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)a_ok[j];
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), la + j * 1024);
+        }
+        char* lb = smem + buf * STAGE + A_BYTES + (w * 4) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int swz = (lane >> 1) & 7;
+    const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
+    const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
+        const char* ta = smem + buf * STAGE + (wm * 64) * 128;
+        const char* tb = smem + buf * STAGE + A_BYTES + (wn * 128) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? frag_off1 : frag_off0;
+            frag fa[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const frag*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                frag fw[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag*>(tb + (half * 4 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[half * 4 + i][j] = El<T>::mfma(fw[i], fa[j], acc[half * 4 + i][j]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: per wave 64 rows x 128 cols in two passes of 64 cols through an LDS patch --------------
+    constexpr int COLS = 64, ROWB = (COLS + 8) * 2, CH = COLS / 8;
+    char* patch = smem + w * (64 * ROWB);
+    const int g4 = (lane >> 4) * 4, i16 = lane & 15;
+    const int m_base = m_blk + wm * 64, n_base = n_blk + wn * 128;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = grp * 4 + ii;
+            const int n = n_base + i * 16 + g4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(p.bias + n);
+                bv[0] = El<T>::tof((u16)(t[0] & 0xffff)); bv[1] = El<T>::tof((u16)(t[0] >> 16));
+                bv[2] = El<T>::tof((u16)(t[1] & 0xffff)); bv[3] = El<T>::tof((u16)(t[1] >> 16));
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                u16 o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bv[r];
+                    if (p.act == 1) v = gelu_tanh(v);
+                    o[r] = El<T>::fromf(v);
+                }
+                u32x2 pk = {(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+                *reinterpret_cast<u32x2*>(patch + (j * 16 + i16) * ROWB + (ii * 16 + g4) * 2) = pk;
+            }
+        }
+        const int n0 = n_base + grp * 64;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int idx = lane + 64 * k;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = m_base + row, n = n0 + ch * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * ROWB + ch * 16);
+            if (m < p.M && n < p.N) {
+                const size_t off = (size_t)rowmap(m, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + n;
+                if (p.res || p.gate) {
+                    float f[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f[2 * r] = El<T>::tof((u16)(v[r] & 0xffff)); f[2 * r + 1] = El<T>::tof((u16)(v[r] >> 16)); }
+                    if (p.gate) {
+                        const float* gp = p.gate + (size_t)(m / p.rows_per_sample) * p.gate_stride + n;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { f[r] *= g0[r]; f[4 + r] *= g1[r]; }
+                    }
+                    if (p.res) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rv[r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rv[r] >> 16)); }
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (unsigned)El<T>::fromf(f[2 * r]) | ((unsigned)El<T>::fromf(f[2 * r + 1]) << 16);
+                    *reinterpret_cast<u32x4*>(p.out + off) = o;
+                } else {
+                    *reinterpret_cast<u32x4*>(p.out + off) = v;
+                }
+            }
+        }
+    }
+}
+
+// tiny-M linear: out[r][n] = act(sum_k x[r][k] w[n][k] + b[n]); x/out fp32, weights T.  One wave per n.
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int R, int K, const u16* __restrict__ w,
+                                                           const u16* __restrict__ bias, int N, float* __restrict__ out, int act_silu_in,
+                                                           int act_silu_out) {
+    const int lane = threadIdx.x & 63;
+    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int KV = K >> 3;
+    for (int r = 0; r < R; ++r) {
+        float acc = 0.f;
+        for (int kv = lane; kv < KV; kv += 64) {
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(w + (size_t)n * K + kv * 8);
+            const float* xp = x + (size_t)r * K + kv * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x0 = xp[2 * k], x1 = xp[2 * k + 1];
+                if (act_silu_in) { x0 = x0 / (1.f + __expf(-x0)); x1 = x1 / (1.f + __expf(-x1)); }
+                acc += El<T>::tof((u16)(wv[k] & 0xffff)) * x0 + El<T>::tof((u16)(wv[k] >> 16)) * x1;
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float v = acc + (bias ? El<T>::tof(bias[n]) : 0.f);
+            if (act_silu_out) v = v / (1.f + __expf(-v));
+            out[(size_t)r * N + n] = v;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
+    if (!a.a || !a.w || !a.out) CS_FAIL(CS_E_ARG, "gemm2: null pointer");
+    if (a.K % BK) CS_FAIL(CS_E_SHAPE, "gemm2: K=%d must be a multiple of 64", a.K);
+    if (a.N % 8 || a.ldc % 8 || a.c_col_off % 8 || a.lda % 8) CS_FAIL(CS_E_SHAPE, "gemm2: N, lda, ldc, col offset must be multiples of 8");
+    if (a.M <= 0 || a.N <= 0) return (a.M < 0 || a.N < 0) ? CS_E_SHAPE : CS_OK;
+    if (a.gate && a.rows_per_sample <= 0) CS_FAIL(CS_E_ARG, "gemm2: rows_per_sample required with gate");
+    G2Params p;
+    p.a = (const u16*)a.a; p.lda = a.lda ? a.lda : a.K; p.a_seg = a.a_seg_rows; p.a_stride = a.a_seg_stride; p.a_off = a.a_row_off;
+    p.w = (const u16*)a.w; p.bias = (const u16*)a.bias; p.M = a.M; p.N = a.N; p.K = a.K; p.KT = a.K / BK;
+    p.out = (u16*)a.out; p.res = (const u16*)a.res; p.ldc = a.ldc ? a.ldc : a.N; p.c_col = a.c_col_off;
+    p.c_seg = a.c_seg_rows; p.c_stride = a.c_seg_stride; p.c_off = a.c_row_off;
+    p.gate = (const float*)a.gate; p.gate_stride = a.gate_stride; p.rows_per_sample = a.rows_per_sample; p.act = a.act;
+    p.tiles_n = (a.N + 255) / 256;            // the packed weight has tiles_n * 256 rows (zero padded)
+    p.nblk = ((a.M + 255) / 256) * p.tiles_n;
+    constexpr size_t lds = 2 * (256 * BK * 2 + 256 * BK * 2);
+    static bool configured = false;
+    if (!configured) {
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<bf16_el>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    if (a.dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, dim3(p.nblk), dim3(512), lds, s, p);
+    else if (a.dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, dim3(p.nblk), dim3(512), lds, s, p);
+    else CS_FAIL(CS_E_DTYPE, "gemm2: dtype must be f16 or bf16");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,
+                        int dtype, hipStream_t s) {
+    if (!x || !w || !out) CS_FAIL(CS_E_ARG, "small_linear: null pointer");
+    if (K % 8) CS_FAIL(CS_E_SHAPE, "small_linear: K must be a multiple of 8");
+    if (R <= 0 || N <= 0) return CS_OK;
+    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    if (dtype == CS_F16) hipLaunchKernelGGL(small_linear_kernel<f16>, grid, block, 0, s, x, R, K, (const u16*)w, (const u16*)bias, N, out, silu_in, silu_out);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(small_linear_kernel<bf16_el>, grid, block, 0, s, x, R, K, (const u16*)w, (const u16*)bias, N, out, silu_in, silu_out);
+    else CS_FAIL(CS_E_DTYPE, "small_linear: dtype must be f16 or bf16");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

@@ -30,6 +30,7 @@ struct AttnArgs {
     f16* out; int out_stride;     // [B, Nq, H*dh]
     int B, H, Nq, Nk, dh;
     float scale;
+    int dtype;               // CS_F16 (default 0 is treated as f16) or CS_BF16
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -60,3 +61,28 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
 // conv_out: NHWC [B][H][W][Cin] -> NCHW [B][Cout][H][W], 3x3 pad 1 (Cout small)
 int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias, int Cout,
                     f16* out, hipStream_t s);
+
+// ---- transformer (FLUX DiT) ops, f16 or bf16 (dtype = CS_F16 / CS_BF16) -------------------------------------
+struct Gemm2Args {
+    const void* a; long lda; int a_seg_rows, a_seg_stride; long a_row_off;   // A row r -> (r/seg)*stride + r%seg + off  (seg = 0: identity)
+    const void* w; const void* bias;      // w: [ceil(N/256)*256][K] (zero padded rows), bias [N]
+    int M, N, K;
+    void* out; const void* res; long ldc; int c_col_off; int c_seg_rows, c_seg_stride; long c_row_off;
+    const float* gate; long gate_stride; int rows_per_sample;   // out = res + gate[m / rows_per_sample][n] * v
+    int act;                               // 0 none, 1 GELU(tanh)
+    int dtype;
+};
+int launch_gemm2(const Gemm2Args& a, hipStream_t s);
+int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,
+                        int dtype, hipStream_t s);
+// y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b] ; x,y [M][C] (dtype), scale/shift fp32 rows of stride mod_stride
+int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
+                       float eps, int dtype, hipStream_t s);
+// in place on a fused qkv buffer [S_total rows][ld]: per head RMSNorm(q) * wq, RMSNorm(k) * wk, then RoPE (pairs) with cos/sin [S][dh/2]
+int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col, const void* wq, const void* wk,
+                        const void* wq_ctx, const void* wk_ctx, int ctx_rows, const float* cosv, const float* sinv, float eps, int dtype,
+                        hipStream_t s);
+// sinusoidal embedding (flip_sin_to_cos, shift 0) of scalars: out[r][C] fp32
+int launch_sinusoid_f32(const float* t, float mult, int R, int C, float* out, hipStream_t s);
+int launch_add3_f32(const float* a, const float* b, const float* c, float* out, long n, hipStream_t s);
+int launch_cast_f32(const float* x, void* out, long n, int dtype, hipStream_t s);

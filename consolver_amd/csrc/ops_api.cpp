@@ -59,6 +59,22 @@ int cs_op_attention(const void* q, int q_stride, const void* k, int k_stride, co
     return launch_attention(a, (hipStream_t)stream);
 }
 
+int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
+                int rows_per_sample, int act, void* out, long ldc, int col_off, int dtype, void* stream) {
+    Gemm2Args g{};
+    g.a = x; g.lda = K; g.w = w; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out = out; g.res = res; g.ldc = ldc ? ldc : N; g.c_col_off = col_off;
+    g.gate = gate; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample; g.act = act; g.dtype = dtype;
+    return launch_gemm2(g, (hipStream_t)stream);
+}
+
+int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                       int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream) {
+    AttnArgs a{};
+    a.q = (const f16*)q; a.q_stride = q_stride; a.k = (const f16*)k; a.k_stride = k_stride; a.v = (const f16*)v; a.v_stride = v_stride;
+    a.out = (f16*)out; a.out_stride = out_stride; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh; a.scale = scale; a.dtype = dtype;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 size_t cs_op_group_norm_workspace(int B, int C) { return (size_t)B * (GN_SPLITS + 1) * C * 2 * sizeof(float); }
 
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,

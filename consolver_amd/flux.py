@@ -1,0 +1,206 @@
+"""HIP-backed FLUX.1-Kontext DiT (``FluxTransformer2DModel`` stand-in) + the latent layout helpers and
+the edit sampling loop of the FLUX side of the hot path.
+
+Mirrors what the reference drives (edit_ppo/pipeline.py:1074-1140, edit_ppo/denoise_diffusion.py:96-160):
+
+    x_in = cat([latents, image_latents], dim=1)
+    v    = transformer(hidden_states=x_in, timestep=t/1000, guidance=g, pooled_projections=pooled,
+                       encoder_hidden_states=t5, txt_ids=txt_ids, img_ids=ids, return_dict=False)[0][:, :L]
+    latents = scheduler.step(v, t, latents, return_dict=False)[0]
+
+Weights load by their diffusers state-dict names.  There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .tables import calculate_shift
+
+FLUX_KONTEXT_CONFIG = dict(in_channels=64, num_layers=19, num_single_layers=38, num_heads=24, head_dim=128,
+                           joint_attention_dim=4096, pooled_projection_dim=768, guidance_embeds=True,
+                           axes_dims_rope=(16, 56, 56), dtype=torch.bfloat16)
+
+
+# ---- layout helpers (pure index shuffles, edit_ppo/pipeline.py:574-611) ------------------------------------------
+def prepare_latent_image_ids(height, width, first=0.0):
+    ids = np.zeros((height, width, 3), np.float32)
+    ids[..., 0] = first
+    ids[..., 1] += np.arange(height, dtype=np.float32)[:, None]
+    ids[..., 2] += np.arange(width, dtype=np.float32)[None, :]
+    return ids.reshape(height * width, 3)
+
+
+def pack_latents(latents):
+    """[B, C, H, W] -> [B, (H/2)(W/2), 4C] (2x2 patches)."""
+    B, Cc, H, W = latents.shape
+    x = latents.view(B, Cc, H // 2, 2, W // 2, 2).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(B, (H // 2) * (W // 2), Cc * 4)
+
+
+def unpack_latents(latents, height, width, vae_scale_factor=8):
+    B, _, ch = latents.shape
+    h = 2 * (int(height) // (vae_scale_factor * 2))
+    w = 2 * (int(width) // (vae_scale_factor * 2))
+    x = latents.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5)
+    return x.reshape(B, ch // 4, h, w)
+
+
+def rope_tables(ids, axes_dims, theta=10000.0):
+    """cos/sin [S, head_dim/2] fp32 of the 3-axis rotary embedding (float64 angles like diffusers)."""
+    cos, sin = [], []
+    ids = np.asarray(ids, np.float64)
+    for i, d in enumerate(axes_dims):
+        freqs = 1.0 / (theta ** (np.arange(0, d, 2, dtype=np.float64)[: d // 2] / d))
+        ang = np.outer(ids[:, i], freqs)
+        cos.append(np.cos(ang)); sin.append(np.sin(ang))
+    return np.concatenate(cos, 1).astype(np.float32), np.concatenate(sin, 1).astype(np.float32)
+
+
+class HipFluxTransformer2DModel:
+    is_consolver_hip = True
+
+    def __init__(self, config=None, device="cuda:0"):
+        cfg = dict(FLUX_KONTEXT_CONFIG)
+        cfg.update(config or {})
+        self.config = cfg
+        self.dtype = cfg["dtype"]
+        self.device = torch.device(device)
+        c = L.CsFluxConfig()
+        c.in_channels, c.num_layers, c.num_single_layers = cfg["in_channels"], cfg["num_layers"], cfg["num_single_layers"]
+        c.num_heads, c.head_dim = cfg["num_heads"], cfg["head_dim"]
+        c.joint_attention_dim, c.pooled_projection_dim = cfg["joint_attention_dim"], cfg["pooled_projection_dim"]
+        c.guidance_embeds = int(cfg["guidance_embeds"])
+        for i in range(3):
+            c.axes_dims_rope[i] = cfg["axes_dims_rope"][i]
+        c.dtype = L.dtype_code(self.dtype)
+        h = C.c_void_p()
+        L.check(L.lib().cs_flux_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._finalized = False
+        self._ws = None
+        self._ws_key = None
+        self._rope = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().cs_flux_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def manifest(self):
+        lib = L.lib()
+        out, shape, nd = [], (C.c_int64 * 2)(), C.c_int()
+        for i in range(lib.cs_flux_num_weights(self._h)):
+            name = lib.cs_flux_weight_name(self._h, i, shape, C.byref(nd)).decode()
+            out.append((name, tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def set_weight(self, name, tensor):
+        """tensor: torch tensor (cpu or cuda) of the manifest shape; converted to the model dtype."""
+        t = tensor.detach().to(self.dtype).contiguous()
+        sh = (C.c_int64 * t.dim())(*t.shape)
+        L.check(L.lib().cs_flux_set_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda), sh, t.dim()))
+
+    def load_state_dict(self, sd, strict=True):
+        want = dict(self.manifest())
+        missing = [k for k in want if k not in sd]
+        if missing and strict:
+            raise KeyError(f"missing {len(missing)} tensors, e.g. {missing[:3]}")
+        torch.cuda.set_device(self.device)
+        for name, shape in want.items():
+            if tuple(sd[name].shape) != shape:
+                raise ValueError(f"{name}: shape {tuple(sd[name].shape)} != {shape}")
+            self.set_weight(name, sd[name])
+        return self.finalize()
+
+    def finalize(self):
+        torch.cuda.set_device(self.device)
+        L.check(L.lib().cs_flux_finalize(self._h))
+        self._finalized = True
+        return self
+
+    def flops(self, batch, txt_len, img_len):
+        return float(L.lib().cs_flux_flops(self._h, batch, txt_len, img_len))
+
+    def _rope_dev(self, txt_ids, img_ids):
+        ids = np.concatenate([np.asarray(txt_ids.detach().cpu() if torch.is_tensor(txt_ids) else txt_ids, np.float32),
+                              np.asarray(img_ids.detach().cpu() if torch.is_tensor(img_ids) else img_ids, np.float32)], 0)
+        key = ids.tobytes()
+        if key not in self._rope:
+            cos, sin = rope_tables(ids, self.config["axes_dims_rope"])
+            self._rope = {key: (torch.from_numpy(cos).to(self.device), torch.from_numpy(sin).to(self.device))}
+        return self._rope[key]
+
+    def __call__(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
+                 txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False, out=None, **_ignored):
+        if not self._finalized:
+            raise RuntimeError("weights not loaded")
+        L.require_cuda(hidden_states, "hidden_states")
+        hs = hidden_states.to(self.dtype).contiguous()
+        enc = L.require_cuda(encoder_hidden_states, "encoder_hidden_states").to(self.dtype).contiguous()
+        B, I, _ = hs.shape
+        T = enc.shape[1]
+        pooled = L.require_cuda(pooled_projections, "pooled_projections").to(torch.float32).contiguous()
+        t = timestep.to(device=hs.device, dtype=torch.float32).reshape(-1) if torch.is_tensor(timestep) else \
+            torch.full((B,), float(timestep), dtype=torch.float32, device=hs.device)
+        if t.numel() == 1:
+            t = t.expand(B).contiguous()
+        g = None
+        if self.config["guidance_embeds"]:
+            if guidance is None:
+                raise ValueError("guidance is required (guidance_embeds=True)")
+            g = guidance.to(device=hs.device, dtype=torch.float32).reshape(-1)
+            if g.numel() == 1:
+                g = g.expand(B).contiguous()
+        cos, sin = self._rope_dev(txt_ids, img_ids)
+        if cos.shape[0] != T + I:
+            raise ValueError(f"ids cover {cos.shape[0]} tokens, expected {T + I}")
+        key = (B, T, I)
+        if self._ws_key != key:
+            n = int(L.lib().cs_flux_workspace_bytes(self._h, B, T, I))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=hs.device)
+            self._ws_key = key
+        if out is None:
+            out = torch.empty(B, I, self.config["in_channels"], dtype=self.dtype, device=hs.device)
+        L.check(L.lib().cs_flux_forward(self._h, L.ptr(hs), B, I, L.ptr(enc), T, L.ptr(pooled), L.ptr(t), L.ptr(g), L.ptr(cos),
+                                        L.ptr(sin), L.ptr(out), L.ptr(self._ws), self._ws.numel(), L.stream_ptr(hs.device)))
+        if return_dict:
+            return {"sample": out}
+        return (out,)
+
+
+class FluxKontextSamplingEngine:
+    """The FLUX edit loop (edit_ppo/pipeline.py:1009-1140 minus encoders / VAE): sigma schedule with the
+    resolution-dependent shift, [latents | image_latents] joint input, FMPPOScheduler update."""
+
+    def __init__(self, transformer, scheduler, guidance_scale=2.5):
+        self.transformer, self.scheduler, self.guidance_scale = transformer, scheduler, float(guidance_scale)
+
+    @torch.no_grad()
+    def generate(self, latents, image_latents, prompt_embeds, pooled_prompt_embeds, latent_hw, image_hw=None,
+                 num_inference_steps=8):
+        """latents / image_latents: packed [B, L, 64]; latent_hw = (H/2, W/2) of the packed grid."""
+        dev = latents.device
+        B, Lq, _ = latents.shape
+        sch = self.scheduler
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        mu = calculate_shift(Lq, sch.config.get("base_image_seq_len", 256), sch.config.get("max_image_seq_len", 4096),
+                             sch.config.get("base_shift", 0.5), sch.config.get("max_shift", 1.15))
+        sch.set_timesteps(sigmas=sigmas, mu=mu, device=dev)
+        sch.set_begin_index(0)
+        ids = prepare_latent_image_ids(*latent_hw)
+        if image_latents is not None:
+            ids = np.concatenate([ids, prepare_latent_image_ids(*(image_hw or latent_hw), first=1.0)], 0)
+        txt_ids = np.zeros((prompt_embeds.shape[1], 3), np.float32)
+        guidance = torch.full([B], self.guidance_scale, device=dev, dtype=torch.float32)
+        x = latents
+        for t in sch.timesteps:
+            x_in = torch.cat([x, image_latents], dim=1) if image_latents is not None else x
+            v = self.transformer(x_in, (t / 1000).expand(B), guidance=guidance, pooled_projections=pooled_prompt_embeds,
+                                 encoder_hidden_states=prompt_embeds, txt_ids=txt_ids, img_ids=ids)[0][:, :Lq]
+            x = sch.step(v.contiguous(), t, x, return_dict=False)[0]
+        return x

@@ -27,3 +27,23 @@ def synthetic_prompt_embeds(batch, ctx_len=77, dim=768, seed=1001):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(batch, ctx_len, dim, generator=g)
     return torch.nn.functional.layer_norm(x, (dim,))
+
+
+def synthetic_flux_state_dict(manifest, seed=20251226, device="cpu", dtype=torch.float32):
+    """seeded FLUX-DiT weights: linear ~ N(0, 1/fan_in), norm weights ~ 1, modulation linears small so that
+    gates stay O(0.1-1) (an untrained adaLN-Zero would gate every block off)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in manifest:
+        if name.endswith("norm_q.weight") or name.endswith("norm_k.weight") or name.endswith("norm_added_q.weight") or name.endswith("norm_added_k.weight"):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif name.endswith(".weight"):
+            w = torch.randn(shape, generator=g, device=device) * (1.0 / shape[1]) ** 0.5
+            if ".norm" in name and name.endswith("linear.weight"):
+                w = w * 0.5
+        else:
+            w = 0.05 * torch.randn(shape, generator=g, device=device)
+            if ".norm" in name and name.endswith("linear.bias"):
+                w = w + 0.3
+        sd[name] = w.to(dtype)
+    return sd

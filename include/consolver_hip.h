@@ -182,6 +182,43 @@ int cs_unet_set_profiling(CsUNet* u, int on);
 int cs_unet_profile_entries(const CsUNet* u);
 const char* cs_unet_profile_entry(const CsUNet* u, int i, double* ms, double* flops, double* bytes, int* launches);
 
+/* ------------------------------------------------------------------------
+ * FLUX.1-Kontext DiT forward (FluxTransformer2DModel): replaces the third-party call
+ *   transformer(hidden_states, timestep / 1000, guidance, pooled_projections, encoder_hidden_states,
+ *               txt_ids, img_ids)[0]        (edit_ppo/pipeline.py:1087-1097, edit_ppo/denoise_diffusion.py:135-144)
+ * ---------------------------------------------------------------------- */
+typedef struct CsFluxConfig {
+    int in_channels;           /* 64  (packed 2x2 latents)   */
+    int num_layers;            /* 19  double-stream blocks   */
+    int num_single_layers;     /* 38  single-stream blocks   */
+    int num_heads;             /* 24                         */
+    int head_dim;              /* 128                        */
+    int joint_attention_dim;   /* 4096 (T5)                  */
+    int pooled_projection_dim; /* 768  (CLIP pooled)         */
+    int guidance_embeds;       /* 1                          */
+    int axes_dims_rope[3];     /* 16, 56, 56                 */
+    int dtype;                 /* CS_BF16 (reference) or CS_F16 */
+} CsFluxConfig;
+
+typedef struct CsFlux CsFlux;
+
+int cs_flux_create(const CsFluxConfig* cfg, CsFlux** out);
+void cs_flux_destroy(CsFlux* f);
+int cs_flux_num_weights(const CsFlux* f);
+const char* cs_flux_weight_name(const CsFlux* f, int i, int64_t* shape2, int* ndim);
+/* data: 16-bit elements in the model dtype, diffusers layout; on_device != 0: device pointer (copied). */
+int cs_flux_set_weight(CsFlux* f, const char* name, const void* data, int on_device, const int64_t* shape, int ndim);
+int cs_flux_finalize(CsFlux* f);
+size_t cs_flux_workspace_bytes(const CsFlux* f, int batch, int txt_len, int img_len);
+double cs_flux_flops(const CsFlux* f, int batch, int txt_len, int img_len);
+/* hidden_states [B, img_len, in_channels], encoder_hidden_states [B, txt_len, joint_attention_dim] (model dtype);
+ * pooled_f32 [B, pooled_projection_dim], timestep [B] (= sigma, i.e. t/1000), guidance [B]: device fp32;
+ * rope_cos / rope_sin [txt_len + img_len, head_dim/2] device fp32 (host-computed from txt_ids/img_ids,
+ * edit_ppo/pipeline.py:574-585); out [B, img_len, in_channels]. */
+int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len, const void* encoder_hidden_states, int txt_len,
+                    const float* pooled_f32, const float* timestep, const float* guidance, const float* rope_cos, const float* rope_sin,
+                    void* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

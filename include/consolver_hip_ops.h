@@ -51,6 +51,14 @@ int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int 
 /* LayerNorm over the last dim of x[M,C] */
 int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
 
+/* transformer GEMM (f16 / bf16, dtype = CS_F16 1 | CS_BF16 2): out[m][n] = act(x[m,:] . w[n,:] + bias[n]) (+ res, * gate);
+ * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
+int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
+                int rows_per_sample, int act, void* out, long ldc, int col_off, int dtype, void* stream);
+/* cs_op_attention with an explicit dtype (bf16: head dim 128) */
+int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                       int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream);
+
 /* kernel-selection knobs (tests / tuning): "conv_halo" = 0 never, 1 auto (default), 2 whenever the shape allows */
 int cs_set_tuning(const char* key, int value);
 

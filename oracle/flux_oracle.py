@@ -1,0 +1,110 @@
+"""CPU restatement (plain torch ops, fp32) of the FLUX DiT (``FluxTransformer2DModel``) forward.
+
+TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED: the arithmetic lives in diffusers (git main, unpinned,
+readme.md:234) which is not under /root/reference nor installed, and the reference holds no test or vector
+for it.  This follows the public FLUX.1 architecture with the diffusers state-dict key
+names, anchored on the call sites edit_ppo/pipeline.py:1087-1097 and edit_ppo/denoise_diffusion.py:135-144.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def sinusoid(t, dim=256):
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    a = t.float()[:, None] * freqs[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], -1)          # flip_sin_to_cos=True
+
+
+def rope_tables(ids, axes_dims, theta=10000.0):
+    cos, sin = [], []
+    ids = np.asarray(ids, np.float64)
+    for i, d in enumerate(axes_dims):
+        freqs = 1.0 / (theta ** (np.arange(0, d, 2, dtype=np.float64)[: d // 2] / d))
+        ang = np.outer(ids[:, i], freqs)
+        cos.append(np.cos(ang)); sin.append(np.sin(ang))
+    cos = torch.from_numpy(np.concatenate(cos, 1)).float().repeat_interleave(2, dim=1)
+    sin = torch.from_numpy(np.concatenate(sin, 1)).float().repeat_interleave(2, dim=1)
+    return cos, sin                                              # [S, head_dim]
+
+
+def apply_rope(x, cos, sin):                                    # x [B, H, S, D]
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return x * cos[None, None] + rot * sin[None, None]
+
+
+class FluxOracle:
+    def __init__(self, sd, config):
+        self.cfg = config
+        self.sd = {k: v.float() for k, v in sd.items()}
+        self.D = config["num_heads"] * config["head_dim"]
+
+    def lin(self, x, p):
+        return F.linear(x, self.sd[p + ".weight"], self.sd[p + ".bias"])
+
+    def rms(self, x, p):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * self.sd[p + ".weight"]
+
+    def heads(self, x):
+        B, S, _ = x.shape
+        return x.view(B, S, self.cfg["num_heads"], self.cfg["head_dim"]).transpose(1, 2)
+
+    def attn(self, q, k, v):
+        a = torch.softmax(q @ k.transpose(-1, -2) * self.cfg["head_dim"] ** -0.5, dim=-1) @ v
+        return a.transpose(1, 2).reshape(a.shape[0], a.shape[2], self.D)
+
+    @torch.no_grad()
+    def __call__(self, hidden_states, timestep, guidance, pooled, enc, txt_ids, img_ids):
+        cfg, D = self.cfg, self.D
+        x = self.lin(hidden_states.float(), "x_embedder")
+        c = self.lin(enc.float(), "context_embedder")
+        tt = "time_text_embed."
+        temb = self.lin(F.silu(self.lin(sinusoid(timestep.float() * 1000), tt + "timestep_embedder.linear_1")), tt + "timestep_embedder.linear_2")
+        if cfg["guidance_embeds"]:
+            temb = temb + self.lin(F.silu(self.lin(sinusoid(guidance.float() * 1000), tt + "guidance_embedder.linear_1")), tt + "guidance_embedder.linear_2")
+        temb = temb + self.lin(F.silu(self.lin(pooled.float(), tt + "text_embedder.linear_1")), tt + "text_embedder.linear_2")
+        ids = np.concatenate([np.asarray(txt_ids, np.float32), np.asarray(img_ids, np.float32)], 0)
+        cos, sin = rope_tables(ids, cfg["axes_dims_rope"])
+        T = c.shape[1]
+        silu_t = F.silu(temb)
+        ln = lambda h: F.layer_norm(h, (D,), eps=1e-6)
+        for i in range(cfg["num_layers"]):
+            b = f"transformer_blocks.{i}"
+            m = self.lin(silu_t, b + ".norm1.linear")[:, None].chunk(6, dim=-1)
+            mc = self.lin(silu_t, b + ".norm1_context.linear")[:, None].chunk(6, dim=-1)
+            nx = ln(x) * (1 + m[1]) + m[0]
+            nc = ln(c) * (1 + mc[1]) + mc[0]
+            q = self.rms(self.heads(self.lin(nx, b + ".attn.to_q")), b + ".attn.norm_q")
+            k = self.rms(self.heads(self.lin(nx, b + ".attn.to_k")), b + ".attn.norm_k")
+            v = self.heads(self.lin(nx, b + ".attn.to_v"))
+            cq = self.rms(self.heads(self.lin(nc, b + ".attn.add_q_proj")), b + ".attn.norm_added_q")
+            ck = self.rms(self.heads(self.lin(nc, b + ".attn.add_k_proj")), b + ".attn.norm_added_k")
+            cv = self.heads(self.lin(nc, b + ".attn.add_v_proj"))
+            q, k, v = torch.cat([cq, q], 2), torch.cat([ck, k], 2), torch.cat([cv, v], 2)
+            a = self.attn(apply_rope(q, cos, sin), apply_rope(k, cos, sin), v)
+            ca, xa = a[:, :T], a[:, T:]
+            x = x + m[2] * self.lin(xa, b + ".attn.to_out.0")
+            c = c + mc[2] * self.lin(ca, b + ".attn.to_add_out")
+            nx = ln(x) * (1 + m[4]) + m[3]
+            x = x + m[5] * self.lin(F.gelu(self.lin(nx, b + ".ff.net.0.proj"), approximate="tanh"), b + ".ff.net.2")
+            nc = ln(c) * (1 + mc[4]) + mc[3]
+            c = c + mc[5] * self.lin(F.gelu(self.lin(nc, b + ".ff_context.net.0.proj"), approximate="tanh"), b + ".ff_context.net.2")
+        h = torch.cat([c, x], dim=1)
+        for i in range(cfg["num_single_layers"]):
+            b = f"single_transformer_blocks.{i}"
+            m = self.lin(silu_t, b + ".norm.linear")[:, None].chunk(3, dim=-1)
+            n = ln(h) * (1 + m[1]) + m[0]
+            mlp = F.gelu(self.lin(n, b + ".proj_mlp"), approximate="tanh")
+            q = self.rms(self.heads(self.lin(n, b + ".attn.to_q")), b + ".attn.norm_q")
+            k = self.rms(self.heads(self.lin(n, b + ".attn.to_k")), b + ".attn.norm_k")
+            v = self.heads(self.lin(n, b + ".attn.to_v"))
+            a = self.attn(apply_rope(q, cos, sin), apply_rope(k, cos, sin), v)
+            h = h + m[2] * self.lin(torch.cat([a, mlp], dim=2), b + ".proj_out")
+        x = h[:, T:]
+        sc, sh = self.lin(silu_t, "norm_out.linear")[:, None].chunk(2, dim=-1)
+        x = ln(x) * (1 + sc) + sh
+        return self.lin(x, "proj_out")
