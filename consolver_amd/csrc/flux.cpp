@@ -167,7 +167,7 @@ struct FRun {
 int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const void* enc, int T, const float* pooled, const float* timestep,
                  const float* guidance, const float* rcos, const float* rsin, void* out, char* ws, size_t ws_bytes, hipStream_t s) {
     const CsFluxConfig& c = f->cfg; const int D = f->D, S = T + I, H = c.num_heads, dh = c.head_dim;
-    f->arena.reset(ws, ws_bytes, dry); f->dry_flops = 0;
+    f->arena.reset(dry ? (char*)256 : ws, ws_bytes, dry); f->dry_flops = 0;
     FRun Rn{f, s, dry}; Rn.dt = c.dtype;
     const size_t e = 2;
     float* sin_t = (float*)Rn.alloc((size_t)B * 256 * 4); float* h1 = (float*)Rn.alloc((size_t)B * D * 4);
