@@ -182,8 +182,10 @@ class FluxKontextSamplingEngine:
 
     @torch.no_grad()
     def generate(self, latents, image_latents, prompt_embeds, pooled_prompt_embeds, latent_hw, image_hw=None,
-                 num_inference_steps=8):
-        """latents / image_latents: packed [B, L, 64]; latent_hw = (H/2, W/2) of the packed grid."""
+                 num_inference_steps=8, record=False):
+        """latents / image_latents: packed [B, L, 64]; latent_hw = (H/2, W/2) of the packed grid.
+        record=True additionally returns the PPO trajectory records of edit_ppo/denoise_diffusion.py:152-172
+        (conds{x, epsilon}, probs, actions, masks; steps i > 0 only)."""
         dev = latents.device
         B, Lq, _ = latents.shape
         sch = self.scheduler
@@ -198,9 +200,21 @@ class FluxKontextSamplingEngine:
         txt_ids = np.zeros((prompt_embeds.shape[1], 3), np.float32)
         guidance = torch.full([B], self.guidance_scale, device=dev, dtype=torch.float32)
         x = latents
-        for t in sch.timesteps:
-            x_in = torch.cat([x, image_latents], dim=1) if image_latents is not None else x
-            v = self.transformer(x_in, (t / 1000).expand(B), guidance=guidance, pooled_projections=pooled_prompt_embeds,
-                                 encoder_hidden_states=prompt_embeds, txt_ids=txt_ids, img_ids=ids)[0][:, :Lq]
-            x = sch.step(v.contiguous(), t, x, return_dict=False)[0]
-        return x
+        rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
+        prev_record = sch.record_conds
+        sch.record_conds = bool(record)
+        try:
+            for i, t in enumerate(sch.timesteps):
+                x_in = torch.cat([x, image_latents], dim=1) if image_latents is not None else x
+                v = self.transformer(x_in, (t / 1000).expand(B), guidance=guidance, pooled_projections=pooled_prompt_embeds,
+                                     encoder_hidden_states=prompt_embeds, txt_ids=txt_ids, img_ids=ids)[0][:, :Lq]
+                x, actions, probs, conds, masks = sch.step(v.contiguous(), t, x, return_dict=False)
+                if record and i > 0:
+                    rec["x"].append(conds["x"].unsqueeze(1)); rec["epsilon"].append(conds["epsilon"].unsqueeze(1))
+                    rec["probs"].append(probs.unsqueeze(1)); rec["actions"].append(actions.unsqueeze(1)); rec["masks"].append(masks.unsqueeze(1))
+        finally:
+            sch.record_conds = prev_record
+        if not record:
+            return x
+        cat = {k: torch.cat(v, dim=1) for k, v in rec.items()}
+        return x, {"x": cat["x"], "epsilon": cat["epsilon"]}, cat["probs"], cat["actions"], cat["masks"]

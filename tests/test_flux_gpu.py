@@ -98,3 +98,9 @@ def test_flux_edit_loop_with_fmppo_scheduler():
     out = eng.generate(lat, img, enc, pooled, latent_hw=(8, 16), num_inference_steps=4)
     assert out.shape == lat.shape and out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
     assert sch.step_index == 4 and float((out.float() - lat.float()).abs().mean()) > 1e-3
+    # PPO rollout records (edit_ppo/denoise_diffusion.py:152-172): steps i > 0 only
+    out2, conds, probs, actions, masks = eng.generate(lat, img, enc, pooled, latent_hw=(8, 16), num_inference_steps=4, record=True)
+    assert conds["x"].shape == (1, 3, 2) and conds["epsilon"].shape == (1, 3, 2, 128, 64)
+    assert probs.shape == actions.shape == masks.shape == (1, 3, 1) and float(masks.min()) == 1.0
+    sig = sch.sigmas.cpu()
+    assert torch.allclose(conds["x"][0, :, 0].float().cpu(), sig[1:4].to(torch.bfloat16).float())      # bf16-rounded sigmas
