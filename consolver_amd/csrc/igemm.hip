@@ -270,6 +270,40 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Wave stagger: waves 0-3 (group A) and 4-7 (group B) share the four SIMDs pairwise.  Run in lock-step, all
+    // eight waves read their fragments right after the barrier and all multiply afterwards, so the LDS pipe and
+    // the MFMA pipe take turns (measured: the two times ADD).  Group B therefore multiplies tap t one iteration
+    // late -- after the next barrier, while group A is reading tap t+1's fragments -- and reads its own
+    // fragments while group A multiplies.  Same registers, same LDS traffic, same results.
+    const bool groupB = w >= 4;
+    f16x8 fa[2][MT], fw[2][NT];
+    auto read_frags = [&](const char* ha, const char* tb, int t) {
+        const int dy = t / 3, dx = t - 3 * dy;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int hyv = UP ? ((fy[j] + dy - 1) >> 1) + 1 : fy[j] + dy;
+            const int hxv = UP ? ((fx[j] + dx - 1) >> 1) + 1 : fx[j] + dx;
+            const int hr = fi[j] + hyv * p.HALO_W + hxv;
+            const int sw = (g ^ (hr & 7)) * 16;
+            fa[0][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + sw);
+            fa[1][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + (sw ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            fw[0][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag0);
+            fw[1][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag1);
+        }
+    };
+    auto multiply = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+    };
+
     int it = 0, ab = 0;
     for (int c = c_begin; c < c_end; ++c, ab ^= 1) {
         const char* ha = lA + ab * A_BYTES;
@@ -280,33 +314,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
             if (t < 8) stage_w(c, t + 1, wb ^ 1);
             else if (c + 1 < c_end) stage_w(c + 1, 0, wb ^ 1);
             if (c + 1 < c_end) { stage_a(c + 1, t, ab ^ 1); halo_advance(); }
-            const int dy = t / 3, dx = t - 3 * dy;
             const char* tb = lB + wb * B_BYTES + (wn * 80) * 128;
-            int arow[MT], asw[MT];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int hyv = UP ? ((fy[j] + dy - 1) >> 1) + 1 : fy[j] + dy;
-                const int hxv = UP ? ((fx[j] + dx - 1) >> 1) + 1 : fx[j] + dx;
-                const int hr = fi[j] + hyv * p.HALO_W + hxv;
-                arow[j] = hr * 128; asw[j] = (g ^ (hr & 7)) * 16;
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 fa[MT], fw[NT];
-#pragma unroll
-                for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ha + arow[j] + (asw[j] ^ (ks * 64)));
-#pragma unroll
-                for (int i = 0; i < NT; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? wfrag1 : wfrag0));
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-            }
+            if (groupB && it > 0) multiply();      // group B: tap it-1, fragments read before the previous barrier
+            read_frags(ha, tb, t);
+            if (!groupB) multiply();               // group A: this tap
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
     }
+    if (groupB) multiply();                        // drain: the last tap of group B
     if (p.splits == 1) {
         igemm_epilogue<false, NT, MT, 5>(p.e, acc, m_blk + wm * 64, n_blk + wn * 80, lane, smem + w * 11264);
     } else {
