@@ -45,6 +45,11 @@ class CsUNetConfig(C.Structure):
                 ("down_has_attn", C.c_int * 4), ("up_has_attn", C.c_int * 4)]
 
 
+class CsVaeConfig(C.Structure):
+    _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int)]
+
+
 # every symbol declared in include/consolver_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "cs_abi_version": (C.c_int, []),
@@ -60,6 +65,16 @@ SYMBOLS = {
     "cs_stack_history": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "cs_lms_ddim_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
     "cs_lms_euler_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
+    "cs_vae_create": (C.c_int, [C.POINTER(CsVaeConfig), C.POINTER(C.c_void_p)]),
+    "cs_vae_destroy": (None, [C.c_void_p]),
+    "cs_vae_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "cs_vae_num_weights": (C.c_int, [C.c_void_p]),
+    "cs_vae_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "cs_vae_finalize": (C.c_int, [C.c_void_p]),
+    "cs_vae_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "cs_vae_flops": (C.c_double, [C.c_void_p, C.c_int]),
+    "cs_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
     "cs_unet_create": (C.c_int, [C.POINTER(CsUNetConfig), C.POINTER(C.c_void_p)]),
     "cs_unet_destroy": (None, [C.c_void_p]),
     "cs_unet_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -26,6 +26,7 @@ SOURCES = {
     "flux_ops.hip": [],
     "flux.cpp": [],
     "unet.cpp": [],
+    "vae.cpp": [],
     "ops_api.cpp": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",

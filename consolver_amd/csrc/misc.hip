@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ la
 // conv_out: one wave per output pixel, lanes over 8-channel vectors of the NHWC input
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x, int B, int Cin, int H, int W,
-                                                       const f16* __restrict__ w, const f16* __restrict__ bias, f16* __restrict__ out) {
+                                                       const f16* __restrict__ w, const f16* __restrict__ bias, f16* __restrict__ out,
+                                                       int postprocess) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= (long)B * H * W) return;
@@ -117,11 +118,93 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x
         float v = 0.f;
 #pragma unroll
         for (int o = 0; o < COUT; ++o) if (lane == o) v = acc[o];
-        out[(((size_t)b * COUT + lane) * H + yo) * W + xo] = (f16)(v + (float)bias[lane]);
+        v += (float)bias[lane];
+        if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
+        out[(((size_t)b * COUT + lane) * H + yo) * W + xo] = (f16)v;
+    }
+}
+
+__global__ void pixel_linear_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
+                                    int B, int C, int HW, float in_scale, float in_shift) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int bi = (int)(i / HW), px = (int)(i - (long)bi * HW);
+    for (int o = 0; o < C; ++o) {
+        float acc = (float)b[o];
+        for (int c = 0; c < C; ++c) acc += (float)w[o * C + c] * ((float)x[((size_t)bi * C + c) * HW + px] * in_scale + in_shift);
+        out[((size_t)bi * C + o) * HW + px] = (f16)acc;
+    }
+}
+
+// one wave per row; the row (cols <= 8192) is held in registers
+__global__ __launch_bounds__(256) void row_softmax_kernel(f16* __restrict__ x, long rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int MAXV = 16;
+    const int CV = cols >> 3;
+    float v[MAXV][8];
+    float mx = -INFINITY;
+    f16* p = x + row * cols;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const f16x8 t = *reinterpret_cast<const f16x8*>(p + cv * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[j][k] = (float)t[k] * scale; mx = fmaxf(mx, v[j][k]); }
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j)
+        if (lane + 64 * j < CV) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[j][k] = __expf(v[j][k] - mx); sum += v[j][k]; }
+        }
+    const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            f16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (f16)(v[j][k] * inv);
+            *reinterpret_cast<f16x8*>(p + cv * 8) = o;
+        }
     }
 }
 
 }  // namespace
+
+int launch_pixel_linear_nchw(const f16* x, const f16* w, const f16* b, f16* out, int B, int C, int HW, float in_scale, float in_shift, hipStream_t s) {
+    if (!x || !w || !b || !out) CS_FAIL(CS_E_ARG, "pixel_linear: null pointer");
+    const long n = (long)B * HW;
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(pixel_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, out, B, C, HW, in_scale, in_shift);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_row_softmax(f16* x, long rows, int cols, float scale, hipStream_t s) {
+    if (!x) CS_FAIL(CS_E_ARG, "row_softmax: null pointer");
+    if (cols % 8 || cols > 8192) CS_FAIL(CS_E_SHAPE, "row_softmax: cols=%d unsupported", cols);
+    if (rows <= 0) return CS_OK;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, cols, scale);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s) {
+    if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out3: null pointer");
+    if (Cin % 8) CS_FAIL(CS_E_SHAPE, "conv_out3: Cin must be a multiple of 8");
+    if (B <= 0) return CS_OK;
+    const long M = (long)B * H * W;
+    hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, postprocess);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
 
 int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16* b, int N, f16* out, int act_silu, hipStream_t s) {
     if (!x || !w || !out) CS_FAIL(CS_E_ARG, "rowvec_linear: null pointer");
@@ -161,7 +244,7 @@ int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, co
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out);
+    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -143,9 +143,10 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
     if (!a.x0 || !a.out || !a.partial || !a.gamma || !a.beta) CS_FAIL(CS_E_ARG, "group_norm: null pointer");
     if (a.c0 % 8 || a.c1 % 8 || Ctot % a.groups) CS_FAIL(CS_E_SHAPE, "group_norm: channels (%d,%d) groups %d", a.c0, a.c1, a.groups);
     if (a.B <= 0 || a.HW <= 0) return a.B < 0 ? CS_E_SHAPE : CS_OK;
-    int S = GN_SPLITS;
+    const int smax = a.splits > 0 ? a.splits : GN_SPLITS;
+    int S = smax;
     while (S > 1 && (a.HW % S)) S >>= 1;
-    float* scale_shift = a.partial + (size_t)a.B * GN_SPLITS * Ctot * 2;
+    float* scale_shift = a.partial + (size_t)a.B * smax * Ctot * 2;
     for (int src = 0; src < 2; ++src) {
         const f16* x = src ? a.x1 : a.x0;
         const int C = src ? a.c1 : a.c0;

@@ -40,7 +40,8 @@ struct GroupNormArgs {
     const f16* x0; const f16* x1; int c0, c1;
     int B, HW, groups; float eps; int silu;
     const f16* gamma; const f16* beta;     // [C]
-    float* partial;                         // workspace >= B * GN_SPLITS * C * 2 floats
+    int splits;                             // 0 -> GN_SPLITS; larger for big images (VAE decoder), power of two
+    float* partial;                         // workspace >= B * (splits + 1) * C * 2 floats
     f16* out;
 };
 #define GN_SPLITS 16
@@ -86,3 +87,11 @@ int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh
 int launch_sinusoid_f32(const float* t, float mult, int R, int C, float* out, hipStream_t s);
 int launch_add3_f32(const float* a, const float* b, const float* c, float* out, long n, hipStream_t s);
 int launch_cast_f32(const float* x, void* out, long n, int dtype, hipStream_t s);
+
+// ---- VAE decoder helpers -------------------------------------------------------------------------------------
+// per-pixel CxC linear on NCHW fp16 (post_quant_conv), with an input scale (1 / scaling_factor)
+int launch_pixel_linear_nchw(const f16* x, const f16* w, const f16* b, f16* out, int B, int C, int HW, float in_scale, float in_shift, hipStream_t s);
+// row softmax of scores [rows][cols] fp16 in place: softmax(scale * x)
+int launch_row_softmax(f16* x, long rows, int cols, float scale, hipStream_t s);
+// conv 3x3 to 3 output channels, NHWC in -> NCHW out, optional (y/2+0.5).clamp(0,1)
+int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s);

@@ -23,6 +23,11 @@ def synthetic_unet_state_dict(manifest, seed=20251226):
     return sd
 
 
+def synthetic_vae_state_dict(manifest, seed=20251227):
+    """Same recipe for the AutoencoderKL decoder; conv_out is scaled so images land inside [-1, 1] with some clipping."""
+    return synthetic_unet_state_dict(manifest, seed)
+
+
 def synthetic_prompt_embeds(batch, ctx_len=77, dim=768, seed=1001):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(batch, ctx_len, dim, generator=g)

@@ -1,0 +1,126 @@
+"""HIP-backed SD1.5 ``AutoencoderKL`` decoder stand-in and the reference's ``decode_latents``.
+
+``decode_latents(vae, latents, batch_size)`` mirrors utils.py:6-34 (same name, arguments and chunking):
+``1 / vae.config.scaling_factor * latents`` -> ``vae.decode(chunk, return_dict=False)[0]`` ->
+``(image / 2 + 0.5).clamp(0, 1)`` -> ``torch.cat``.  With the HIP model the scale and the [0, 1] map
+are folded into the first / last kernel of each chunk's decode and every chunk is written straight
+into its slice of the output (no ``torch.cat`` copy); the values are the same.
+"""
+import ctypes as C
+import types
+
+import torch
+
+from . import _lib as L
+
+SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215)
+
+
+class HipAutoencoderKL:
+    is_consolver_hip = True
+    dtype = torch.float16
+
+    def __init__(self, config=None, device="cuda:0"):
+        cfg = dict(SD15_VAE_CONFIG)
+        cfg.update(config or {})
+        self.config = types.SimpleNamespace(**cfg)
+        self.device = torch.device(device)
+        c = L.CsVaeConfig()
+        c.latent_channels, c.out_channels = cfg["latent_channels"], cfg["out_channels"]
+        for i in range(4):
+            c.block_out_channels[i] = cfg["block_out_channels"][i]
+        c.layers_per_block, c.norm_num_groups, c.sample_size = cfg["layers_per_block"], cfg["norm_num_groups"], cfg["sample_size"]
+        h = C.c_void_p()
+        L.check(L.lib().cs_vae_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._ws = None
+        self._ws_batch = 0
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().cs_vae_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def manifest(self):
+        lib = L.lib()
+        out = []
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(lib.cs_vae_num_weights(self._h)):
+            name = lib.cs_vae_weight_name(self._h, i, shape, C.byref(nd)).decode()
+            out.append((name, tuple(shape[k] for k in range(nd.value))))
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        """Decoder-side tensors of a diffusers AutoencoderKL state dict (encoder keys are ignored)."""
+        lib = L.lib()
+        want = dict(self.manifest())
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"missing {len(missing)} tensors, e.g. {missing[:3]}")
+        for name, shape in want.items():
+            t = sd[name].detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {shape}")
+            sh = (C.c_int64 * len(shape))(*shape)
+            L.check(lib.cs_vae_set_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), sh, len(shape)))
+        torch.cuda.set_device(self.device)
+        L.check(lib.cs_vae_finalize(self._h))
+        self._finalized = True
+        return self
+
+    def flops(self, batch):
+        return float(L.lib().cs_vae_flops(self._h, batch))
+
+    def _workspace(self, batch):
+        if self._ws is None or batch > self._ws_batch:
+            n = int(L.lib().cs_vae_workspace_bytes(self._h, batch))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_batch = batch
+        return self._ws
+
+    def decode_into(self, z, out, in_scale=1.0, in_shift=0.0, postprocess=False):
+        if not self._finalized:
+            raise RuntimeError("weights not loaded")
+        L.require_cuda(z, "z")
+        z = z.to(torch.float16).contiguous()
+        B, Lc, h, w = z.shape
+        if Lc != self.config.latent_channels or h != self.config.sample_size or w != self.config.sample_size:
+            raise ValueError(f"latents {tuple(z.shape)} do not match the configured [*, {self.config.latent_channels}, "
+                             f"{self.config.sample_size}, {self.config.sample_size}]")
+        if out.shape != (B, self.config.out_channels, 8 * h, 8 * w) or out.dtype != torch.float16 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp16 [B, 3, 8h, 8w] tensor")
+        if B == 0:
+            return out
+        ws = self._workspace(B)
+        L.check(L.lib().cs_vae_decode(self._h, C.c_void_p(z.data_ptr()), B, float(in_scale), float(in_shift), C.c_void_p(out.data_ptr()),
+                                      int(postprocess), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                      C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
+
+    def decode(self, z, return_dict=False, **_ignored):
+        B, _, h, w = z.shape
+        out = torch.empty(B, self.config.out_channels, 8 * h, 8 * w, dtype=torch.float16, device=z.device)
+        self.decode_into(z, out)
+        if return_dict:
+            return types.SimpleNamespace(sample=out)
+        return (out,)
+
+
+def decode_latents(vae, latents, batch_size=1):
+    """utils.py:6-34.  Returns [N, 3, H, W] in [0, 1]."""
+    if not getattr(vae, "is_consolver_hip", False):
+        raise RuntimeError("decode_latents needs the HIP AutoencoderKL (no CPU fallback in the product path)")
+    if batch_size < 1:
+        raise ValueError("batch_size must be >= 1")
+    N, _, h, w = latents.shape
+    out = torch.empty(N, vae.config.out_channels, 8 * h, 8 * w, dtype=torch.float16, device=latents.device)
+    for s in range(0, N, batch_size):
+        e = min(s + batch_size, N)
+        vae.decode_into(latents[s:e], out[s:e], in_scale=1.0 / vae.config.scaling_factor, postprocess=True)
+    return out

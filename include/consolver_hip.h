@@ -219,6 +219,39 @@ int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len
                     const float* pooled_f32, const float* timestep, const float* guidance, const float* rope_cos, const float* rope_sin,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * AutoencoderKL decoder (SD1.5 VAE): latents -> images.  Replaces
+ * `vae.decode(latents / vae.config.scaling_factor).sample` and the
+ * `(image / 2 + 0.5).clamp(0, 1)` that follows it in decode_latents
+ * (utils.py:6-34; gen_pretrain/pipeline.py:589-593).
+ * ---------------------------------------------------------------------- */
+typedef struct CsVaeConfig {
+    int latent_channels, out_channels; /* 4, 3                          */
+    int block_out_channels[4];         /* 128, 256, 512, 512            */
+    int layers_per_block;              /* 2 (decoder blocks hold 3)     */
+    int norm_num_groups;               /* 32                            */
+    int sample_size;                   /* 64 (latent H = W)             */
+} CsVaeConfig;
+
+typedef struct CsVae CsVae;
+
+int cs_vae_create(const CsVaeConfig* cfg, CsVae** out);
+void cs_vae_destroy(CsVae* v);
+/* tensors by their diffusers AutoencoderKL state-dict names ("post_quant_conv.weight",
+ * "decoder.up_blocks.0.resnets.0.conv1.weight", ...); fp32 host memory, PyTorch layout */
+int cs_vae_set_weight(CsVae* v, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int cs_vae_num_weights(const CsVae* v);
+const char* cs_vae_weight_name(const CsVae* v, int i, int64_t* shape4, int* ndim);
+int cs_vae_finalize(CsVae* v);
+size_t cs_vae_workspace_bytes(const CsVae* v, int batch);
+double cs_vae_flops(const CsVae* v, int batch);
+/* latents: [batch, 4, h, w] NCHW fp16 (device).  The decoder input is
+ * latents * in_scale + in_shift (in_scale = 1 / scaling_factor, utils.py:21).
+ * images: [batch, 3, 8h, 8w] NCHW fp16; postprocess != 0 applies
+ * (x / 2 + 0.5).clamp(0, 1) (utils.py:29) in the last kernel. */
+int cs_vae_decode(CsVae* v, const void* latents, int batch, float in_scale, float in_shift, void* images,
+                  int postprocess, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
