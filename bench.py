@@ -4,8 +4,10 @@
 Workload (BASELINE.json configs[1]): SD1.5 UNet fp16 + PPOScheduler (order 4, CFG 3), batch 16
 prompts per GPU, 8 solver steps, synthetic seeded weights / prompt embeddings / noise (no
 checkpoints exist offline).  A "step" of this bench = one full 8-step generation of one batch
-(8 CFG dual-batch UNet forwards at effective batch 32 + 8 fused solver updates); the unit of the
-metric is one image's final latents (VAE decode is the step after the path and not timed).
+(8 CFG dual-batch UNet forwards at effective batch 32 + 8 fused solver updates + the VAE decode of the
+batch to 512x512 pixels, decode_latents utils.py:6-34); the unit of the metric is one decoded image.
+`--decode 0` stops at the final latents (the rate without the decoder is also reported as
+"latents_per_s" in the default run).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 Multi-GPU: one process per GPU (torch.distributed/RCCL only for the barrier and the max-over-ranks
@@ -37,7 +39,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0):
+def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=None):
     """The oracle (CPU restatement of the same path, kind 'port') timed on the host cores:
     configs[0] = B=1, 8 steps, CFG 3, fp32 (2 UNet sample-forwards + 1 solver update per step).
     Runs all steps when they fit the time budget, otherwise the steps done are scaled up."""
@@ -70,9 +72,19 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0):
         if el / done * (done + 1) > budget_s:
             break
     el = time.perf_counter() - t0
-    return {"value": done / (el * steps_total), "unit": "images/s", "cores": cores, "kind": "port",
+    per_image = el * steps_total / done
+    note = ""
+    if vae_sd is not None:                      # the reference pipeline decodes every image (decode_latents, utils.py:6-34)
+        from oracle import vae_oracle
+        vo = vae_oracle.VaeOracle(vae_sd, round_weights_to_f16=False)
+        t1 = time.perf_counter()
+        vae_oracle.decode_latents(vo, torch.from_numpy(lat).float(), 1)
+        dec = time.perf_counter() - t1
+        per_image += dec
+        note = f" + 1 VAE decode ({dec:.1f} s)"
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{done} of {steps_total} solver steps of configs[0] (B=1, CFG dual UNet forward fp32 + solver update per step) "
-                      f"in {el:.1f} s on {cores} threads" + ("" if done == steps_total else f", scaled x{steps_total}/{done}")}
+                      f"in {el:.1f} s on {cores} threads" + ("" if done == steps_total else f", scaled x{steps_total}/{done}") + note}
 
 
 def main():
@@ -84,6 +96,7 @@ def main():
     ap.add_argument("--num-inference-steps", type=int, default=8)
     ap.add_argument("--guidance", type=float, default=3.0)
     ap.add_argument("--graph", type=int, default=0, help="capture the whole generation in one hipGraph")
+    ap.add_argument("--decode", type=int, default=1, help="1: VAE-decode every batch to pixels inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
     args = ap.parse_args()
@@ -104,8 +117,9 @@ def main():
     import consolver_amd
     from consolver_amd.unet import HipUNet2DConditionModel
     from consolver_amd.engine import SDSamplingEngine
-    from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds
+    from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds, synthetic_vae_state_dict
     from consolver_amd.launch import shard_bounds
+    from consolver_amd.vae import HipAutoencoderKL
 
     unet = HipUNet2DConditionModel(device=dev)
     sd = synthetic_unet_state_dict(unet.manifest(), seed=20251226)
@@ -118,7 +132,12 @@ def main():
         for p in sch.factor_net.parameters():      # seeded N(0, 0.5) policy (zero-init = uniform sampling), SURVEY 8(d)
             p.copy_(torch.randn(p.shape, generator=g) * 0.5)
     sch.factor_net.to(dev)
-    eng = SDSamplingEngine(unet, sch, guidance_scale=args.guidance)
+    vae, vae_sd = None, None
+    if args.decode:
+        vae = HipAutoencoderKL(device=dev)
+        vae_sd = synthetic_vae_state_dict(vae.manifest(), seed=20251227)
+        vae.load_state_dict(vae_sd)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=args.guidance, vae=vae)
 
     # prompts: global list sharded contiguously over ranks (gen_ppo.py:349-357); every rank gets `batch` per generation
     B, n = args.batch, args.num_inference_steps
@@ -130,7 +149,8 @@ def main():
     noise = torch.randn(B, 4, 64, 64, generator=gen).half().to(dev)
 
     def one():
-        return eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=bool(args.graph))
+        return eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=bool(args.graph),
+                            output_type="pt" if args.decode else "latent")
 
     for _ in range(args.warmup):
         one()
@@ -139,6 +159,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.forward_events = [] if not args.graph else None
+    eng.decode_events = [] if args.decode else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one()
@@ -161,6 +182,10 @@ def main():
     else:
         fwd_ms = elapsed * 1e3 / (args.steps * n)
     eng.forward_events = None
+    decode_ms = None
+    if eng.decode_events:
+        decode_ms = sum(a.elapsed_time(b) for a, b in eng.decode_events) / len(eng.decode_events)
+    eng.decode_events = None
     achieved = flops_fwd / (fwd_ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
                 "traffic": None, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
@@ -179,7 +204,8 @@ def main():
     if rank == 0:
         images = B * world * args.steps
         rec = {
-            "metric": "images/sec at 8-step ConsistencySolver 512x512 (final latents; SD1.5 UNet fp16 + PPOScheduler, CFG 3)",
+            "metric": "images/sec at 8-step ConsistencySolver 512x512 (SD1.5 UNet fp16 + PPOScheduler, CFG 3" +
+                      (", VAE-decoded pixels)" if args.decode else ", final latents)"),
             "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic (seeded weights, prompt embeddings and noise of the SD1.5 shapes)",
@@ -188,10 +214,15 @@ def main():
                        "parallelism": f"dp{world} (prompt shards, no data-path collective)", "hipgraph": bool(args.graph)},
             "roofline": roofline,
         }
+        if decode_ms is not None:
+            rec["config"]["vae_decode"] = "AutoencoderKL decoder fp16, inside the timed region"
+            rec["vae_decode"] = {"ms_per_batch": decode_ms, "tflops": vae.flops(B) / (decode_ms * 1e-3) / 1e12,
+                                 "frac_of_step": decode_ms * args.steps / (elapsed * 1e3)}
+            rec["latents_per_s"] = images / (elapsed - decode_ms * 1e-3 * args.steps)
         if kernels:
             rec["roofline_kernels"] = kernels
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance)
+            rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance, vae_sd=vae_sd)
         elif world == 1:
             rec["cpu_baseline"] = None
         print(json.dumps(rec))

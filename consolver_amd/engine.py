@@ -20,8 +20,10 @@ from . import _lib as L
 
 
 class SDSamplingEngine:
-    def __init__(self, unet, scheduler, guidance_scale=3.0):
+    def __init__(self, unet, scheduler, guidance_scale=3.0, vae=None):
         self.unet = unet
+        self.vae = vae                  # HipAutoencoderKL for output_type="pt" (decode_latents, utils.py:6-34)
+        self.decode_events = None       # optional list collecting (start, stop) events around the VAE decode
         self.scheduler = scheduler
         self.guidance_scale = float(guidance_scale)
         self._bufs = None
@@ -70,10 +72,29 @@ class SDSamplingEngine:
 
     @torch.no_grad()
     def generate(self, prompt_embeds, negative_prompt_embeds=None, latents=None, num_inference_steps=8, generator=None,
-                 use_graph=False):
+                 use_graph=False, output_type="latent", decode_batch_size=None):
         """prompt_embeds [B,77,768]; latents [B,4,64,64] initial noise (already scaled by
-        init_noise_sigma = 1).  Returns the final latents [B,4,H,W] fp16 (a view of an internal buffer
-        that the next call overwrites -- clone to keep)."""
+        init_noise_sigma = 1).  output_type="latent" returns the final latents [B,4,H,W] fp16 (a view of an
+        internal buffer that the next call overwrites -- clone to keep); output_type="pt" returns the decoded
+        images [B,3,8H,8W] fp16 in [0, 1] (decode_latents, utils.py:6-34; needs ``vae``)."""
+        if output_type not in ("latent", "pt"):
+            raise ValueError("output_type must be 'latent' or 'pt'")
+        if output_type == "pt" and self.vae is None:
+            raise RuntimeError("output_type='pt' needs a HIP AutoencoderKL (SDSamplingEngine(..., vae=...))")
+        lat = self._generate_latents(prompt_embeds, negative_prompt_embeds, latents, num_inference_steps, generator, use_graph)
+        if output_type == "latent":
+            return lat
+        from .vae import decode_latents
+        if self.decode_events is not None:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        img = decode_latents(self.vae, lat, decode_batch_size or lat.shape[0])
+        if self.decode_events is not None:
+            b.record()
+            self.decode_events.append((a, b))
+        return img
+
+    def _generate_latents(self, prompt_embeds, negative_prompt_embeds, latents, num_inference_steps, generator, use_graph):
         L.require_cuda(prompt_embeds, "prompt_embeds")
         dev = prompt_embeds.device
         B = prompt_embeds.shape[0]

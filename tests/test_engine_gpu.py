@@ -93,3 +93,29 @@ def test_engine_trajectory_full_sd15_two_steps():
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 2-step SD1.5 rel l2", err)
     assert err < 1e-2, err
+
+
+def test_engine_pixel_output_matches_decode_of_its_latents():
+    """output_type="pt" == decode_latents (utils.py:6-34) of the latents the same engine returns, and matches the
+    fp32 VAE oracle applied to those latents (the decoder's own tolerance, tests/test_vae_gpu.py)."""
+    from consolver_amd.vae import HipAutoencoderKL
+    from consolver_amd.synth import synthetic_vae_state_dict
+    from oracle import vae_oracle
+    unet, sd, sch, w = make(dict(layers_per_block=1, sample_size=16))
+    vae = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
+    vsd = synthetic_vae_state_dict(vae.manifest(), seed=3)
+    vae.load_state_dict(vsd)
+    B, n = 3, 2
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half().to(DEV), synthetic_prompt_embeds(B, seed=1002).half().to(DEV)
+    noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(43)).half().to(DEV)
+    idx = [torch.zeros(B, 3, dtype=torch.long, device=DEV) + 5 for _ in range(n)]
+    eng = SDSamplingEngine(unet, sch, guidance_scale=3.0, vae=vae)
+    sch.factor_net.forced_action_idx = list(idx)
+    lat = eng.generate(pe, ne, latents=noise, num_inference_steps=n).clone()
+    sch.factor_net.forced_action_idx = list(idx)
+    img = eng.generate(pe, ne, latents=noise, num_inference_steps=n, output_type="pt", decode_batch_size=2)
+    assert img.shape == (B, 3, 128, 128) and float(img.min()) >= 0 and float(img.max()) <= 1
+    want = vae_oracle.decode_latents(vae_oracle.VaeOracle(vsd, vars(vae.config)), lat.float().cpu(), 2)
+    assert (img.float().cpu() - want).abs().max() < 2e-2
+    with pytest.raises(RuntimeError):
+        SDSamplingEngine(unet, sch).generate(pe, ne, latents=noise, num_inference_steps=n, output_type="pt")
