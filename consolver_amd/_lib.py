@@ -65,6 +65,12 @@ SYMBOLS = {
     "cs_stack_history": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "cs_lms_ddim_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
     "cs_lms_euler_step": (C.c_int, [C.POINTER(CsStepArgs), C.c_void_p]),
+    "cs_psnr_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "cs_image_psnr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                C.c_void_p]),
+    "cs_ppo_advantages": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_ppo_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
+                              C.c_void_p]),
     "cs_vae_create": (C.c_int, [C.POINTER(CsVaeConfig), C.POINTER(C.c_void_p)]),
     "cs_vae_destroy": (None, [C.c_void_p]),
     "cs_vae_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -27,6 +27,7 @@ SOURCES = {
     "flux.cpp": [],
     "unet.cpp": [],
     "vae.cpp": [],
+    "ppo.hip": [],
     "ops_api.cpp": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",

@@ -1,0 +1,109 @@
+"""PPO rollout consumer (config 5): decode -> reward -> advantages -> flattened PPO batch, and the loss value.
+
+Mirror of the body of the training loop in train_ppo.py:352-427 up to (not including) the optimiser
+step, with the reference's names:
+
+* ``calculate_reward(reward_type, reward_model, reward_model_processor, model_pred, target, device)``
+  (edit_ppo/reward_model.py:138-161).  Only the arithmetic-only rewards are on the path
+  (SURVEY 8 a21): ``"image_psnr"`` (:484-509).  The backbone rewards (depth / inception / clip / ...)
+  are third-party networks and out of scope; they raise.
+* ``compute_advantages`` = train_ppo.py:376-390, ``ppo_loss`` = :408-421 (forward value only: the
+  optimiser update is SURVEY row f-3).
+* ``collect_rollout`` = :352-403 for one batch of teacher pairs.
+
+Everything runs in the HIP library (cs_image_psnr / cs_ppo_advantages / cs_ppo_loss); there is no
+CPU fallback.
+"""
+import torch
+
+from . import _lib as L
+from .rollout import denoise_diffusion
+from .vae import decode_latents
+
+_DT = {torch.float32: 0, torch.float16: 1}
+
+
+def _psnr(pred, target, clamp_hi):
+    L.require_cuda(pred, "model_pred")
+    L.require_cuda(target, "target")
+    if pred.shape != target.shape:
+        raise ValueError(f"shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)} (the bilinear-resize branch, "
+                         "reward_model.py:492-494, is not on the hot path)")
+    if pred.dtype != target.dtype:
+        target = target.to(pred.dtype)
+    if pred.dtype not in _DT:
+        pred, target = pred.float(), target.float()
+    pred, target = pred.contiguous(), target.contiguous()
+    B = pred.shape[0]
+    out = torch.empty(B, 1, dtype=torch.float32, device=pred.device)
+    if B == 0:
+        return out
+    elems = pred[0].numel()
+    lib = L.lib()
+    ws = torch.empty(int(lib.cs_psnr_workspace_bytes(B)), dtype=torch.uint8, device=pred.device)
+    L.check(lib.cs_image_psnr(L.ptr(pred), L.ptr(target), B, elems, _DT[pred.dtype], float(clamp_hi), L.ptr(out), L.ptr(ws), ws.numel(),
+                              L.stream_ptr(pred.device)))
+    return out
+
+
+def calculate_image_psnr_reward(reward_model_processor, model_pred, target, device=None):
+    """edit_ppo/reward_model.py:484-509: [B,3,H,W] in [0,1] x2 -> PSNR [B,1] clamped to [0, 100]."""
+    return _psnr(model_pred, target, 100.0)
+
+
+def depth_psnr_tail(pred_depth, target_depth):
+    """edit_ppo/reward_model.py:404-422: PSNR of normalised depth maps [B,H,W], clamp(min=0) only -> [B,1]."""
+    return _psnr(pred_depth, target_depth, 0.0)
+
+
+def calculate_reward(reward_type, reward_model, reward_model_processor, model_pred, target, device=None):
+    """edit_ppo/reward_model.py:138-161.  decode_latents already maps to [0, 1], so the clamp at :141-142 is a no-op here."""
+    if reward_type == "image_psnr":
+        return calculate_image_psnr_reward(reward_model_processor, model_pred, target, device)
+    if reward_type in ("depth", "inception", "segmentation", "clip", "llava", "qwen_vl", "dino"):
+        raise NotImplementedError(f"reward_type '{reward_type}' needs a third-party backbone network (out of scope, SURVEY 8 a21)")
+    raise ValueError(f"Unknown reward_type: {reward_type}")
+
+
+def compute_advantages(rewards, masks, num_inference_steps):
+    """train_ppo.py:376-390: rewards [B,1] -> advantages [B (n-1), A] (normalised x10, tiled over the recorded steps, masked)."""
+    L.require_cuda(rewards, "rewards")
+    r = rewards.reshape(-1).to(torch.float32).contiguous()
+    B, steps = r.shape[0], num_inference_steps - 1
+    m = masks.reshape(B * steps, -1).to(torch.float32).contiguous()
+    out = torch.empty_like(m)
+    L.check(L.lib().cs_ppo_advantages(L.ptr(r), B, steps, m.shape[1], L.ptr(m), L.ptr(out), L.stream_ptr(r.device)))
+    return out
+
+
+def ppo_loss(curr_probs, old_probs, entropy, advantages, clip_range=0.2, entropy_coef=0.01):
+    """train_ppo.py:408-421 (value only): clipped surrogate on the joint distribution - entropy bonus -> 0-d fp32 tensor."""
+    L.require_cuda(curr_probs, "curr_probs")
+    c, o, e, a = (t.to(torch.float32).contiguous() for t in (curr_probs, old_probs, entropy, advantages))
+    R, A = c.shape
+    if a.shape != (R, A):
+        a = a.expand(R, A).contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=c.device)
+    L.check(L.lib().cs_ppo_loss(L.ptr(c), L.ptr(o), L.ptr(e), L.ptr(a), R, A, float(clip_range), float(entropy_coef), L.ptr(out),
+                                L.stream_ptr(c.device)))
+    return out[0]
+
+
+def collect_rollout(text_encoder, noise_scheduler, unet, vae, noise, text, tokenizer, target_latents, cfg=3.0, num_inference_steps=8,
+                    reward_type="image_psnr", reward_model=None, reward_model_processor=None, decode_batch_size=8,
+                    prompt_embeds=None, negative_prompt_embeds=None):
+    """train_ppo.py:352-403 for one batch: rollout, decode pred and teacher latents, reward, advantages, and the
+    records flattened to [B (n-1), ...].  Returns a dict(conds, actions, probs, masks, advantages, rewards, model_pred)."""
+    n = num_inference_steps
+    model_pred, conds, probs, actions, masks, _ = denoise_diffusion(
+        text_encoder, noise_scheduler, unet, noise, text, tokenizer, cfg=float(cfg), num_inference_steps=n,
+        prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+    model_pred_decoded = decode_latents(vae, model_pred, batch_size=decode_batch_size)
+    target_decoded = decode_latents(vae, target_latents, batch_size=decode_batch_size)
+    rewards = calculate_reward(reward_type, reward_model, reward_model_processor, model_pred_decoded, target_decoded, noise.device)
+    B = model_pred.shape[0]
+    flat = lambda v: v.reshape(v.shape[0] * (n - 1), *v.shape[2:])
+    conds = {k: flat(v) for k, v in conds.items()}
+    actions, probs, masks = (t.reshape(B * (n - 1), -1) for t in (actions, probs, masks))
+    advantages = compute_advantages(rewards, masks, n)
+    return dict(conds=conds, actions=actions, probs=probs, masks=masks, advantages=advantages, rewards=rewards, model_pred=model_pred)

@@ -252,6 +252,26 @@ double cs_vae_flops(const CsVae* v, int batch);
 int cs_vae_decode(CsVae* v, const void* latents, int batch, float in_scale, float in_shift, void* images,
                   int postprocess, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * PPO rollout consumer arithmetic (train_ppo.py:352-427)
+ * ---------------------------------------------------------------------- */
+/* Per-image PSNR of two image batches [B, elems] (fp16 or fp32, values in [0,1]):
+ * clamp(10 log10(1 / (mean((pred - target)^2) + 1e-8)), 0, clamp_hi) -> out[B] fp32.
+ * clamp_hi = 100 is calculate_image_psnr_reward (edit_ppo/reward_model.py:484-509);
+ * clamp_hi <= 0 means "clamp(min=0) only", the PSNR tail of the depth reward (:404-422). */
+size_t cs_psnr_workspace_bytes(int batch);
+int cs_image_psnr(const void* pred, const void* target, int B, int64_t elems, int dtype, float clamp_hi,
+                  float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* advantages[(b, j), a] = (r[b] - mean(r)) / (std_unbiased(r) + 1e-8) * 10 * masks[(b, j), a],
+ * j over the recorded steps (n - 1) (train_ppo.py:376-390).  All fp32. */
+int cs_ppo_advantages(const float* rewards, int B, int recorded_steps, int A, const float* masks,
+                      float* out, void* stream);
+/* value of the clipped surrogate + entropy bonus (train_ppo.py:408-421); inputs [R, A] fp32,
+ * loss: one fp32 on the device. */
+int cs_ppo_loss(const float* curr_probs, const float* old_probs, const float* entropy,
+                const float* advantages, int R, int A, float clip_range, float entropy_coef,
+                float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
