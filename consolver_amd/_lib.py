@@ -9,7 +9,7 @@ import os
 import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libconsolver_hip.so")
+LIB_PATH = os.environ.get("CONSOLVER_HIP_LIB") or os.path.join(PKG, "libconsolver_hip.so")   # override: A/B builds in tools/
 
 CS_F32, CS_F16, CS_BF16 = 0, 1, 2
 CS_MAX_ORDER = 8

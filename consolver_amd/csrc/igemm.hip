@@ -71,8 +71,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // (the k-loop's stage buffers are free by now), then streams the patch out ROW-wise: 16 bytes per lane,
 // whole 128/160-byte row segments per pixel, with the time-embedding and residual adds done on the way
 // (fp16-rounded conv output + fp16 residual, i.e. the same two roundings torch's fp16 graph performs).
-template <bool GEGLU, int NT, int MT, int GROUP>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], int m_base, int n_base, int lane, char* wave_lds) {
+// row of the wave's 64-row patch -> output row m (or -1): consecutive rows for the GEMM-shaped kernels, the pixels of a
+// 2-D image patch for the halo conv kernel
+struct LinearRows {
+    int m_base, M;
+    __device__ __forceinline__ int operator()(int row) const { const int m = m_base + row; return m < M ? m : -1; }
+};
+
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     constexpr int COLS = GEGLU ? GROUP * 8 : GROUP * 16;      // output columns per pass
     constexpr int ROWB = (COLS + 8) * 2;                      // padded LDS row (bytes, multiple of 16)
@@ -115,9 +122,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         for (int k = 0; k < CH; ++k) {
             const int idx = lane + 64 * k;
             const int row = idx / CH, ch = idx - row * CH;
-            const int m = m_base + row;
+            const int m = rows(row);
             const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
-            if (m < p.M) {
+            if (m >= 0) {
                 const size_t off = (size_t)m * Nout + n0 + ch * 8;
                 if (p.temb || p.res) {
                     float f[8];
@@ -147,39 +154,57 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 
 // ------------------------------------------------------------------------------------------------
 // Halo-resident 3x3 convolution (stride 1, pad 1): the generic implicit GEMM re-stages the input
-// pixels of a tile once per tap (9x) and is bound by L2->LDS bandwidth, not by MFMA.  Here a
-// workgroup owns 256 consecutive output pixels (whole image rows) x 160 channels; per 64-channel
-// chunk the (rows+2) x (W+2) input HALO is staged into LDS ONCE (zero page for the padding ring)
-// and all nine taps multiply out of it with shifted row addresses, while only the 160x64 weight
-// tile streams per tap.  Bytes staged per k-step drop from 36.9 KB (128x160 tile) to 25.6 KB for 2x
-// the FLOPs (205 vs 71 FLOP/B); glds issues per MFMA drop 2.8x.
-//   * 8 wave64 (4 pixel groups x 2 channel groups), wave tile 64 x 80, one workgroup per CU;
+// pixels of a tile once per tap (9x) and is bound by L2->LDS traffic, not by MFMA.  Here a workgroup
+// owns a 2-D PATCH of 256 output pixels (16 x 16; whole 8-wide images, several per tile, when the image
+// is smaller) x BN channels; per 64-channel chunk the (TH+2) x (TW+2) input HALO of the patch is
+// staged into LDS ONCE (zero page for the padding ring) and all nine taps multiply out of it with
+// shifted row addresses, while only the BN x 64 weight tile streams per tap.  A 16 x 16 patch needs
+// 324 halo rows whatever the image size (64 x 4 row strips needed 396 and stopped working past W = 64),
+// so the same kernel serves the UNet (8..64 wide) and the VAE decoder (64..512 wide).
+//   * 8 wave64 (4 pixel groups x 2 channel groups), wave tile 64 x BN/2, one workgroup per CU;
 //   * halo rows are 128 B, chunk index XOR-swizzled with (row & 7): conflict-free ds_read_b128 for
 //     ANY run of 16 consecutive rows, which is what a shifted tap reads;
-//   * k order is chunk-major / tap-minor; the next chunk's halo is prefetched in nine slices (one per
-//     tap) into the second halo buffer, the next tap's weights into the second weight buffer.
+//   * k order is chunk-major / tap-minor; the next chunk's halo is prefetched in eight slices (taps
+//     1..8) into the second halo buffer, the next tap's weights into the next of THREE weight buffers;
+//   * wave stagger: see the comment at the loop.  The third weight buffer and the tap-1 start of the halo
+//     prefetch exist for it: a buffer is only re-staged two barriers after its last fragment read.
 // ------------------------------------------------------------------------------------------------
 struct HaloParams {
     IgemmParams e;          // epilogue view (M, N, HoWo, bias, temb, res, out, tiles_n, nblk)
     const f16* x; const f16* w;
     int Cin, H, W, B, NC;   // INPUT geometry; NC = Cin / 64
-    int Wo;                 // output width (2 W when the nearest-x2 upsample is fused)
-    int TRW;                // output pixels per image inside one tile (min(256, Ho*Wo))
-    int HALO_W, HALO_IMG;   // W + 2 ; halo rows per image * (W + 2)
+    int Ho, Wo;             // output geometry (2 H x 2 W when the nearest-x2 upsample is fused)
+    int tw_shift, trw_shift;   // patch: TW = 1 << tw_shift output columns, TRW = TH * TW = 1 << trw_shift pixels per image in a tile
+    int PX, PP;             // patches per image row, patches per image (PP == 1: 256 / TRW whole images per tile)
+    int HALO_W, HALO_IMG;   // halo row length (TW_in + 2) ; halo rows per image patch
     int NHALO, NQ;          // halo rows per tile ; DMA instructions (8 rows each) per halo
     int splits;             // split-K over channel chunks (gridDim.y); > 1 -> fp32 partials to `partial`
     float* partial;         // [splits][M][N]
 };
 
 constexpr int HALO_ROWS_MAX = 400;
+#ifndef CS_HALO_NWB
+#define CS_HALO_NWB 3
+#endif
 
-template <bool UP>
+struct PatchRows {          // tile-local pixel -> output row
+    int o_base, b0, y0, x0, B, Ho, Wo, tw_shift, trw_shift;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int o = o_base + row;
+        const int img = o >> trw_shift, rem = o & ((1 << trw_shift) - 1);
+        const int fy = rem >> tw_shift, fx = rem & ((1 << tw_shift) - 1);
+        const int b = b0 + img;
+        return b < B ? (b * Ho + y0 + fy) * Wo + x0 + fx : -1;
+    }
+};
+
+template <bool UP, int BN>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
-    constexpr int BN = 160, NT = 5, MT = 4;
+    constexpr int NT = BN / 32, MT = 4, NBQ = BN / 8;      // NBQ: weight-tile DMA instructions (8 rows each)
     constexpr int A_BYTES = HALO_ROWS_MAX * 128, B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lA = smem;                    // [2][A_BYTES]
-    char* const lB = smem + 2 * A_BYTES;      // [2][B_BYTES]
+    char* const lB = smem + 2 * A_BYTES;      // [3][B_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -190,19 +215,25 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tm = id / p.e.tiles_n, tn = id - tm * p.e.tiles_n;
-    const int m_blk = tm * 256, n_blk = tn * BN;
-    const int HWo = p.e.HoWo;
-    const int b0 = m_blk / HWo, y0 = (m_blk - b0 * HWo) / p.Wo;          // first output row of the tile
-    const int iy_base = (UP ? (y0 >> 1) : y0) - 1;                        // input row of halo row 0
+    const int n_blk = tn * BN;
+    // tile -> (first image, patch origin)
+    int b0, y0, x0;
+    if (p.PP == 1) { b0 = tm << (8 - p.trw_shift); y0 = 0; x0 = 0; }
+    else {
+        b0 = tm / p.PP;
+        const int pr = tm - b0 * p.PP, py = pr / p.PX, px = pr - py * p.PX;
+        y0 = py << (p.trw_shift - p.tw_shift); x0 = px << p.tw_shift;
+    }
+    const int iy_base = (UP ? (y0 >> 1) : y0) - 1, ix_base = (UP ? (x0 >> 1) : x0) - 1;    // input pixel of halo (0, 0)
     const int c_per = p.NC / p.splits, c_begin = blockIdx.y * c_per, c_end = c_begin + c_per;
 
-    // ---- halo staging: at tap t this wave issues DMA instruction q = t + 9 w (rows 8q .. 8q+7).  The lane's
-    // halo row walks hr = 72 w + (lane>>3) + 8 t; its (image, y, x) coordinates are advanced incrementally
-    // (HALO_W >= 10 > 8: at most one wrap per step), so no per-tap divisions and no per-tap register table.
+    // ---- halo staging: slice s (0..7) of a chunk is DMA instruction q = s + 8 w of this wave (rows 8q .. 8q+7).  The
+    // lane's halo row walks hr = 64 w + (lane>>3) + 8 s; its (image, y, x) coordinates advance incrementally
+    // (HALO_W >= 10 > 8: at most one wrap per step), so no per-slice divisions and no per-slice register table.
     const int pch = lane & 7;
     int hi0, hy0, hx0;
     {
-        const int hr = 72 * w + (lane >> 3);
+        const int hr = 64 * w + (lane >> 3);
         hi0 = hr / p.HALO_IMG; const int rem = hr - hi0 * p.HALO_IMG;
         hy0 = rem / p.HALO_W; hx0 = rem - hy0 * p.HALO_W;
     }
@@ -211,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
     int hi = hi0, hy = hy0, hx = hx0;
     auto halo_pix = [&]() -> int {      // input pixel index of the current halo row, or -1 (padding / out of tile)
-        const int b = b0 + hi, y = iy_base + hy, x = hx - 1;
+        const int b = b0 + hi, y = iy_base + hy, x = ix_base + hx;
         const bool ok = (b < p.B) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W) & (hi * p.HALO_IMG + hy * p.HALO_W + hx < p.NHALO);
         return ok ? (b * p.H + y) * p.W + x : -1;
     };
@@ -222,21 +253,21 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
         const bool wrapy = hy >= halo_rows;
         hy = wrapy ? 0 : hy; hi += wrapy ? 1 : 0;
     };
-    // weight tile: 20 DMA instructions, wave w issues q = w, w + 8 (, w + 16 when w < 4)
+    // weight tile: NBQ DMA instructions, wave w issues q = w, w + 8 (, w + 16 when that is < NBQ)
     const f16* b_src[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = w + 8 * j;
         const int r = 8 * q + (lane >> 3);
-        b_src[j] = p.w + (size_t)(n_blk + (q < 20 ? r : 0)) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+        b_src[j] = p.w + (size_t)(n_blk + (q < NBQ ? r : 0)) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
     }
 
-    auto stage_a = [&](int c, int t, int buf) {          // one ninth of chunk c's halo
-        if (t + 9 * w < p.NQ) {
+    auto stage_a = [&](int c, int sl, int buf) {         // one eighth of chunk c's halo
+        if (sl + 8 * w < p.NQ) {
             const int pix = halo_pix();
             const uintptr_t real = (uintptr_t)(p.x + ((long)(pix < 0 ? 0 : pix) * p.Cin + c * BK + a_sw));
             const uintptr_t msk = (uintptr_t)0 - (uintptr_t)(pix >= 0);
-            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), lA + buf * A_BYTES + (t + 9 * w) * 1024);
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), lA + buf * A_BYTES + (sl + 8 * w) * 1024);
         }
     };
     auto stage_w = [&](int c, int t, int buf) {
@@ -244,16 +275,16 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
         char* lb = lB + buf * B_BYTES;
         glds16(b_src[0] + koff, lb + w * 1024);
         glds16(b_src[1] + koff, lb + (w + 8) * 1024);
-        if (w < 4) glds16(b_src[2] + koff, lb + (w + 16) * 1024);
+        if (NBQ > 16 && w + 16 < NBQ) glds16(b_src[2] + koff, lb + (w + 16) * 1024);
     };
 
-    // ---- fragment addressing: output pixel -> (image offset, row in tile, column) ------------------------
+    // ---- fragment addressing: output pixel -> (image offset, row in patch, column in patch) ---------------
     int fi[MT], fy[MT], fx[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int o = wm * 64 + j * 16 + (lane & 15);
-        const int img = o / p.TRW, rem = o - img * p.TRW;
-        fy[j] = rem / p.Wo; fx[j] = rem - fy[j] * p.Wo; fi[j] = img * p.HALO_IMG;
+        const int img = o >> p.trw_shift, rem = o & ((1 << p.trw_shift) - 1);
+        fy[j] = rem >> p.tw_shift; fx[j] = rem & ((1 << p.tw_shift) - 1); fi[j] = img * p.HALO_IMG;
     }
     const int g = lane >> 4;
     const int swz = (lane >> 1) & 7;
@@ -265,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int t = 0; t < 9; ++t) { stage_a(c_begin, t, 0); halo_advance(); }
+    for (int sl = 0; sl < 8; ++sl) { stage_a(c_begin, sl, 0); halo_advance(); }
     stage_w(c_begin, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -275,6 +306,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     // the MFMA pipe take turns (measured: the two times ADD).  Group B therefore multiplies tap t one iteration
     // late -- after the next barrier, while group A is reading tap t+1's fragments -- and reads its own
     // fragments while group A multiplies.  Same registers, same LDS traffic, same results.
+    // Group B's fragment reads of iteration `it` may still be in the LDS queue when the barrier that ends `it` opens;
+    // they have certainly returned when group B passes the NEXT barrier (its multiply in it+1 consumed them).  So a
+    // buffer is re-staged no earlier than iteration it+2: weights rotate through three buffers, and the next chunk's
+    // halo (into the buffer last read at tap 8 of the previous chunk) starts at tap 1, not tap 0.
     const bool groupB = w >= 4;
     f16x8 fa[2][MT], fw[2][NT];
     auto read_frags = [&](const char* ha, const char* tb, int t) {
@@ -304,37 +339,40 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
     };
 
-    int it = 0, ab = 0;
+    int it = 0, ab = 0, wb = 0;
     for (int c = c_begin; c < c_end; ++c, ab ^= 1) {
         const char* ha = lA + ab * A_BYTES;
         hi = hi0; hy = hy0; hx = hx0;
 #pragma unroll 1
         for (int t = 0; t < 9; ++t, ++it) {
-            const int wb = it & 1;
-            if (t < 8) stage_w(c, t + 1, wb ^ 1);
-            else if (c + 1 < c_end) stage_w(c + 1, 0, wb ^ 1);
-            if (c + 1 < c_end) { stage_a(c + 1, t, ab ^ 1); halo_advance(); }
-            const char* tb = lB + wb * B_BYTES + (wn * 80) * 128;
+            const int wnext = wb == (CS_HALO_NWB - 1) ? 0 : wb + 1;
+            if (t < 8) stage_w(c, t + 1, wnext);
+            else if (c + 1 < c_end) stage_w(c + 1, 0, wnext);
+            if (t > 0 && c + 1 < c_end) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
+            const char* tb = lB + wb * B_BYTES + (wn * (BN / 2)) * 128;
             if (groupB && it > 0) multiply();      // group B: tap it-1, fragments read before the previous barrier
             read_frags(ha, tb, t);
             if (!groupB) multiply();               // group A: this tap
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            wb = wnext;
         }
     }
     if (groupB) multiply();                        // drain: the last tap of group B
+    const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
-        igemm_epilogue<false, NT, MT, 5>(p.e, acc, m_blk + wm * 64, n_blk + wn * 80, lane, smem + w * 11264);
+        __syncthreads();                           // group B's last reads are consumed; the stage buffers become the epilogue patches
+        igemm_epilogue<false, NT, MT, NT>(p.e, acc, rows, n_blk + wn * (BN / 2), lane, smem + w * 11264);
     } else {
         // split-K: raw fp32 partial sums, 16-byte stores (4 consecutive channels per lane)
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const int m = m_blk + wm * 64 + j * 16 + (lane & 15);
-            if (m >= p.e.M) continue;
+            const int m = rows(j * 16 + (lane & 15));
+            if (m < 0) continue;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + wn * 80 + i * 16 + g * 4) = acc[i][j];
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + wn * (BN / 2) + i * 16 + g * 4) = acc[i][j];
         }
     }
 }
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         __syncthreads();
     }
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
-    igemm_epilogue<GEGLU, NT, MT, (GEGLU ? 10 : 5)>(p, acc, m_blk + wm * 64, n_blk + wn * 160, lane, smem + w * 11264);
+    igemm_epilogue<GEGLU, NT, MT, (GEGLU ? 10 : 5)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -595,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, m_blk + wm * 64, n_blk + wn * (BN / 2), lane, smem + w * 11264);
+    igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -646,45 +684,59 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n;
     const bool conv3 = a.taps == 9;
     const int use_halo = g_tune_halo;   // 0 = never, 1 = when it pays, 2 = whenever the shape allows (tests)
-    const int Wo = a.upsample ? 2 * a.Wi : a.Wi, HWo = a.Ho * a.Wo;
-    if (use_halo && conv3 && a.stride == 1 && a.c1 == 0 && a.N % 160 == 0 && !a.geglu &&
-        (256 % Wo == 0) && Wo >= 8 && (HWo % 256 == 0 || 256 % HWo == 0) && !(a.upsample && HWo < 256)) {
-        const int tiles_m = (p.M + 255) / 256, tiles_n = a.N / 160;
+    const int Wo = a.upsample ? 2 * a.Wi : a.Wi, Ho = a.upsample ? 2 * a.Hi : a.Hi;
+    const int hbn = a.N % 160 == 0 ? 160 : (a.N % 128 == 0 ? 128 : 0);
+    // patch geometry: TW = min(Wo, 16) in {8, 16}; TH = min(Ho, 256 / TW); both powers of two dividing the image
+    const int TW = Wo >= 16 ? 16 : Wo, THmax = TW ? 256 / TW : 0, TH = Ho < THmax ? Ho : THmax;
+    const bool pow2 = TW == 8 || TW == 16;
+    const bool geom_ok = pow2 && TH >= 2 && (TH & (TH - 1)) == 0 && Wo % TW == 0 && Ho % TH == 0 && Ho == a.Ho && Wo == a.Wo &&
+                         (!a.upsample || (TH % 2 == 0 && TW % 2 == 0 && TW / 2 + 2 >= 10));
+    if (use_halo && conv3 && a.stride == 1 && a.c1 == 0 && hbn && !a.geglu && geom_ok) {
+        const int TRW = TH * TW, IPT = 256 / TRW;                       // output pixels per image in a tile; images per tile
+        const int PX = Wo / TW, PY = Ho / TH, PP = PX * PY;
+        const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP, tiles_n = a.N / hbn;
         const int NC = cin / BK;
         int splits = 1;
         if (tiles_m * tiles_n < 160 && a.splitk_ws) {          // small images: split the channel chunks to fill the chip
             while (splits < 8 && tiles_m * tiles_n * splits < 192 && NC % (splits * 2) == 0 &&
                    (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
         }
-        const bool pays = tiles_m * tiles_n * splits >= 160 && !(cin == 320 && a.N == 320 && !a.upsample);
-        if (pays || use_halo == 2) {
-            HaloParams h;
+        const bool pays = tiles_m * tiles_n * splits >= 160;
+        const int tin_w = a.upsample ? TW / 2 : TW, tin_h = a.upsample ? TH / 2 : TH;
+        HaloParams h;
+        h.HALO_W = tin_w + 2; h.HALO_IMG = (tin_h + 2) * (tin_w + 2); h.NHALO = IPT * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
+        if ((pays || use_halo == 2) && h.NHALO <= HALO_ROWS_MAX && h.NQ <= 64 && (PP == 1 || IPT == 1)) {
             h.e = p; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n;
-            h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Wo = Wo;
-            h.TRW = HWo < 256 ? HWo : 256;
-            const int rows_out = h.TRW / Wo, ipt = 256 / h.TRW;
-            const int rows_in = a.upsample ? rows_out / 2 + 2 : rows_out + 2;
-            h.HALO_W = a.Wi + 2; h.HALO_IMG = rows_in * (a.Wi + 2); h.NHALO = ipt * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
+            h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Ho = Ho; h.Wo = Wo;
+            h.tw_shift = TW == 16 ? 4 : 3; h.trw_shift = 0; while ((1 << h.trw_shift) < TRW) ++h.trw_shift;
+            h.PX = PX; h.PP = PP;
             h.splits = splits; h.partial = a.splitk_ws;
-            if (h.NHALO <= HALO_ROWS_MAX && (!a.upsample || rows_out % 2 == 0)) {
-                constexpr size_t lds = 2 * (HALO_ROWS_MAX * 128 + 160 * 128);
-                static bool configured = false;
-                if (!configured) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    configured = true;
-                }
-                if (a.upsample) hipLaunchKernelGGL(conv3_halo_kernel<true>, dim3(h.e.nblk, splits), dim3(512), lds, s, h);
-                else hipLaunchKernelGGL(conv3_halo_kernel<false>, dim3(h.e.nblk, splits), dim3(512), lds, s, h);
-                CS_CHECK_LAUNCH();
-                if (splits > 1) {
-                    const long total = (long)p.M * (p.N / 8);
-                    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
-                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, h.e, (const float*)a.splitk_ws, splits);
-                    CS_CHECK_LAUNCH();
-                }
-                return CS_OK;
+            constexpr size_t lds = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);
+            static bool configured = false;
+            if (!configured) {
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                configured = true;
             }
+            const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * 128);
+            const dim3 grid(h.e.nblk, splits);
+            if (hbn == 160) {
+                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 160>), grid, dim3(512), l, s, h);
+                else hipLaunchKernelGGL((conv3_halo_kernel<false, 160>), grid, dim3(512), l, s, h);
+            } else {
+                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 128>), grid, dim3(512), l, s, h);
+                else hipLaunchKernelGGL((conv3_halo_kernel<false, 128>), grid, dim3(512), l, s, h);
+            }
+            CS_CHECK_LAUNCH();
+            if (splits > 1) {
+                const long total = (long)p.M * (p.N / 8);
+                int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid2), dim3(256), 0, s, h.e, (const float*)a.splitk_ws, splits);
+                CS_CHECK_LAUNCH();
+            }
+            return CS_OK;
         }
     }
     if (a.geglu && conv3) CS_FAIL(CS_E_ARG, "igemm: GEGLU epilogue only for linear layers");

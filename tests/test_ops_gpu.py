@@ -71,15 +71,19 @@ def test_conv2d(case):
     assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
 
 
-HALO_CASES = [  # B, H, cin, N : halo-resident conv3x3 kernel forced on small shapes (covers every tile geometry)
-    (2, 64, 64, 320), (3, 32, 128, 160), (2, 16, 64, 320), (5, 8, 64, 160), (1, 8, 128, 320), (1, 64, 320, 640)]
+HALO_CASES = [  # B, H, W, cin, N : halo-resident conv3x3 kernel forced on small shapes (covers every tile geometry:
+    # 16x16 patches of 16..256-wide images, whole 8-wide images 4 per tile with a ragged last tile, non-square images,
+    # 160- and 128-channel tiles)
+    (2, 64, 64, 64, 320), (3, 32, 32, 128, 160), (2, 16, 16, 64, 320), (5, 8, 8, 64, 160), (1, 8, 8, 128, 320), (1, 64, 64, 320, 640),
+    (1, 128, 128, 64, 128), (1, 256, 256, 64, 256), (2, 64, 64, 128, 512), (3, 8, 8, 64, 128), (1, 16, 16, 64, 384),
+    (2, 16, 32, 64, 160), (1, 32, 16, 64, 128), (3, 16, 8, 64, 160), (1, 48, 80, 64, 128)]
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_conv3x3_halo_kernel(case):
-    B, H, cin, N = case
-    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
-    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
+    B, H, W, cin, N = case
+    x, w, b = rnd(B, H, W, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, W, N, seed=5)
     ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
     ops.set_tuning("conv_halo", 2)
     try:
@@ -97,7 +101,7 @@ def test_conv3x3_halo_kernel(case):
     assert rel_l2(out.float(), generic.float()) < 5e-4      # same math, different k order
 
 
-@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320)])
+@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320), (1, 64, 64, 256), (2, 128, 64, 128)])
 def test_conv3x3_halo_kernel_fused_upsample(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
