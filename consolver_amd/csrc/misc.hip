@@ -124,6 +124,61 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x
     }
 }
 
+
+// conv_out for big images (the VAE's 128 -> 3 at 512 x 512): one workgroup = one 16 x 16 output patch; per 64-channel
+// chunk the 18 x 18 input halo is staged in LDS once (128-byte rows, chunk index XOR (row & 7)) and every thread
+// accumulates its pixel's COUT dot products with v_dot2_f32_f16; the (wave-uniform) weights come through the scalar cache.
+// The one-wave-per-pixel kernel above re-read the 9-tap neighbourhood from L2 per pixel with a quarter of its lanes.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restrict__ x, int Cin, int H, int W, const f16* __restrict__ w,
+                                                             const f16* __restrict__ bias, f16* __restrict__ out, int postprocess) {
+    __shared__ __attribute__((aligned(16))) f16 halo[324 * 64];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int PX = W >> 4;
+    const int b = blockIdx.y, py = blockIdx.x / PX, px = blockIdx.x - py * PX;
+    const int y0 = py * 16, x0 = px * 16;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 324 * 8; i += 256) {
+            const int row = i >> 3, ch = i & 7;
+            const int hy = row / 18, hx = row - hy * 18;
+            const int y = y0 + hy - 1, xx = x0 + hx - 1;
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f16x8*>(x + (((size_t)b * H + y) * W + xx) * Cin + c0 + ch * 8);
+            *reinterpret_cast<f16x8*>(halo + row * 64 + ((ch ^ (row & 7)) << 3)) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const int hr = (ty + dy) * 18 + tx + dx;
+            const f16* hp = halo + hr * 64;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(hp + ((ch ^ (hr & 7)) << 3));
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const f16x8 wv = *reinterpret_cast<const f16x8*>(w + ((size_t)o * 9 + tap) * Cin + c0 + ch * 8);     // uniform -> s_load
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[o] = __builtin_amdgcn_fdot2(f16x2{v[2 * k], v[2 * k + 1]}, f16x2{wv[2 * k], wv[2 * k + 1]}, acc[o], false);
+                }
+            }
+        }
+    }
+    const int y = y0 + ty, xx = x0 + tx;
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        float v = acc[o] + (float)bias[o];
+        if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
+        out[(((size_t)b * COUT + o) * H + y) * W + xx] = (f16)v;
+    }
+}
+
 __global__ void pixel_linear_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
                                     int B, int C, int HW, float in_scale, float in_shift) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,6 +255,11 @@ int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, c
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out3: null pointer");
     if (Cin % 8) CS_FAIL(CS_E_SHAPE, "conv_out3: Cin must be a multiple of 8");
     if (B <= 0) return CS_OK;
+    if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
+        hipLaunchKernelGGL(conv_out_patch_kernel<3>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
     const long M = (long)B * H * W;
     hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, postprocess);
     CS_CHECK_LAUNCH();

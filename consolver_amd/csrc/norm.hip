@@ -39,22 +39,27 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_
     }
 }
 
-// pass 2: one wave per (sample, group): reduce the splits, group statistics, per-channel scale/shift
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
-                                                         const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// pass 2: one workgroup per (sample, group): reduce the splits, group statistics, per-channel scale/shift
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
+                                                          const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
+    __shared__ float red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int cpg = Ctot / groups;
     float a = 0.f, q = 0.f;
-    for (int i = lane; i < S * cpg; i += 64) {            // (split, channel) pairs of this group
+    for (int i = tid; i < S * cpg; i += 256) {            // (split, channel) pairs of this group
         const int s = i / cpg, c = g * cpg + (i - s * cpg);
         const float* p = partial + (((size_t)b * S + s) * Ctot + c) * 2;
         a += p[0]; q += p[1];
     }
     a = wave_sum(a); q = wave_sum(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = q; }
+    __syncthreads();
+    a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const float n = (float)cpg * (float)HW;
     const float mean = a / n;
     const float rstd = rsqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
         const float sc = (float)gamma[c] * rstd;
         scale_shift[((size_t)b * Ctot + c) * 2] = sc;
         scale_shift[((size_t)b * Ctot + c) * 2 + 1] = (float)beta[c] - mean * sc;
@@ -157,7 +162,7 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
         if (T > 1024) CS_FAIL(CS_E_SHAPE, "group_norm: C=%d too wide", C);
         hipLaunchKernelGGL(gn_stats_kernel, dim3(S, a.B), dim3(T), (size_t)T * 16 * sizeof(float), s, x, C, a.HW, src ? a.c0 : 0, Ctot, a.partial);
     }
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s,
                        a.partial, S, Ctot, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
     int chunks = (a.HW * (Ctot / 8) + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
     if (chunks < 1) chunks = 1;

@@ -1,0 +1,1 @@
+for v in $1 $2 $1 $2; do echo "== $v"; CONSOLVER_HIP_LIB=$PWD/tools/ab/lib_$v.so python tools/bench_ops.py $3 2>&1 | grep -E "$4"; done
