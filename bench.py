@@ -204,8 +204,18 @@ def main():
         decode_ms = sum(a.elapsed_time(b) for a, b in eng.decode_events) / len(eng.decode_events)
         eng.decode_events = None
     achieved = flops_fwd / (fwd_ms * 1e-3) / 1e12
+    # HBM-side bytes per UNet forward: PMC counters are collected offline (separate rocprofv3 --pmc passes, tools/profile_round.sh)
+    # and committed under profiles/; the newest committed measurement at this batch size is quoted here
+    traffic, traffic_src = None, None
+    if eff_batch == 32:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+            try:
+                traffic, traffic_src = json.load(open(f))["traffic_bytes_per_forward"], os.path.relpath(f, ROOT)
+            except Exception:
+                pass
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
-                "traffic": None, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
                 "launch_ms": fwd_ms, "flops_per_launch": flops_fwd}
 
     kernels = None

@@ -1,0 +1,26 @@
+"""UNet forward A/B tool: batch 32 (16 images x CFG) SD1.5 forward, mean of N runs + per-class profile.
+CS_TUNE="key=value,..." sets library tuning knobs; CONSOLVER_HIP_LIB selects an alternative build."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from consolver_amd import ops
+from consolver_amd.unet import HipUNet2DConditionModel
+from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds
+dev = "cuda:0"
+for kv in os.environ.get("CS_TUNE", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("="); ops.set_tuning(k, int(v))
+u = HipUNet2DConditionModel(device=dev); u.load_state_dict(synthetic_unet_state_dict(u.manifest()))
+lat = torch.randn(16, 4, 64, 64, device=dev).half()
+ctx = synthetic_prompt_embeds(32).half().to(dev)
+t = torch.tensor([499.0], device=dev)
+for _ in range(3): u(lat, t, encoder_hidden_states=ctx, dup=2)
+torch.cuda.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(n): u(lat, t, encoder_hidden_states=ctx, dup=2, reuse_kv=True)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / n
+print(f"forward {ms:.3f} ms  {u.flops(32) / ms / 1e9:.1f} TFLOP/s  ({u.flops(32) / ms / 1e9 / 2500 * 100:.1f} % of fp16 MFMA peak)")
+u.set_profiling(True); u(lat, t, encoder_hidden_states=ctx, dup=2, reuse_kv=True); pr = u.profile(); u.set_profiling(False)
+print("  ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()))
