@@ -71,6 +71,13 @@ SYMBOLS = {
     "cs_ppo_advantages": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_ppo_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p,
                               C.c_void_p]),
+    "cs_policy_param_count": (C.c_size_t, [C.POINTER(CsFactorNet)]),
+    "cs_policy_workspace_bytes": (C.c_size_t, [C.POINTER(CsFactorNet), C.c_int]),
+    "cs_ppo_policy_grads": (C.c_int, [C.POINTER(CsFactorNet), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_clip_grad_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "cs_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_void_p]),
     "cs_vae_create": (C.c_int, [C.POINTER(CsVaeConfig), C.POINTER(C.c_void_p)]),
     "cs_vae_destroy": (None, [C.c_void_p]),
     "cs_vae_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -7,13 +7,15 @@ step, with the reference's names:
   (edit_ppo/reward_model.py:138-161).  Only the arithmetic-only rewards are on the path
   (SURVEY 8 a21): ``"image_psnr"`` (:484-509).  The backbone rewards (depth / inception / clip / ...)
   are third-party networks and out of scope; they raise.
-* ``compute_advantages`` = train_ppo.py:376-390, ``ppo_loss`` = :408-421 (forward value only: the
-  optimiser update is SURVEY row f-3).
+* ``compute_advantages`` = train_ppo.py:376-390, ``ppo_loss`` = :408-421 (value), ``PolicyTrainer`` = the
+  optimisation step :404-437 (gradients, clip_grad_norm_, AdamW) and the checkpoint format.
 * ``collect_rollout`` = :352-403 for one batch of teacher pairs.
 
 Everything runs in the HIP library (cs_image_psnr / cs_ppo_advantages / cs_ppo_loss); there is no
 CPU fallback.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -107,3 +109,95 @@ def collect_rollout(text_encoder, noise_scheduler, unet, vae, noise, text, token
     actions, probs, masks = (t.reshape(B * (n - 1), -1) for t in (actions, probs, masks))
     advantages = compute_advantages(rewards, masks, n)
     return dict(conds=conds, actions=actions, probs=probs, masks=masks, advantages=advantages, rewards=rewards, model_pred=model_pred)
+
+
+class PolicyTrainer:
+    """The optimisation step of train_ppo.py:404-437 on the HIP library: gradient of the clipped-surrogate + entropy loss
+    with respect to ``factor_net``'s parameters (hand-derived backward, cs_ppo_policy_grads), ``clip_grad_norm_`` and
+    ``torch.optim.AdamW`` semantics (cs_clip_grad_norm / cs_adamw_step), parameters updated in place.
+
+    ``factor_net`` must hold fp32 parameters on the GPU (the reference trains the policy in fp32, train_ppo.py:205-229).
+    Checkpoints use the reference's format: ``<dir>/checkpoint-<step>/model.ckpt`` = ``torch.save(factor_net.state_dict())``
+    including the ``action_values`` buffer (train_ppo.py:174-178)."""
+
+    def __init__(self, factor_net, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0,
+                 clip_range=0.2, entropy_coef=0.01):
+        self.net = factor_net
+        self.lr, self.betas, self.weight_decay, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(weight_decay), float(eps)
+        self.max_grad_norm, self.clip_range, self.entropy_coef = float(max_grad_norm), float(clip_range), float(entropy_coef)
+        self.params = [factor_net.mlp[0].weight, factor_net.mlp[0].bias, factor_net.mlp[2].weight, factor_net.mlp[2].bias,
+                       factor_net.mlp[4].weight, factor_net.mlp[4].bias]
+        for p in self.params:
+            L.require_cuda(p, "factor_net parameter (call .to('cuda') first)")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("PolicyTrainer needs contiguous fp32 parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        if n != int(L.lib().cs_policy_param_count(C.byref(factor_net._net_struct()))):
+            raise RuntimeError("parameter count mismatch between the module and the library")
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.grads)
+        self.exp_avg_sq = torch.zeros_like(self.grads)
+        self.step_count = 0
+        self._ws = None
+        self._out = torch.zeros(2, dtype=torch.float32, device=dev)       # loss, grad norm
+
+    def grad_views(self):
+        """per-parameter views of the packed gradient vector, state-dict order."""
+        out, o = {}, 0
+        for name, p in zip(("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias"), self.params):
+            out[name] = self.grads[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        return out
+
+    def compute_grads(self, conds, actions, old_probs, advantages):
+        """-> loss (0-d tensor); gradients are left in ``self.grads`` (un-clipped)."""
+        net = self.net
+        x = L.require_cuda(conds["x"], "conds['x']").to(torch.float32).contiguous()
+        R = x.shape[0]
+        cosf = None
+        if net.use_conv:
+            eps = conds["epsilon"]
+            cosf = net.cosine_features([eps[:, k] for k in range(net.order_dim)], net.order_dim)
+        a, o, adv = (t.to(torch.float32).reshape(R, -1).contiguous() for t in (actions, old_probs, advantages))
+        if adv.shape[1] != a.shape[1]:
+            adv = adv.expand(R, a.shape[1]).contiguous()
+        st = net._net_struct()
+        lib = L.lib()
+        need = int(lib.cs_policy_workspace_bytes(C.byref(st), R))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        L.check(lib.cs_ppo_policy_grads(C.byref(st), L.ptr(x), L.ptr(cosf), L.ptr(a), L.ptr(net._weights32()[6]), L.ptr(o), L.ptr(adv), R,
+                                        self.clip_range, self.entropy_coef, L.ptr(self.grads), L.ptr(self._out), L.ptr(self._ws),
+                                        self._ws.numel(), L.stream_ptr(x.device)))
+        return self._out[0]
+
+    def step(self, conds, actions, old_probs, advantages):
+        """one PPO epoch iteration (train_ppo.py:408-437) -> (loss, total grad norm before clipping), both 0-d tensors."""
+        loss = self.compute_grads(conds, actions, old_probs, advantages).clone()
+        lib, st = L.lib(), L.stream_ptr(self.grads.device)
+        L.check(lib.cs_clip_grad_norm(L.ptr(self.grads), self.grads.numel(), self.max_grad_norm, L.ptr(self._out[1:]), st))
+        self.step_count += 1
+        o = 0
+        for p in self.params:
+            n = p.numel()
+            L.check(lib.cs_adamw_step(L.ptr(p.data), L.ptr(self.grads[o:]), L.ptr(self.exp_avg[o:]), L.ptr(self.exp_avg_sq[o:]), n,
+                                      self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, st))
+            o += n
+        return loss, self._out[1].clone()
+
+    # -- checkpoint format of the reference (train_ppo.py:174-186) ---------------------------------------------
+    def save_checkpoint(self, output_dir, global_step):
+        import os
+        d = os.path.join(output_dir, f"checkpoint-{global_step}")
+        os.makedirs(d, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.net.state_dict().items()}, os.path.join(d, "model.ckpt"))
+        return d
+
+    def load_checkpoint(self, input_dir):
+        import os
+        sd = torch.load(os.path.join(input_dir, "model.ckpt"), map_location="cpu")
+        with torch.no_grad():
+            for k, v in self.net.state_dict().items():
+                v.copy_(sd[k].to(v.device, v.dtype))
+        return self

@@ -272,6 +272,27 @@ int cs_ppo_loss(const float* curr_probs, const float* old_probs, const float* en
                 const float* advantages, int R, int A, float clip_range, float entropy_coef,
                 float* loss, void* stream);
 
+/* ------------------------------------------------------------------------
+ * PPO policy update (train_ppo.py:404-437): gradients of the loss with respect to the
+ * factor net, clip_grad_norm_, AdamW.  All fp32 device memory.
+ * ---------------------------------------------------------------------- */
+/* number of trainable parameters = floats in the packed gradient vector, laid out in state-dict
+ * order: mlp.0.weight [H, in], mlp.0.bias, mlp.2.weight [H, H], mlp.2.bias, mlp.4.weight [A K, H], mlp.4.bias */
+size_t cs_policy_param_count(const CsFactorNet* net);
+size_t cs_policy_workspace_bytes(const CsFactorNet* net, int R);
+/* x [R, 2] (timestep pairs, un-normalised), cos_feat [R, in_dim - 2] or NULL, actions / old_probs / advantages [R, A],
+ * action_values [A, K] -> grads (packed, see above) = d loss / d params, loss (one float, may be NULL) with
+ * loss = -mean min(adv rho, adv clip(rho, 1 +- clip_range)) - entropy_coef mean(H / ln K) (train_ppo.py:408-427). */
+int cs_ppo_policy_grads(const CsFactorNet* net, const float* x, const float* cos_feat, const float* actions,
+                        const float* action_values, const float* old_probs, const float* advantages, int R,
+                        float clip_range, float entropy_coef, float* grads, float* loss,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* torch.nn.utils.clip_grad_norm_ over one packed vector (train_ppo.py:432-435); total_norm may be NULL */
+int cs_clip_grad_norm(float* grads, int64_t n, float max_norm, float* total_norm, void* stream);
+/* one torch.optim.AdamW step on one tensor (train_ppo.py:223-229,436); step counts from 1 */
+int cs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -256,6 +256,61 @@ def gen_sd():
         ro[f"r{ri}_actions"] = actions.numpy()
         ro[f"r{ri}_masks"] = masks.numpy()
     np.savez_compressed(os.path.join(OUT, "sd_rollout.npz"), **ro)
+
+    # ---------------- PPO policy update (train_ppo.py:404-437) -------------------
+    # The reference's FactorNetPPO under torch autograd, the loss expression of the training loop, clip_grad_norm_ and
+    # torch.optim.AdamW for two optimisation epochs on one collected batch.
+    up = {}
+    torch.set_grad_enabled(True)
+    for ui, (o, sc, uc, K, H, R) in enumerate([(4, 0, False, 11, 32, 48), (2, 2, True, 5, 16, 21), (3, 1, False, 7, 24, 1)]):
+        with ref_stubs.quiet():
+            net = FactorNetPPO(hidden_dim=H, num_actions=K, order_dim=o, scaler_dim=sc, use_conv=uc)
+        w0 = _seeded_weights(torch, net, 4000 + ui)
+        A = o + sc - 1
+        rng = np.random.default_rng(4100 + ui)
+        ts = rng.integers(1, 999, size=(R, 1)).astype(np.float32)
+        x = np.concatenate([ts, np.maximum(ts - 125, 0)], 1).astype(np.float32)
+        conds = {"x": torch.from_numpy(x)}
+        if uc:
+            eps = rng.standard_normal((R, o, 4, 6, 6)).astype(np.float32)
+            conds["epsilon"] = torch.from_numpy(eps)
+            up[f"u{ui}_eps"] = eps
+        av = net.action_values.numpy()
+        idx = rng.integers(0, K, size=(R, A))
+        actions = np.take_along_axis(np.broadcast_to(av, (R, A, K)), idx[..., None], 2)[..., 0].astype(np.float32)
+        with torch.no_grad():
+            cur, _ = net.get_action_probs(conds, torch.from_numpy(actions))
+        old = np.clip(cur.numpy() * rng.uniform(0.55, 1.6, size=(R, A)), 1e-4, 1.0).astype(np.float32)   # ratios on both sides of the clip range
+        adv = (rng.standard_normal((R, 1)) * 10).astype(np.float32) * (rng.random((R, A)) > 0.25).astype(np.float32)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+        clip_range, entropy_coef, max_norm = 0.2, 0.01, 1.0
+        for ep in range(2):
+            cur, ent = net(conds, torch.from_numpy(actions))
+            lp = (cur + 1e-9).log().sum(dim=1).unsqueeze(1)
+            olp = (torch.from_numpy(old) + 1e-9).log().sum(dim=1).unsqueeze(1)
+            ratio = (lp - olp).exp()
+            clipped = torch.clamp(ratio, 1 - clip_range, 1 + clip_range)
+            a = torch.from_numpy(adv)
+            loss = -torch.min(a * ratio, a * clipped).mean() - entropy_coef * ent.mean()
+            loss.backward()
+            up[f"u{ui}_e{ep}_loss"] = np.float32(loss.item())
+            for k, prm in net.named_parameters():
+                up[f"u{ui}_e{ep}_grad_{k}"] = prm.grad.detach().numpy().copy()
+            up[f"u{ui}_e{ep}_norm"] = np.float32(torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm).item())
+            opt.step()
+            opt.zero_grad()
+            for k, v in net.state_dict().items():
+                up[f"u{ui}_e{ep}_after_{k}"] = v.detach().numpy().copy()
+        up[f"u{ui}_cfg"] = np.asarray([o, sc, int(uc), K, H, R], np.int64)
+        up[f"u{ui}_hyper"] = np.asarray([1e-3, 0.9, 0.999, 1e-2, 1e-8, clip_range, entropy_coef, max_norm], np.float64)
+        up[f"u{ui}_x"] = x
+        up[f"u{ui}_actions"] = actions
+        up[f"u{ui}_old_probs"] = old
+        up[f"u{ui}_adv"] = adv
+        for k, v in w0.items():
+            up[f"u{ui}_w_{k}"] = v
+    torch.set_grad_enabled(False)
+    np.savez_compressed(os.path.join(OUT, "sd_ppo_update.npz"), **up)
     print("sd fixtures written")
 
 

@@ -137,3 +137,37 @@ def test_flux_scheduler_tables(golden):
     with pytest.raises(ValueError):
         s.step(torch.zeros(1, 4, 4), 3, torch.zeros(1, 4, 4))    # integer timestep
     assert abs(tables.calculate_shift(4096) - 1.15) < 1e-12
+
+
+def test_teacher_pair_dataset_roundtrip(tmp_path):
+    """on-disk teacher-pair format (generate_data.py:180-213 / data_processing.py:10-83)"""
+    import torch
+    from consolver_amd import ppo_data as pd
+    g = torch.Generator().manual_seed(0)
+    want = {}
+    for i in range(5):
+        sid = pd.teacher_pair_id(3, i)
+        assert sid == f"3_{i:08d}"
+        noise, lat = torch.randn(4, 8, 8, generator=g), torch.randn(4, 8, 8, generator=g)
+        pd.save_teacher_pair(str(tmp_path), sid, f"prompt {i}\n", noise, lat)
+        want[sid] = (f"prompt {i}", noise, lat)
+    assert sorted(os.listdir(tmp_path))[:2] == ["3_00000000.txt", "3_00000001.txt"]
+    ds = pd.TeacherPairDataset(str(tmp_path), strict=True)
+    assert len(ds) == 5
+    for i in range(5):
+        text, noise, lat = ds[i]
+        t, n, l = want[ds.ids[i]]
+        assert text == t and torch.equal(noise, n) and torch.equal(lat, l)
+    text, noise, lat = pd.collate_teacher_pairs([ds[i] for i in range(4)])
+    assert noise.shape == (4, 4, 8, 8) and len(text) == 4
+    t2, n2, l2 = pd.repeat_random_sample((text, noise, lat))
+    assert len(set(t2)) == 1 and all(torch.equal(n2[0], n2[k]) for k in range(4)) and l2.shape == lat.shape
+    j = text.index(t2[0])
+    assert torch.equal(n2[0], noise[j]) and torch.equal(l2[0], lat[j])
+    # NaN latents are rejected at write time and skipped (replaced by another sample) at read time unless strict
+    with pytest.raises(ValueError):
+        pd.save_teacher_pair(str(tmp_path), "9_00000000", "x", noise[0], torch.full((4, 8, 8), float("nan")))
+    torch.save(torch.full((4, 8, 8), float("nan")), os.path.join(tmp_path, "latent_3_00000002.pth"))
+    with pytest.raises(FileNotFoundError):
+        ds[2]
+    assert pd.TeacherPairDataset(str(tmp_path))[2][0].startswith("prompt")

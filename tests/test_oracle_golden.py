@@ -217,3 +217,32 @@ def test_shard_rules(n, world):
     spans = [so.shard_bounds_ceil(n, world, r) for r in range(world)]  # generate_ours.py:176-177
     assert sum(e - s for s, e in spans) == n
     assert all(e - s <= -(-n // world) for s, e in spans)
+
+
+def test_ppo_policy_update_vs_reference_autograd(golden):
+    """train_ppo.py:404-437: the oracle's hand-derived gradients, clip_grad_norm_ and AdamW restatements against the
+    reference's FactorNetPPO under torch autograd + torch.optim.AdamW (two optimisation epochs on one batch; plain,
+    use_conv and single-row batches; ratios on both sides of the clip range)."""
+    g = golden["sd_ppo_update"]
+    for ui in range(3):
+        o, sc, uc, K, H, R = [int(v) for v in g[f"u{ui}_cfg"]]
+        lr, b1, b2, wd, eps, clip_range, entropy_coef, max_norm = [float(v) for v in g[f"u{ui}_hyper"]]
+        w = weights(g, f"u{ui}_w_")
+        eps_stack = g[f"u{ui}_eps"] if uc else None
+        state = {}
+        for ep in range(2):
+            loss, grads = so.ppo_policy_grads(w, g[f"u{ui}_x"], g[f"u{ui}_actions"], g[f"u{ui}_old_probs"], g[f"u{ui}_adv"],
+                                              eps_stack=eps_stack, use_conv=bool(uc), clip_range=clip_range, entropy_coef=entropy_coef)
+            assert abs(loss - float(g[f"u{ui}_e{ep}_loss"])) < 2e-5 * max(1.0, abs(loss))
+            for k, gr in grads.items():
+                want = g[f"u{ui}_e{ep}_grad_{k}"]
+                assert gr.shape == want.shape
+                assert rel_l2(gr, want) < 2e-5, (ui, ep, k, rel_l2(gr, want))
+            total, clipped = so.clip_grad_norm(grads, max_norm)
+            assert abs(total - float(g[f"u{ui}_e{ep}_norm"])) < 2e-5 * max(1.0, total)
+            w_new = so.adamw_step({k: v for k, v in w.items()}, clipped, state, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+            for k in grads:
+                want = g[f"u{ui}_e{ep}_after_{k}"]
+                assert np.abs(w_new[k] - want).max() < 2e-6 + 2e-5 * np.abs(want).max(), (ui, ep, k)
+            np.testing.assert_array_equal(w_new["action_values"], g[f"u{ui}_e{ep}_after_action_values"])   # buffer, not a parameter
+            w = w_new

@@ -150,3 +150,89 @@ def test_collect_rollout_reduced_networks():
     loss = ppo.ppo_loss(cur, out["probs"], ent, out["advantages"])
     want = so.ppo_loss(cur.cpu().numpy(), out["probs"].cpu().numpy(), ent.cpu().numpy(), out["advantages"].cpu().numpy())
     assert abs(float(loss) - float(want)) < 1e-4 * max(1.0, abs(float(want)))
+
+
+def _trainer_from_golden(g, ui):
+    o, sc, uc, K, H, R = [int(v) for v in g[f"u{ui}_cfg"]]
+    net = consolver_amd.FactorNetPPO(hidden_dim=H, num_actions=K, order_dim=o, scaler_dim=sc, use_conv=bool(uc))
+    sd = {k[len(f"u{ui}_w_"):]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith(f"u{ui}_w_")}
+    net.load_state_dict(sd)
+    net.to(DEV)
+    lr, b1, b2, wd, eps, clip_range, entropy_coef, max_norm = [float(v) for v in g[f"u{ui}_hyper"]]
+    tr = ppo.PolicyTrainer(net, lr=lr, betas=(b1, b2), weight_decay=wd, eps=eps, max_grad_norm=max_norm, clip_range=clip_range,
+                           entropy_coef=entropy_coef)
+    conds = {"x": cu(g[f"u{ui}_x"])}
+    if uc:
+        conds["epsilon"] = cu(g[f"u{ui}_eps"])
+    return net, tr, conds, (o, sc, uc, K, H, R)
+
+
+def test_policy_update_matches_reference_autograd_and_adamw(golden):
+    """train_ppo.py:404-437 on the HIP library against the golden vectors produced by the reference's FactorNetPPO under
+    torch autograd, clip_grad_norm_ and torch.optim.AdamW (two epochs on one batch; plain, use_conv, single-row)."""
+    g = golden["sd_ppo_update"]
+    for ui in range(3):
+        net, tr, conds, _ = _trainer_from_golden(g, ui)
+        actions, old, adv = cu(g[f"u{ui}_actions"]), cu(g[f"u{ui}_old_probs"]), cu(g[f"u{ui}_adv"])
+        for ep in range(2):
+            loss = float(tr.compute_grads(conds, actions, old, adv))
+            want_loss = float(g[f"u{ui}_e{ep}_loss"])
+            assert abs(loss - want_loss) < 5e-5 * max(1.0, abs(want_loss)), (ui, ep, loss, want_loss)
+            for k, gv in tr.grad_views().items():
+                want = g[f"u{ui}_e{ep}_grad_{k}"]
+                err = np.linalg.norm(gv.cpu().numpy() - want) / max(np.linalg.norm(want), 1e-12)
+                assert err < 1e-4, (ui, ep, k, err)
+            loss2, norm = tr.step(conds, actions, old, adv)
+            assert abs(float(loss2) - want_loss) < 5e-5 * max(1.0, abs(want_loss))
+            assert abs(float(norm) - float(g[f"u{ui}_e{ep}_norm"])) < 1e-4 * max(1.0, float(norm))
+            for k, v in net.state_dict().items():
+                want = g[f"u{ui}_e{ep}_after_{k}"]
+                assert np.abs(v.cpu().numpy() - want).max() < 3e-6 + 5e-5 * np.abs(want).max(), (ui, ep, k)
+
+
+def test_policy_update_at_rollout_size_vs_oracle(tmp_path):
+    """config-5 size: B = 80 trajectories x (n - 1) = 7 recorded steps, hidden 256, 11 bins; HIP vs the numpy oracle;
+    deterministic; the probabilities the library itself evaluates after the step reflect the in-place update; checkpoint
+    round trip in the reference's format."""
+    torch.manual_seed(0)
+    net = consolver_amd.FactorNetPPO(hidden_dim=256, num_actions=11, order_dim=4, scaler_dim=0)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape) * 0.3 / max(1.0, p.shape[-1] ** 0.5) * 4)
+    net.to(DEV)
+    w = {k: v.cpu().numpy().copy() for k, v in net.state_dict().items()}
+    R, A = 560, 3
+    rng = np.random.default_rng(1)
+    t = rng.integers(1, 999, size=(R, 1)).astype(np.float32)
+    x = np.concatenate([t, np.maximum(t - 125, 0)], 1)
+    idx = rng.integers(0, 11, size=(R, A))
+    actions = np.take_along_axis(np.broadcast_to(w["action_values"], (R, A, 11)), idx[..., None], 2)[..., 0]
+    cur = so.gather_actions(so.factor_net_probs(w, x), w["action_values"], idx)[1]
+    old = np.clip(cur * rng.uniform(0.6, 1.5, (R, A)), 1e-4, 1).astype(np.float32)
+    adv = (rng.normal(0, 10, (R, 1)) * (rng.random((R, A)) > 0.2)).astype(np.float32)
+    tr = ppo.PolicyTrainer(net, lr=1e-4, weight_decay=1e-3)
+    conds = {"x": cu(x)}
+    loss = float(tr.compute_grads(conds, cu(actions), cu(old), cu(adv)))
+    g1 = tr.grads.clone()
+    want_loss, want = so.ppo_policy_grads(w, x, actions, old, adv)
+    assert abs(loss - want_loss) < 5e-5 * max(1.0, abs(want_loss))
+    for k, gv in tr.grad_views().items():
+        err = np.linalg.norm(gv.cpu().numpy() - want[k]) / np.linalg.norm(want[k])
+        assert err < 1e-4, (k, err)
+    tr.compute_grads(conds, cu(actions), cu(old), cu(adv))
+    assert torch.equal(g1, tr.grads)                              # no atomics: bit-identical
+    _, norm = tr.step(conds, cu(actions), cu(old), cu(adv))
+    total, clipped = so.clip_grad_norm(want, 1.0)
+    assert abs(float(norm) - total) < 1e-4 * total
+    w_new = so.adamw_step(w, clipped, {}, lr=1e-4, weight_decay=1e-3)
+    for k, v in net.state_dict().items():
+        assert np.abs(v.cpu().numpy() - w_new[k]).max() < 1e-6 + 2e-5 * np.abs(w_new[k]).max(), k
+    # the library's own forward sees the updated parameters
+    probs = net.forward_(conds).cpu().numpy()
+    np.testing.assert_allclose(probs, so.factor_net_probs(w_new, x), rtol=2e-4, atol=2e-6)
+    d = tr.save_checkpoint(str(tmp_path), 7)
+    assert d.endswith("checkpoint-7") and sorted(torch.load(d + "/model.ckpt").keys()) == sorted(net.state_dict().keys())
+    net2 = consolver_amd.FactorNetPPO(hidden_dim=256, num_actions=11, order_dim=4, scaler_dim=0).to(DEV)
+    ppo.PolicyTrainer(net2).load_checkpoint(d)
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, net.state_dict()[k])
