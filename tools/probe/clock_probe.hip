@@ -1,0 +1,174 @@
+// Diagnostic (not part of the library): what MFMA rate and shader clock does THIS device hold on an LDS-read + MFMA loop
+// shaped like the GEMM / conv main loops (8 wave64 per CU, wave tile 64 x 160, v_mfma_f32_16x16x32_f16, every operand
+// re-read from LDS by ds_read_b128), on random vs zero operands?  MI355X_MICROARCH.md "DVFS give-back": the chip lowers
+// its clock under MFMA load on random data, so the nominal 2.5 PFLOP/s is not reachable by any kernel on such data.
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/clock_probe tools/probe/clock_probe.hip && /tmp/clock_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 2) void probe(const f16* __restrict__ src, int iters, unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 72 KB: [256 + 320 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 576 * 8; i += 512) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(blockIdx.x % 4) * 576 * 64 + i * 8);
+    __syncthreads();
+    f32x4 acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    const char* ta = smem + (wm * 64) * 128; const char* tb = smem + 256 * 128 + (wn * 160) * 128;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            f16x8 fa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// same loop + the GEMM's staging: 9 LDS-DMA pieces (1 KiB each) per wave per k-step into the other 72 KB stage,
+// MODE 0: burst at the top of the k-step + vmcnt(0) + barrier at the end (what gemm_big_kernel does)
+// MODE 1: pieces spread between the MFMA groups, same wait
+// MODE 2: burst, but the wait is vmcnt(9): the stage issued in THIS k-step may still fly at the barrier (needs 3 stages in a real kernel)
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void probe_dma(const f16* __restrict__ src, const f16* __restrict__ stream, long stream_rows, int iters,
+                                                    unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 72 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 2 * 576 * 8; i += 512) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(i % (576 * 8)) * 8);
+    __syncthreads();
+    f32x4 acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    long row = ((long)blockIdx.x * 577 + w * 72 + (lane >> 3)) % stream_rows;
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const char* ta = smem + buf * 73728 + (wm * 64) * 128; const char* tb = smem + buf * 73728 + 256 * 128 + (wn * 160) * 128;
+        char* dst = smem + (buf ^ 1) * 73728 + w * 9 * 1024;
+        auto piece = [&](int j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(stream + (row * 64 + (lane & 7) * 8)), (lptr_t)(dst + j * 1024), 16, 0, 0);
+            row += 8; if (row >= stream_rows) row -= stream_rows;
+        };
+        if (MODE != 1) { for (int j = 0; j < 9; ++j) piece(j); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            f16x8 fa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (MODE == 1) { const int q = ks * 2 + half; piece(2 * q); piece(2 * q + 1); if (q == 3) piece(8); }
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        if (MODE == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int MODE>
+static void run_dma(const f16* d, const f16* stream, long rows, const char* what, unsigned long long* st, float* sink) {
+    const int blocks = 256, iters = 4000;
+    hipFuncSetAttribute((const void*)probe_dma<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe_dma<MODE>, dim3(blocks), dim3(512), 2 * 73728, 0, d, stream, rows, iters, st, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= 12;
+    }
+    std::vector<unsigned long long> s(blocks * 2);
+    hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flops = (double)blocks * iters * 8 * 80 * 16384.0;
+    printf("  + staging, %-46s %.1f TFLOP/s, clock %.3f GHz, cycles per k-step per wave %.0f, DMA %.2f TB/s\n", what, flops / (ms * 1e-3) / 1e12, ghz[blocks / 2],
+           (double)s[0] / iters, (double)blocks * iters * 73728.0 / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+    const int blocks = 256, iters = 20000;
+    const size_t n = 4 * 576 * 64;
+    std::vector<f16> h(n);
+    f16* d; unsigned long long* st; float* sink;
+    hipMalloc(&d, n * sizeof(f16)); hipMalloc(&st, blocks * 2 * sizeof(unsigned long long)); hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void*)probe, hipFuncAttributeMaxDynamicSharedMemorySize, 576 * 128);
+    for (int mode = 0; mode < 2; ++mode) {
+        srand(1);
+        for (size_t i = 0; i < n; ++i) h[i] = mode == 0 ? (f16)((rand() / (float)RAND_MAX - 0.5f) * 0.25f) : (f16)0.f;   // small values: accumulators stay finite
+        hipMemcpy(d, h.data(), n * sizeof(f16), hipMemcpyHostToDevice);
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        for (int rep = 0; rep < 3; ++rep) {              // ~2 s of back-to-back launches before the quoted one
+            hipEventRecord(a);
+            for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe, dim3(blocks), dim3(512), 576 * 128, 0, d, iters, st, sink);
+            hipEventRecord(b); hipEventSynchronize(b);
+        }
+        float ms; hipEventElapsedTime(&ms, a, b); ms /= 12;
+        std::vector<unsigned long long> s(blocks * 2);
+        hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> ghz;
+        for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        const double flops = (double)blocks * iters * 8 * 80 * 16384.0;
+        printf("%s operands: %.1f TFLOP/s (%.1f %% of 2500), median in-kernel clock %.3f GHz, cycles per k-step per wave %.0f (1280 = MFMA-bound)\n",
+               mode == 0 ? "random" : "zero  ", flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 25.0, ghz[blocks / 2],
+               (double)s[0] / iters);
+    }
+    // staging variants on random operands; stream = 16 MB (Infinity-Cache / L2 resident) and 1 GB (HBM) tables of 128-byte rows
+    srand(1);
+    for (size_t i = 0; i < n; ++i) h[i] = (f16)((rand() / (float)RAND_MAX - 0.5f) * 0.25f);
+    hipMemcpy(d, h.data(), n * sizeof(f16), hipMemcpyHostToDevice);
+    for (long mb : {16L, 1024L}) {
+        const long rows = mb * 1024 * 1024 / 128;
+        f16* stream; hipMalloc(&stream, rows * 128);
+        for (long o = 0; o < rows * 64; o += (long)n) hipMemcpy(stream + o, d, std::min((long)n, rows * 64 - o) * sizeof(f16), hipMemcpyDeviceToDevice);
+        printf("stream table %ld MB:\n", mb);
+        run_dma<0>(d, stream, rows, "burst at top, vmcnt(0) + barrier (as shipped):", st, sink);
+        run_dma<1>(d, stream, rows, "pieces spread between MFMA groups, vmcnt(0):", st, sink);
+        run_dma<2>(d, stream, rows, "burst, vmcnt(9): one stage stays in flight:", st, sink);
+        hipFree(stream);
+    }
+    return 0;
+}
