@@ -171,3 +171,31 @@ def test_teacher_pair_dataset_roundtrip(tmp_path):
     with pytest.raises(FileNotFoundError):
         ds[2]
     assert pd.TeacherPairDataset(str(tmp_path))[2][0].startswith("prompt")
+
+
+def test_evaluation_harness_files_pairs_statistics(tmp_path):
+    """gen_ppo.py:318-325 naming, compute_reward.py:52-95 pair finder / loader, :332-365 statistics, :447-462 JSON schema"""
+    import json
+    import torch
+    from consolver_amd import evaluation as ev
+    g = torch.Generator().manual_seed(0)
+    d1, d2 = tmp_path / "ours", tmp_path / "teacher"
+    imgs = {}
+    for i in range(3):
+        img = torch.rand(3, 16, 24, generator=g)
+        png, txt = ev.save_generation(str(d1 / "sub"), 2, i, img, f"prompt {i}")
+        assert os.path.basename(png) == f"2_{i:08d}.png" and open(txt).read() == f"prompt {i}"
+        imgs[i] = img
+        if i < 2:
+            ev.save_generation(str(d2 / "sub"), 2, i, img.flip(-1), "x")
+    back = ev.load_image_tensor(str(d1 / "sub" / "2_00000001.png"), "cpu")
+    assert back.shape == (3, 16, 24) and back.dtype == torch.float32
+    assert torch.equal(back, (imgs[1] * 255).round() / 255)                 # 8-bit quantisation, (x * 255).round()
+    pairs = ev.find_image_pairs(str(d1), str(d2))
+    assert [os.path.basename(a) for a, _ in pairs] == ["2_00000000.png", "2_00000001.png"]      # the unpaired third file is skipped
+    assert all(os.path.relpath(a, d1) == os.path.relpath(b, d2) for a, b in pairs)
+    st = ev.calculate_statistics({"image_psnr": [10.0, 20.0, 40.0], "clip": []})
+    assert st["image_psnr"] == {"mean": 70.0 / 3, "std": float(np.std([10.0, 20.0, 40.0])), "min": 10.0, "max": 40.0, "median": 20.0, "count": 3}
+    assert st["clip"] == {"mean": 0.0, "std": 0.0, "min": 0.0, "max": 0.0, "median": 0.0, "count": 0}
+    out = ev.write_results(str(tmp_path / "r.json"), {"image_psnr": [1.0, 2.0]}, {"dir1": "a", "dir2": "b", "num_pairs": 2})
+    assert sorted(json.load(open(tmp_path / "r.json")).keys()) == ["config", "raw_scores", "statistics"] and out["statistics"]["image_psnr"]["count"] == 2

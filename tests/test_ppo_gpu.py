@@ -236,3 +236,22 @@ def test_policy_update_at_rollout_size_vs_oracle(tmp_path):
     ppo.PolicyTrainer(net2).load_checkpoint(d)
     for k, v in net2.state_dict().items():
         assert torch.equal(v, net.state_dict()[k])
+
+
+def test_score_image_pairs_on_gpu(tmp_path):
+    """compute_reward.py pair scoring reduced to the arithmetic-only reward: PNG files -> GPU PSNR -> statistics JSON"""
+    from consolver_amd import evaluation as ev
+    g = torch.Generator().manual_seed(3)
+    want = []
+    for i in range(5):
+        a = torch.rand(3, 32, 32, generator=g)
+        b = (a + 0.05 * torch.randn(3, 32, 32, generator=g)).clamp(0, 1)
+        ev.save_generation(str(tmp_path / "a"), 0, i, a, "p")
+        ev.save_generation(str(tmp_path / "b"), 0, i, b, "p")
+        qa, qb = (a * 255).round() / 255, (b * 255).round() / 255
+        want.append(float(so.image_psnr_reward(qa[None].numpy(), qb[None].numpy())[0, 0]))
+    pairs = ev.find_image_pairs(str(tmp_path / "a"), str(tmp_path / "b"))
+    res = ev.score_image_pairs(pairs, batch_size=2, device=DEV)
+    np.testing.assert_allclose(res["image_psnr"], want, atol=2e-4)
+    out = ev.write_results(str(tmp_path / "out.json"), res, {"num_pairs": len(pairs)})
+    assert out["statistics"]["image_psnr"]["count"] == 5 and abs(out["statistics"]["image_psnr"]["mean"] - np.mean(want)) < 2e-4

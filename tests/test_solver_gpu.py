@@ -302,3 +302,55 @@ def test_sd_rollout_records_vs_golden(golden):
         assert rel_l2(conds["epsilon"].cpu().numpy(), g[f"r{ri}_conds_eps"]) < 3e-6
         assert rel_l2(lat.cpu().numpy(), g[f"r{ri}_latents"]) < 3e-6
         assert torch.equal(pe_out, pe)
+
+
+def test_ddim_baseline_scheduler_matches_oracle():
+    """order-1 baseline (row f-4): eta = 0 DDIM on PPOScheduler's tables / grid / prev_t rule (scheduler_ppo.py:203,306-332)"""
+    from consolver_amd.baselines import DDIMBaselineScheduler
+    s = DDIMBaselineScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing")
+    ac = so.alphas_cumprod(so.make_betas("scaled_linear", 0.00085, 0.012))
+    rng = np.random.default_rng(0)
+    for n in (1, 4, 8):
+        s.set_timesteps(n, device=DEV)
+        assert s.timesteps.cpu().tolist() == so.sd_timesteps(n, spacing="trailing").tolist()
+        x = rng.standard_normal((3, 4, 8, 8)).astype(np.float32)
+        xg, xo = cu(x), x
+        for t in s.timesteps:
+            e = (0.9 * np.tanh(xo) + 1e-5 * float(t)).astype(np.float32)
+            xg = s.step(cu(e), t, xg, return_dict=False)[0]
+            pt = so.sd_prev_timestep(int(t), n)
+            xo = so.ddim_update(xo, e, ac[int(t)], ac[pt] if pt >= 0 else ac[0])
+            assert rel_l2(xg.cpu().numpy(), xo) < 1e-6
+    # fused CFG form and fp16 I/O
+    s.set_timesteps(4, device=DEV)
+    u, c = rng.standard_normal(x.shape).astype(np.float32), rng.standard_normal(x.shape).astype(np.float32)
+    t = int(s.timesteps[0])
+    got = s.step(cu(c), s.timesteps[0], cu(x), eps_uncond=cu(u), guidance_scale=3.0, return_dict=True).prev_sample
+    want = so.ddim_update(x, so.cfg_combine(u, c, 3.0), ac[t], ac[so.sd_prev_timestep(t, 4)])
+    assert rel_l2(got.cpu().numpy(), want) < 1e-6
+    got16 = s.step(cu(c, torch.float16), s.timesteps[0], cu(x, torch.float16), return_dict=False)[0]
+    assert got16.dtype == torch.float16
+    want16 = so.ddim_update(so.round_f16(x), so.round_f16(c), ac[t], ac[so.sd_prev_timestep(t, 4)])
+    assert rel_l2(got16.float().cpu().numpy(), want16) < 1e-3
+
+
+def test_flow_match_euler_baseline_matches_oracle():
+    """edit_ppo/scheduler_fm.py:405-410 (type == 'euler') on FMPPOScheduler's sigma schedule"""
+    from consolver_amd.baselines import FlowMatchEulerBaselineScheduler
+    s = FlowMatchEulerBaselineScheduler(shift=3.0, use_dynamic_shifting=True)
+    n = 6
+    sig = np.linspace(1.0, 1.0 / n, n)
+    s.set_timesteps(sigmas=sig, mu=1.15, device=DEV)
+    ref = consolver_amd.FMPPOScheduler(shift=3.0, use_dynamic_shifting=True, order_dim=2, scaler_dim=0, mu_dim=0,
+                                       factor_net_kwargs=dict(hidden_dim=4, num_actions=3))
+    ref.set_timesteps(sigmas=sig, mu=1.15, device=DEV)
+    assert torch.equal(s.sigmas, ref.sigmas) and torch.equal(s.timesteps, ref.timesteps)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 16, 64)).astype(np.float32)
+    xg, xo = cu(x), x
+    sg = s.sigmas.cpu().numpy()
+    for i, t in enumerate(s.timesteps):
+        v = (0.7 * np.tanh(xo) - 0.1).astype(np.float32)
+        xg = s.step(cu(v), t, xg, return_dict=False)[0]
+        xo = (xo + np.float32(sg[i + 1] - sg[i]) * v).astype(np.float32)
+        assert rel_l2(xg.cpu().numpy(), xo) < 1e-6
