@@ -50,6 +50,11 @@ class CsVaeConfig(C.Structure):
                 ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int)]
 
 
+class CsClipConfig(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
+                ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("layer_norm_eps", C.c_float)]
+
+
 # every symbol declared in include/consolver_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "cs_abi_version": (C.c_int, []),
@@ -78,6 +83,15 @@ SYMBOLS = {
     "cs_clip_grad_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "cs_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_void_p]),
+    "cs_clip_create": (C.c_int, [C.POINTER(CsClipConfig), C.POINTER(C.c_void_p)]),
+    "cs_clip_destroy": (None, [C.c_void_p]),
+    "cs_clip_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "cs_clip_num_weights": (C.c_int, [C.c_void_p]),
+    "cs_clip_weight_name": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "cs_clip_finalize": (C.c_int, [C.c_void_p]),
+    "cs_clip_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "cs_clip_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "cs_clip_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cs_vae_create": (C.c_int, [C.POINTER(CsVaeConfig), C.POINTER(C.c_void_p)]),
     "cs_vae_destroy": (None, [C.c_void_p]),
     "cs_vae_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
@@ -115,6 +129,8 @@ SYMBOLS = {
     # include/consolver_hip_ops.h
     "cs_op_gemm2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
                               C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "cs_op_attention_causal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "cs_op_attention_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "cs_op_conv2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

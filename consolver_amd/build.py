@@ -27,6 +27,7 @@ SOURCES = {
     "flux.cpp": [],
     "unet.cpp": [],
     "vae.cpp": [],
+    "clip.cpp": [],
     "ppo.hip": [],
     "ops_api.cpp": [],
 }

@@ -1,4 +1,4 @@
-// Fused (flash-style) attention forward for the SD1.5 head sizes 40 / 80 / 160 on gfx950.
+// Fused (flash-style) attention forward for the SD1.5 head sizes 40 / 80 / 160 (+ 128 FLUX, + 64 causal CLIP) on gfx950.
 //
 //   out[b, q, h, :] = softmax(scale * Q K^T) V        (no mask; self and cross attention)
 //
@@ -52,7 +52,7 @@ __device__ __forceinline__ float xor32_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int DH, int QT>
+template <typename T, int DH, int QT, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     typedef typename El<T>::frag frag;
     constexpr int DK = (DH + 31) / 32 * 32;
@@ -197,6 +197,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                     s[kt][t] = El<T>::mfma(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t]);
             }
         }
+        if (CAUSAL) {   // text-encoder attention: key j is visible to query i iff j <= i (Nq == Nk)
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int qi = q0 + t * 16 + i16;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (tile * 64 + kt * 16 + 4 * g + r > qi) s[kt][t][r] = -INFINITY;
+            }
+        }
         if (RAGGED) {   // ragged last tile: mask keys >= Nk (compiled only into the peeled last iteration)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -313,13 +324,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <typename T, int DH, int QT>
+template <typename T, int DH, int QT, bool CAUSAL = false>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
     constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
     constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
-    auto kfn = attn_kernel<T, DH, QT>;
+    auto kfn = attn_kernel<T, DH, QT, CAUSAL>;
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -343,6 +354,10 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     p.q_stride = a.q_stride; p.k_stride = a.k_stride; p.v_stride = a.v_stride; p.out_stride = a.out_stride;
     p.H = a.H; p.Nq = a.Nq; p.Nk = a.Nk;
     p.c = a.scale * 1.4426950408889634f;
+    if (a.causal) {
+        if (a.dh != 64 || a.dtype == CS_BF16 || a.Nq != a.Nk) CS_FAIL(CS_E_UNSUPPORTED, "attention: the causal form is built for f16, head dim 64, Nq == Nk");
+        return launch_attn<f16, 64, 2, true>(p, a.B, s);
+    }
     switch (a.dh) {
         case 40: {
             static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 4;   // tuning knob

@@ -179,6 +179,31 @@ __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restri
     }
 }
 
+
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ ids, const f16* __restrict__ tok, const f16* __restrict__ pos, f16* __restrict__ out,
+                                    long rows, int L, int C, int vocab) {
+    const int CV = C >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * CV) return;
+    const long r = i / CV; const int cv = (int)(i - r * CV);
+    long id = ids[r]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f16x8 a = *reinterpret_cast<const f16x8*>(tok + id * C + cv * 8);
+    const f16x8 b = *reinterpret_cast<const f16x8*>(pos + (r % L) * C + cv * 8);
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)((float)a[k] + (float)b[k]);
+    *reinterpret_cast<f16x8*>(out + r * C + cv * 8) = o;
+}
+
+__global__ void quick_gelu_kernel(f16* __restrict__ x, long nv) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    f16x8 v = *reinterpret_cast<f16x8*>(x + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; v[k] = (f16)(f / (1.0f + __expf(-1.702f * f))); }
+    *reinterpret_cast<f16x8*>(x + i * 8) = v;
+}
+
 __global__ void pixel_linear_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
                                     int B, int C, int HW, float in_scale, float in_shift) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,6 +330,25 @@ int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, co
     if (B <= 0) return CS_OK;
     const long M = (long)B * H * W;
     hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_embed_tokens(const int64_t* ids, const f16* tok, const f16* pos, f16* out, long rows, int L, int C, int vocab, hipStream_t s) {
+    if (!ids || !tok || !pos || !out) CS_FAIL(CS_E_ARG, "embed_tokens: null pointer");
+    if (C % 8 || L <= 0 || vocab <= 0) CS_FAIL(CS_E_SHAPE, "embed_tokens: bad dims");
+    if (rows <= 0) return CS_OK;
+    const long n = rows * (C / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, tok, pos, out, rows, L, C, vocab);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_quick_gelu(f16* x, long n, hipStream_t s) {
+    if (!x) CS_FAIL(CS_E_ARG, "quick_gelu: null pointer");
+    if (n % 8) CS_FAIL(CS_E_SHAPE, "quick_gelu: element count must be a multiple of 8");
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, x, n / 8);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -31,6 +31,7 @@ struct AttnArgs {
     int B, H, Nq, Nk, dh;
     float scale;
     int dtype;               // CS_F16 (default 0 is treated as f16) or CS_BF16
+    int causal;              // 1: key j visible to query i iff j <= i (CLIP text encoder; f16, dh 64, Nq == Nk)
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -95,3 +96,9 @@ int launch_pixel_linear_nchw(const f16* x, const f16* w, const f16* b, f16* out,
 int launch_row_softmax(f16* x, long rows, int cols, float scale, hipStream_t s);
 // conv 3x3 to 3 output channels, NHWC in -> NCHW out, optional (y/2+0.5).clamp(0,1)
 int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s);
+
+// ---- CLIP text encoder helpers -------------------------------------------------------------------------------
+// out[r][:] = tok[ids[r]][:] + pos[r % L][:]   (ids int64, tables fp16)
+int launch_embed_tokens(const int64_t* ids, const f16* tok, const f16* pos, f16* out, long rows, int L, int C, int vocab, hipStream_t s);
+// x <- x * sigmoid(1.702 x) in place (quick_gelu)
+int launch_quick_gelu(f16* x, long n, hipStream_t s);

@@ -75,6 +75,14 @@ int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride,
     return launch_attention(a, (hipStream_t)stream);
 }
 
+int cs_op_attention_causal(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                           int B, int H, int N, int dh, float scale, void* stream) {
+    AttnArgs a{};
+    a.q = (const f16*)q; a.q_stride = q_stride; a.k = (const f16*)k; a.k_stride = k_stride; a.v = (const f16*)v; a.v_stride = v_stride;
+    a.out = (f16*)out; a.out_stride = out_stride; a.B = B; a.H = H; a.Nq = N; a.Nk = N; a.dh = dh; a.scale = scale; a.causal = 1;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 size_t cs_op_group_norm_workspace(int B, int C) { return (size_t)B * (GN_SPLITS + 1) * C * 2 * sizeof(float); }
 
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,

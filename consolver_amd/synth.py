@@ -28,6 +28,23 @@ def synthetic_vae_state_dict(manifest, seed=20251227):
     return synthetic_unet_state_dict(manifest, seed)
 
 
+def synthetic_clip_state_dict(manifest, seed=20251228):
+    """CLIP text tower: embeddings ~ N(0, 0.02^2)-like scale kept O(1) after the first LayerNorm, linears ~ N(0, 1/fan_in)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in manifest:
+        if "embedding" in name:
+            w = 0.5 * torch.randn(shape, generator=g)
+        elif name.endswith(".weight") and len(shape) == 2:
+            w = torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5
+        elif "layer_norm" in name and name.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            w = 0.05 * torch.randn(shape, generator=g)
+        sd[name] = w
+    return sd
+
+
 def synthetic_prompt_embeds(batch, ctx_len=77, dim=768, seed=1001):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(batch, ctx_len, dim, generator=g)

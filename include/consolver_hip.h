@@ -293,6 +293,37 @@ int cs_clip_grad_norm(float* grads, int64_t n, float max_norm, float* total_norm
 int cs_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------
+ * CLIP text encoder (prompt front-end): replaces `text_encoder(input_ids)[0]`
+ * (denoise_ppo.py:25-50; third-party transformers CLIPTextModel).
+ * ---------------------------------------------------------------------- */
+typedef struct CsClipConfig {
+    int vocab_size;                /* 49408 */
+    int hidden_size;               /* 768   */
+    int intermediate_size;         /* 3072  */
+    int num_hidden_layers;         /* 12    */
+    int num_attention_heads;       /* 12 (head dim 64) */
+    int max_position_embeddings;   /* 77    */
+    float layer_norm_eps;          /* 1e-5  */
+} CsClipConfig;
+
+typedef struct CsClip CsClip;
+
+int cs_clip_create(const CsClipConfig* cfg, CsClip** out);
+void cs_clip_destroy(CsClip* c);
+/* tensors by their transformers CLIPTextModel names without the "text_model." prefix
+ * ("embeddings.token_embedding.weight", "encoder.layers.0.self_attn.q_proj.weight", ...); fp32 host memory */
+int cs_clip_set_weight(CsClip* c, const char* name, const float* data_host, const int64_t* shape, int ndim);
+int cs_clip_num_weights(const CsClip* c);
+const char* cs_clip_weight_name(const CsClip* c, int i, int64_t* shape4, int* ndim);
+int cs_clip_finalize(CsClip* c);
+size_t cs_clip_workspace_bytes(const CsClip* c, int batch, int seq_len);
+double cs_clip_flops(const CsClip* c, int batch, int seq_len);
+/* input_ids: [batch, seq_len] int64 (device).  out: last_hidden_state [batch, seq_len, hidden] fp16
+ * (after final_layer_norm), i.e. element [0] of the reference's text_encoder(...) output. */
+int cs_clip_encode(CsClip* c, const int64_t* input_ids, int batch, int seq_len, void* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,10 @@ int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, in
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream);
 
+/* causal form (key j visible to query i iff j <= i): f16, head dim 64, Nq == Nk = N (CLIP text encoder) */
+int cs_op_attention_causal(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                           int B, int H, int N, int dh, float scale, void* stream);
+
 /* kernel-selection knobs (tests / tuning): "conv_halo" = 0 never, 1 auto (default), 2 whenever the shape allows */
 int cs_set_tuning(const char* key, int value);
 

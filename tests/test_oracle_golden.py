@@ -246,3 +246,20 @@ def test_ppo_policy_update_vs_reference_autograd(golden):
                 assert np.abs(w_new[k] - want).max() < 2e-6 + 2e-5 * np.abs(want).max(), (ui, ep, k)
             np.testing.assert_array_equal(w_new["action_values"], g[f"u{ui}_e{ep}_after_action_values"])   # buffer, not a parameter
             w = w_new
+
+
+def test_clip_text_oracle_vs_transformers(golden):
+    """oracle/clip_oracle.py against the installed third-party transformers.CLIPTextModel (reduced config, seeded weights)"""
+    import torch
+    from oracle.clip_oracle import ClipTextOracle, clip_manifest
+    g = golden["clip_text"]
+    V, D, I, NL, H, P = [int(v) for v in g["cfg"]]
+    cfg = dict(vocab_size=V, hidden_size=D, intermediate_size=I, num_hidden_layers=NL, num_attention_heads=H, max_position_embeddings=P)
+    sd = {k[2:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("w_")}
+    assert sorted(sd.keys()) == sorted(n for n, _ in clip_manifest(cfg))
+    for n, shape in clip_manifest(cfg):
+        assert tuple(sd[n].shape) == shape
+    orc = ClipTextOracle(sd, cfg, round_weights_to_f16=False)
+    for name in ("full", "short"):
+        out = orc(torch.from_numpy(np.asarray(g[f"{name}_ids"])))[0].numpy()
+        assert rel_l2(out, g[f"{name}_out"]) < 2e-6
