@@ -128,6 +128,166 @@ static void run_dma(const f16* d, const f16* stream, long rows, const char* what
            (double)s[0] / iters, (double)blocks * iters * 73728.0 / (ms * 1e-3) / 1e12);
 }
 
+// MODE 3 experiment: the ACTIVATION operand is not staged at all: every wave loads its own 64-row A fragments straight from
+// global memory (fragment-shaped global_load_dwordx4: 16 rows x 64 B per instruction), only the weight tile (40 KB per k-step)
+// goes through LDS-DMA.  LDS traffic per k-step drops from 224 KB read + 72 KB written to 160 + 40.
+__global__ __launch_bounds__(512, 2) void probe_direct_a(const f16* __restrict__ src, const f16* __restrict__ stream, long stream_rows, int iters,
+                                                         unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 40 KB (weights only)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 2 * 320 * 8; i += 512) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(i % (320 * 8)) * 8);
+    __syncthreads();
+    f32x4 acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    long row = ((long)blockIdx.x * 577 + w * 40 + (lane >> 3)) % stream_rows;
+    long arow = ((long)blockIdx.x * 256 + wm * 64 + (lane & 15)) % (stream_rows - 64);     // this wave's 64 activation rows (pixels)
+    long acol = 0;                                                                            // k offset inside the 128-B row... rows are 64 halfs: walk rows instead
+    f16x8 fa[2][4], fan[2][4];
+    auto load_a = [&](f16x8 (&dst)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[ks][j] = *reinterpret_cast<const f16x8*>(stream + ((arow + j * 16) * 64 + ks * 32 + (lane >> 4) * 8));
+        arow += 256 * 256; if (arow >= stream_rows - 64) arow -= (stream_rows - 64);
+    };
+    load_a(fa);
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const char* tb = smem + buf * 40960 + (wn * 160) * 128;
+        char* dst = smem + (buf ^ 1) * 40960 + w * 5 * 1024;
+        for (int j = 0; j < 5; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(stream + (row * 64 + (lane & 7) * 8)), (lptr_t)(dst + j * 1024), 16, 0, 0);
+            row += 8; if (row >= stream_rows) row -= stream_rows;
+        }
+        load_a(fan);                                   // next k-step's activations, in flight during this k-step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[ks][j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[ks][j] = fan[ks][j];
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+    (void)acol;
+}
+
+static void run_direct(const f16* d, const f16* stream, long rows, unsigned long long* st, float* sink) {
+    const int blocks = 256, iters = 4000;
+    hipFuncSetAttribute((const void*)probe_direct_a, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 40960);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe_direct_a, dim3(blocks), dim3(512), 2 * 40960, 0, d, stream, rows, iters, st, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= 12;
+    }
+    std::vector<unsigned long long> s(blocks * 2);
+    hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flops = (double)blocks * iters * 8 * 80 * 16384.0;
+    printf("  A fragments straight from global, weights by LDS-DMA:       %.1f TFLOP/s, clock %.3f GHz, cycles per k-step per wave %.0f\n", flops / (ms * 1e-3) / 1e12,
+           ghz[blocks / 2], (double)s[0] / iters);
+}
+
+// MODE 4 experiment: the same 256 x 320 x 64 tile on FOUR waves (one per SIMD, 512 registers each): wave tile 128 x 160, so the
+// LDS fragment reads per k-step drop from 224 KB (8 waves x 28 KB) to 144 KB (4 x 36 KB); 18 DMA pieces per wave per k-step.
+template <int SPREAD>
+__global__ __launch_bounds__(256, 1) void probe_4wave(const f16* __restrict__ src, const f16* __restrict__ stream, long stream_rows, int iters,
+                                                      unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 72 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 2 * 576 * 8; i += 256) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(i % (576 * 8)) * 8);
+    __syncthreads();
+    f32x4 acc[10][8];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    long row = ((long)blockIdx.x * 577 + w * 144 + (lane >> 3)) % stream_rows;
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const char* ta = smem + buf * 73728 + (wm * 128) * 128; const char* tb = smem + buf * 73728 + 256 * 128 + (wn * 160) * 128;
+        char* dst = smem + (buf ^ 1) * 73728 + w * 18 * 1024;
+        auto piece = [&](int j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(stream + (row * 64 + (lane & 7) * 8)), (lptr_t)(dst + j * 1024), 16, 0, 0);
+            row += 8; if (row >= stream_rows) row -= stream_rows;
+        };
+        if (!SPREAD) { for (int j = 0; j < 18; ++j) piece(j); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            f16x8 fa[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (SPREAD) { const int q = ks * 2 + half; for (int j = 0; j < 4; ++j) piece(4 * q + j); if (q == 3) { piece(16); piece(17); } }
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int SPREAD>
+static void run_4wave(const f16* d, const f16* stream, long rows, unsigned long long* st, float* sink) {
+    const int blocks = 256, iters = 4000;
+    hipFuncSetAttribute((const void*)probe_4wave<SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe_4wave<SPREAD>, dim3(blocks), dim3(256), 2 * 73728, 0, d, stream, rows, iters, st, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= 12;
+    }
+    std::vector<unsigned long long> s(blocks * 2);
+    hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flops = (double)blocks * iters * 8 * 80 * 16384.0;
+    printf("  4 waves x (128 x 160), %s:                    %.1f TFLOP/s, clock %.3f GHz, cycles per k-step %.0f (2560 = MFMA-bound)\n", SPREAD ? "pieces spread" : "burst        ",
+           flops / (ms * 1e-3) / 1e12, ghz[blocks / 2], (double)s[0] / iters);
+}
+
 int main() {
     const int blocks = 256, iters = 20000;
     const size_t n = 4 * 576 * 64;
@@ -168,6 +328,9 @@ int main() {
         run_dma<0>(d, stream, rows, "burst at top, vmcnt(0) + barrier (as shipped):", st, sink);
         run_dma<1>(d, stream, rows, "pieces spread between MFMA groups, vmcnt(0):", st, sink);
         run_dma<2>(d, stream, rows, "burst, vmcnt(9): one stage stays in flight:", st, sink);
+        run_direct(d, stream, rows, st, sink);
+        run_4wave<0>(d, stream, rows, st, sink);
+        run_4wave<1>(d, stream, rows, st, sink);
         hipFree(stream);
     }
     return 0;
