@@ -92,17 +92,23 @@ struct LinearRows {
     __device__ __forceinline__ int operator()(int row) const { const int m = m_base + row; return m < M ? m : -1; }
 };
 
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap>
+// RSPLIT > 1 trades column groups for row groups: the patch holds 64 / RSPLIT rows x ALL the wave's columns, so a pass stores
+// 320-byte (not 160-byte) row segments: whole 128-byte lines instead of halves of them.
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
+    static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
+    constexpr int RT = MT / RSPLIT;                           // 16-row tiles per pass
     constexpr int COLS = GEGLU ? GROUP * 8 : GROUP * 16;      // output columns per pass
     constexpr int ROWB = (COLS + 8) * 2;                      // padded LDS row (bytes, multiple of 16)
     constexpr int CH = COLS / 8;                              // 16-byte chunks per row
     const int g4 = (lane >> 4) * 4, i16 = lane & 15;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
 #pragma unroll
-    for (int grp = 0; grp < NT / GROUP; ++grp) {
-        // ---- phase 1: registers -> LDS patch [64 rows][COLS] fp16 ----------------------------------------
+    for (int grp = 0; grp < NT / GROUP; ++grp)
+#pragma unroll
+    for (int rh = 0; rh < RSPLIT; ++rh) {
+        // ---- phase 1: registers -> LDS patch [RT * 16 rows][COLS] fp16 -----------------------------------
 #pragma unroll
         for (int ii = 0; ii < GROUP; ii += (GEGLU ? 2 : 1)) {
             const int i = grp * GROUP + ii;
@@ -119,7 +125,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                 }
             }
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
+            for (int jj = 0; jj < RT; ++jj) {
+                const int j = rh * RT + jj;
                 f16x4 o;
                 if (GEGLU) {
                     const f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
@@ -131,16 +138,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                     for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] + bv[r]);
                 }
                 const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
-                *reinterpret_cast<f16x4*>(wave_lds + (j * 16 + i16) * ROWB + col * 2) = o;
+                *reinterpret_cast<f16x4*>(wave_lds + (jj * 16 + i16) * ROWB + col * 2) = o;
             }
         }
         // ---- phase 2: LDS patch -> global, 16 bytes per lane, + temb + residual ------------------------------
         const int n0 = GEGLU ? ((n_base + grp * GROUP * 16) >> 1) : n_base + grp * GROUP * 16;
+        static_assert((RT * 16 * CH) % 64 == 0, "patch items must fill whole wave passes");
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
+        for (int k = 0; k < RT * 16 * CH / 64; ++k) {
             const int idx = lane + 64 * k;
             const int row = idx / CH, ch = idx - row * CH;
-            const int m = rows(row);
+            const int m = rows(rh * RT * 16 + row);
             const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
             if (m >= 0) {
                 const size_t off = (size_t)m * Nout + n0 + ch * 8;
@@ -524,7 +532,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         __syncthreads();
     }
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
-    igemm_epilogue<GEGLU, NT, MT, (GEGLU ? 10 : 5)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
+    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, 10>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
+    else igemm_epilogue<GEGLU, NT, MT, 10, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
