@@ -173,9 +173,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     // fp16 P values; exactness is unaffected because P and the denominator share the same reference), which
     // is a rare, wave-uniform slow path: the steady state is max3 / v_exp / cvt only.
     constexpr float THR = 8.0f;
-    auto do_tile = [&](int tile, auto ragged_tag, auto first_tag) {
+    auto do_tile = [&](int tile, auto ragged_tag, auto first_tag, auto fast_tag) {
         constexpr bool RAGGED = decltype(ragged_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;       // no per-tile maxima after the first tile (see the driver below)
         const int buf = tile & 1;
         if (tile + 1 < ntiles) load_tile(tile + 1);
         const char* tk = lK + buf * KBUF;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         }
 
         // ---- per-lane tile maxima; move the reference only when needed (wave-uniform decision) ---------
+        if (FIRST || !FAST) {
         float mxl[QT];
         bool over = false;
 #pragma unroll
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[kt][t][r] -= delta;
             }
+        }
         }
 
         // ---- P = exp2(S') -> fp16 fragments of the second product ------------------------------------------
@@ -292,10 +295,39 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         __syncthreads();
     };
     const int full_tiles = p.Nk / 64;
-    if (full_tiles > 0) do_tile(0, std::false_type{}, std::true_type{});
-    else do_tile(0, std::true_type{}, std::true_type{});
-    for (int tile = 1; tile < full_tiles; ++tile) do_tile(tile, std::false_type{}, std::false_type{});
-    if (full_tiles > 0 && full_tiles < ntiles) do_tile(full_tiles, std::true_type{}, std::false_type{});
+    auto run_tiles = [&](auto fast_tag) {
+        if (full_tiles > 0) do_tile(0, std::false_type{}, std::true_type{}, fast_tag);
+        else do_tile(0, std::true_type{}, std::true_type{}, fast_tag);
+        for (int tile = 1; tile < full_tiles; ++tile) do_tile(tile, std::false_type{}, std::false_type{}, fast_tag);
+        if (full_tiles > 0 && full_tiles < ntiles) do_tile(full_tiles, std::true_type{}, std::false_type{}, fast_tag);
+    };
+    // Head dim 40 is issue-bound on the softmax VALU work (64 v_exp + 58 v_max per 56 MFMAs per tile), so its steady state drops
+    // the maxima: every tile is exponentiated against the FIRST tile's column maximum.  That is exact as long as no later score
+    // exceeds it by 2^16 (the fp16 range of P); if one does, P holds an inf, the ones-column denominator comes out non-finite,
+    // and the whole workgroup redoes its rows with the maxima-tracking loop (block-uniform decision, never seen on real inputs).
+    if constexpr (ONES) {
+        run_tiles(std::true_type{});
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float l = __shfl(o_acc[DH / 16][t][(DH % 16) % 4], ((DH % 16) / 4) * 16 + i16, 64);
+            bad |= !(l < INFINITY);                      // inf or NaN
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) {
+#pragma unroll
+            for (int a = 0; a < DVT; ++a)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o_acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < QT; ++t) { m_run[t] = 0.f; l_run[t] = 0.f; }
+            load_tile(0);
+            store_tile(0);
+            __syncthreads();
+            run_tiles(std::false_type{});
+        }
+    } else {
+        run_tiles(std::false_type{});
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------
 #pragma unroll

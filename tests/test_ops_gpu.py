@@ -242,3 +242,19 @@ def test_ops_are_deterministic():
     assert torch.equal(ops.linear(x, w), ops.linear(x, w))
     q = rnd(1, 512, 320, seed=3)
     assert torch.equal(ops.attention(q, q, q, 8), ops.attention(q, q, q, 8))
+
+
+@pytest.mark.parametrize("Nq,Nk,pos", [(256, 256, 200), (128, 77, 70), (64, 4096, 3000)])
+def test_attention_dh40_outlier_key_takes_the_safe_path(Nq, Nk, pos):
+    """head dim 40 exponentiates later tiles against the first tile's maximum; a key whose score exceeds it by more than the fp16
+    range of P (2^16) must trigger the maxima-tracking redo, not produce inf/NaN"""
+    B, H, dh = 2, 8, 40
+    q, k, v = rnd(B, Nq, H * dh, seed=1), rnd(B, Nk, H * dh, seed=2), rnd(B, Nk, H * dh, seed=3)
+    k = k.clone()
+    k[:, pos] = 6.0 * q[:, 5]                                  # score ~ 36 |q|^2 dh^-0.5 log2e >> 16 above the first tile for query 5
+    out = ops.attention(q, k, v, H)
+    qf, kf, vf = (t.float().view(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * dh ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, Nq, H * dh)
+    assert torch.isfinite(out).all()
+    assert rel_l2(out.float(), ref) < 2e-3
+    assert float((out.float() - ref).abs().max()) < 1e-2

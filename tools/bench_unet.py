@@ -10,8 +10,9 @@ for kv in os.environ.get("CS_TUNE", "").split(","):
     if "=" in kv:
         k, v = kv.split("="); ops.set_tuning(k, int(v))
 u = HipUNet2DConditionModel(device=dev); u.load_state_dict(synthetic_unet_state_dict(u.manifest()))
-lat = torch.randn(16, 4, 64, 64, device=dev).half()
-ctx = synthetic_prompt_embeds(32).half().to(dev)
+NL = int(os.environ.get("CS_NLAT", "16"))
+lat = torch.randn(NL, 4, 64, 64, device=dev).half()
+ctx = synthetic_prompt_embeds(2 * NL).half().to(dev)
 t = torch.tensor([499.0], device=dev)
 for _ in range(3): u(lat, t, encoder_hidden_states=ctx, dup=2)
 torch.cuda.synchronize()
@@ -21,6 +22,6 @@ a.record()
 for _ in range(n): u(lat, t, encoder_hidden_states=ctx, dup=2, reuse_kv=True)
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / n
-print(f"forward {ms:.3f} ms  {u.flops(32) / ms / 1e9:.1f} TFLOP/s  ({u.flops(32) / ms / 1e9 / 2500 * 100:.1f} % of fp16 MFMA peak)")
+print(f"forward {ms:.3f} ms  {u.flops(2 * NL) / ms / 1e9:.1f} TFLOP/s  ({u.flops(2 * NL) / ms / 1e9 / 2500 * 100:.1f} % of fp16 MFMA peak)")
 u.set_profiling(True); u(lat, t, encoder_hidden_states=ctx, dup=2, reuse_kv=True); pr = u.profile(); u.set_profiling(False)
 print("  ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()))
