@@ -328,6 +328,11 @@ int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, co
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out: null pointer");
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
+    if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
+        hipLaunchKernelGGL(conv_out_patch_kernel<4>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
     const long M = (long)B * H * W;
     hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0);
     CS_CHECK_LAUNCH();
