@@ -47,7 +47,7 @@ class CsUNetConfig(C.Structure):
 
 class CsVaeConfig(C.Structure):
     _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
-                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int)]
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int), ("use_post_quant_conv", C.c_int)]
 
 
 class CsClipConfig(C.Structure):

@@ -204,6 +204,67 @@ __global__ void quick_gelu_kernel(f16* __restrict__ x, long nv) {
     *reinterpret_cast<f16x8*>(x + i * 8) = v;
 }
 
+// VAE latents with more than 4 channels (FLUX: 16): z = x * scale + shift [-> post_quant 1x1], written NHWC with the channel
+// axis zero-padded to 64 so that conv_in runs through the implicit-GEMM kernel (K = 9 x 64)
+__global__ void latent_to_nhwc64_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
+                                        int B, int C, int HW, float in_scale, float in_shift) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int bi = (int)(i / HW), px = (int)(i - (long)bi * HW);
+    float z[64];
+    for (int c = 0; c < C; ++c) z[c] = (float)x[((size_t)bi * C + c) * HW + px] * in_scale + in_shift;
+    f16* o = out + (size_t)i * 64;
+    for (int oc = 0; oc < 64; oc += 8) {
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 8 && oc + k < C; ++k) {
+            float a;
+            if (w) { a = (float)b[oc + k]; for (int c = 0; c < C; ++c) a += (float)w[(oc + k) * C + c] * z[c]; }
+            else a = z[oc + k];
+            v[k] = (f16)a;
+        }
+        *reinterpret_cast<f16x8*>(o + oc) = v;
+    }
+}
+
+// softmax(scale * x) over long rows (8192 < cols <= 65536): one workgroup per row, two passes over the row in L2
+__global__ __launch_bounds__(256) void row_softmax_block_kernel(f16* __restrict__ x, int cols, float scale) {
+    __shared__ float red[4];
+    __shared__ float bc[2];
+    f16* p = x + (size_t)blockIdx.x * cols;
+    const int CV = cols >> 3;
+    float mx = -INFINITY;
+    for (int cv = threadIdx.x; cv < CV; cv += 256) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(p + cv * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, (float)t[k]);
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) bc[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+    __syncthreads();
+    const float m = bc[0];
+    float sum = 0.f;
+    for (int cv = threadIdx.x; cv < CV; cv += 256) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(p + cv * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += __expf((float)t[k] * scale - m);
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) bc[1] = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    const float inv = bc[1];
+    for (int cv = threadIdx.x; cv < CV; cv += 256) {
+        f16x8 t = *reinterpret_cast<const f16x8*>(p + cv * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (f16)(__expf((float)t[k] * scale - m) * inv);
+        *reinterpret_cast<f16x8*>(p + cv * 8) = t;
+    }
+}
+
 __global__ void pixel_linear_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
                                     int B, int C, int HW, float in_scale, float in_shift) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,8 +330,13 @@ int launch_pixel_linear_nchw(const f16* x, const f16* w, const f16* b, f16* out,
 
 int launch_row_softmax(f16* x, long rows, int cols, float scale, hipStream_t s) {
     if (!x) CS_FAIL(CS_E_ARG, "row_softmax: null pointer");
-    if (cols % 8 || cols > 8192) CS_FAIL(CS_E_SHAPE, "row_softmax: cols=%d unsupported", cols);
+    if (cols % 8 || cols > 65536) CS_FAIL(CS_E_SHAPE, "row_softmax: cols=%d unsupported", cols);
     if (rows <= 0) return CS_OK;
+    if (cols > 8192) {
+        hipLaunchKernelGGL(row_softmax_block_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, cols, scale);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
     hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, cols, scale);
     CS_CHECK_LAUNCH();
     return CS_OK;
@@ -354,6 +420,16 @@ int launch_quick_gelu(f16* x, long n, hipStream_t s) {
     if (n % 8) CS_FAIL(CS_E_SHAPE, "quick_gelu: element count must be a multiple of 8");
     if (n <= 0) return CS_OK;
     hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, x, n / 8);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_latent_to_nhwc64(const f16* x, const f16* w, const f16* b, f16* out, int B, int C, int HW, float in_scale, float in_shift, hipStream_t s) {
+    if (!x || !out || (w && !b)) CS_FAIL(CS_E_ARG, "latent_to_nhwc64: null pointer");
+    if (C < 1 || C > 64) CS_FAIL(CS_E_SHAPE, "latent_to_nhwc64: %d channels unsupported", C);
+    const long n = (long)B * HW;
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(latent_to_nhwc64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, out, B, C, HW, in_scale, in_shift);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

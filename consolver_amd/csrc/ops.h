@@ -102,3 +102,5 @@ int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, c
 int launch_embed_tokens(const int64_t* ids, const f16* tok, const f16* pos, f16* out, long rows, int L, int C, int vocab, hipStream_t s);
 // x <- x * sigmoid(1.702 x) in place (quick_gelu)
 int launch_quick_gelu(f16* x, long n, hipStream_t s);
+// latents with up to 64 channels: z = x * scale + shift [-> 1x1 post_quant when w != null], NHWC with channels zero-padded to 64
+int launch_latent_to_nhwc64(const f16* x, const f16* w, const f16* b, f16* out, int B, int C, int HW, float in_scale, float in_shift, hipStream_t s);

@@ -70,7 +70,7 @@ void expect_resnet(CsVae* v, const std::string& p, int cin, int cout) {
 void build_manifest(CsVae* v) {
     const CsVaeConfig& c = v->cfg;
     const int L = c.latent_channels, top = c.block_out_channels[3];
-    expect_tensor(v, "post_quant_conv.weight", {L, L, 1, 1}); expect_tensor(v, "post_quant_conv.bias", {L});
+    if (c.use_post_quant_conv) { expect_tensor(v, "post_quant_conv.weight", {L, L, 1, 1}); expect_tensor(v, "post_quant_conv.bias", {L}); }
     expect_tensor(v, "decoder.conv_in.weight", {top, L, 3, 3}); expect_tensor(v, "decoder.conv_in.bias", {top});
     expect_resnet(v, "decoder.mid_block.resnets.0", top, top);
     const std::string a = "decoder.mid_block.attentions.0";
@@ -193,14 +193,20 @@ int run_decode(CsVae* v, bool dry, const f16* latents, int B, float in_scale, fl
         for (int i = 0; i < 4; ++i) { ch = c.block_out_channels[3 - i]; const int cin = i ? c.block_out_channels[4 - i] : top;
             maxact = std::max(maxact, (size_t)h * h * std::max(ch, cin)); if (i < 3) { h *= 2; maxact = std::max(maxact, (size_t)h * h * ch); } }
     }
-    f16* z = R.alloc((size_t)B * L * H * W);
+    const bool wide = L != 4;                    // FLUX: 16 latent channels -> NHWC-64 + implicit-GEMM conv_in
+    f16* z = R.alloc((size_t)B * (wide ? 64 : L) * H * W);
     f16* bufs[4];
     for (auto& b : bufs) b = R.alloc((size_t)B * maxact);
     if (R.rc != CS_OK) return R.rc;
     f16 *x = bufs[0], *y = bufs[1], *n = bufs[2], *h = bufs[3];
 
-    R.launch(0, [&] { return launch_pixel_linear_nchw(latents, v->pq_w, v->pq_b, z, B, L, H * W, in_scale, in_shift, s); });
-    R.launch(2.0 * B * H * W * 9.0 * L * top, [&] { return launch_conv_in(z, B, B, L, H, W, v->conv_in.w, v->conv_in.b, top, x, s); });
+    if (!wide) {
+        R.launch(0, [&] { return launch_pixel_linear_nchw(latents, v->pq_w, v->pq_b, z, B, L, H * W, in_scale, in_shift, s); });
+        R.launch(2.0 * B * H * W * 9.0 * L * top, [&] { return launch_conv_in(z, B, B, L, H, W, v->conv_in.w, v->conv_in.b, top, x, s); });
+    } else {
+        R.launch(0, [&] { return launch_latent_to_nhwc64(latents, v->pq_w, v->pq_b, z, B, L, H * W, in_scale, in_shift, s); });
+        R.conv(v->conv_in, z, H, W, 0, nullptr, x);          // weights zero-padded to 64 input channels at load
+    }
 
     // ---- mid block
     R.resnet(v->mid_res[0], x, H, W, n, h, y); std::swap(x, y);
@@ -247,12 +253,13 @@ extern "C" {
 
 int cs_vae_create(const CsVaeConfig* cfg, CsVae** out) {
     if (!cfg || !out) CS_FAIL(CS_E_ARG, "cfg/out is NULL");
-    if (cfg->latent_channels != 4 || cfg->out_channels != 3) CS_FAIL(CS_E_UNSUPPORTED, "vae: built for 4 latent / 3 image channels");
+    if ((cfg->latent_channels != 4 && cfg->latent_channels != 16) || cfg->out_channels != 3) CS_FAIL(CS_E_UNSUPPORTED, "vae: built for 4 or 16 latent / 3 image channels");
+    if (cfg->latent_channels == 4 && !cfg->use_post_quant_conv) CS_FAIL(CS_E_UNSUPPORTED, "vae: the 4-channel path expects post_quant_conv");
     for (int i = 0; i < 4; ++i)
         if (cfg->block_out_channels[i] % 128) CS_FAIL(CS_E_SHAPE, "vae: block_out_channels[%d]=%d must be a multiple of 128", i, cfg->block_out_channels[i]);
     if (cfg->block_out_channels[3] != cfg->block_out_channels[2]) CS_FAIL(CS_E_UNSUPPORTED, "vae: the two deepest blocks must have equal width");
-    if (cfg->sample_size <= 0 || (cfg->sample_size * cfg->sample_size) % 128 || cfg->sample_size * cfg->sample_size > 8192)
-        CS_FAIL(CS_E_SHAPE, "vae: latent sample_size %d unsupported (tokens must be a multiple of 128 and <= 8192)", cfg->sample_size);
+    if (cfg->sample_size <= 0 || (cfg->sample_size * cfg->sample_size) % 128 || cfg->sample_size * cfg->sample_size > 65536)
+        CS_FAIL(CS_E_SHAPE, "vae: latent sample_size %d unsupported (tokens must be a multiple of 128 and <= 65536)", cfg->sample_size);
     if (cfg->layers_per_block < 1 || cfg->norm_num_groups < 1) CS_FAIL(CS_E_ARG, "vae: bad layers_per_block / norm_num_groups");
     CsVae* v = new CsVae();
     v->cfg = *cfg;
@@ -299,8 +306,17 @@ int cs_vae_finalize(CsVae* v) {
     if (v->finalized) return CS_OK;
     for (auto& n : v->names) if (!v->host.count(n)) CS_FAIL(CS_E_STATE, "missing weight '%s'", n.c_str());
     bool ok = true;
-    v->pq_w = upload(v, T(v, "post_quant_conv.weight").data); v->pq_b = upload(v, T(v, "post_quant_conv.bias").data);
-    ok = ok && make_conv(v, "decoder.conv_in", v->conv_in) && make_conv(v, "decoder.conv_out", v->conv_out) && make_norm(v, "decoder.conv_norm_out", v->norm_out);
+    if (v->cfg.use_post_quant_conv) { v->pq_w = upload(v, T(v, "post_quant_conv.weight").data); v->pq_b = upload(v, T(v, "post_quant_conv.bias").data); ok = v->pq_w && v->pq_b; }
+    if (v->cfg.latent_channels != 4) {           // conv_in weights [top][L][3][3] -> [top][9][64], zero beyond L
+        const HostT& w = T(v, "decoder.conv_in.weight");
+        const int64_t co = w.shape[0], ci = w.shape[1];
+        std::vector<f16> o((size_t)co * 9 * 64, (f16)0.f);
+        for (int64_t n = 0; n < co; ++n) for (int64_t c = 0; c < ci; ++c) for (int64_t k = 0; k < 9; ++k) o[(n * 9 + k) * 64 + c] = w.data[(n * ci + c) * 9 + k];
+        v->conv_in.cout = (int)co; v->conv_in.cin = 64; v->conv_in.taps = 9;
+        v->conv_in.w = upload(v, o); v->conv_in.b = upload(v, T(v, "decoder.conv_in.bias").data);
+        ok = ok && v->conv_in.w && v->conv_in.b;
+    } else ok = ok && make_conv(v, "decoder.conv_in", v->conv_in);
+    ok = ok && make_conv(v, "decoder.conv_out", v->conv_out) && make_norm(v, "decoder.conv_norm_out", v->norm_out);
     ok = ok && make_resnet(v, "decoder.mid_block.resnets.0", v->mid_res[0]) && make_resnet(v, "decoder.mid_block.resnets.1", v->mid_res[1]);
     const std::string a = "decoder.mid_block.attentions.0";
     ok = ok && make_norm(v, a + ".group_norm", v->att_gn);
@@ -314,7 +330,7 @@ int cs_vae_finalize(CsVae* v) {
         for (size_t j = 0; j < v->up_res[i].size() && ok; ++j) ok = ok && make_resnet(v, b + ".resnets." + std::to_string(j), v->up_res[i][j]);
         if (i < 3) ok = ok && make_conv(v, b + ".upsamplers.0.conv", v->up_samp[i]);
     }
-    if (!ok || !v->pq_w || !v->pq_b || !v->wq || !v->bq || !v->wk || !v->bk || !v->wv || !v->bv || !v->wo || !v->bo)
+    if (!ok || !v->wq || !v->bq || !v->wk || !v->bk || !v->wv || !v->bv || !v->wo || !v->bo)
         CS_FAIL(CS_E_HIP, "vae: weight upload failed (hipMalloc/hipMemcpy)");
     v->host.clear();
     v->finalized = true;

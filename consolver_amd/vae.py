@@ -14,7 +14,10 @@ import torch
 from . import _lib as L
 
 SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215)
+                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True)
+# FLUX.1 VAE: 16 latent channels, no quant convs, scaling / shift applied at edit_ppo/pipeline.py:623,1148
+FLUX_VAE_CONFIG = dict(latent_channels=16, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                       norm_num_groups=32, sample_size=128, scaling_factor=0.3611, shift_factor=0.1159, use_post_quant_conv=False)
 
 
 class HipAutoencoderKL:
@@ -31,6 +34,7 @@ class HipAutoencoderKL:
         for i in range(4):
             c.block_out_channels[i] = cfg["block_out_channels"][i]
         c.layers_per_block, c.norm_num_groups, c.sample_size = cfg["layers_per_block"], cfg["norm_num_groups"], cfg["sample_size"]
+        c.use_post_quant_conv = int(bool(cfg.get("use_post_quant_conv", True)))
         h = C.c_void_p()
         L.check(L.lib().cs_vae_create(C.byref(c), C.byref(h)))
         self._h = h
@@ -110,6 +114,21 @@ class HipAutoencoderKL:
         if return_dict:
             return types.SimpleNamespace(sample=out)
         return (out,)
+
+
+def flux_decode_latents(vae, packed_latents, height=1024, width=1024, vae_scale_factor=8, batch_size=8):
+    """edit_ppo/utils.py:11-28 (and edit_ppo/pipeline.py:1147-1150): unpack the [B, (h/2)(w/2), 64] token latents to
+    [B, 16, h, w], ``latents / scaling_factor + shift_factor``, decode, ``(x / 2 + 0.5).clamp(0, 1)``."""
+    from .flux import unpack_latents
+    if not getattr(vae, "is_consolver_hip", False):
+        raise RuntimeError("flux_decode_latents needs the HIP AutoencoderKL (no CPU fallback in the product path)")
+    lat = unpack_latents(packed_latents, height, width, vae_scale_factor)
+    N, _, h, w = lat.shape
+    out = torch.empty(N, vae.config.out_channels, 8 * h, 8 * w, dtype=torch.float16, device=lat.device)
+    for s in range(0, N, batch_size):
+        e = min(s + batch_size, N)
+        vae.decode_into(lat[s:e], out[s:e], in_scale=1.0 / vae.config.scaling_factor, in_shift=vae.config.shift_factor, postprocess=True)
+    return out
 
 
 def decode_latents(vae, latents, batch_size=1):

@@ -230,7 +230,8 @@ typedef struct CsVaeConfig {
     int block_out_channels[4];         /* 128, 256, 512, 512            */
     int layers_per_block;              /* 2 (decoder blocks hold 3)     */
     int norm_num_groups;               /* 32                            */
-    int sample_size;                   /* 64 (latent H = W)             */
+    int sample_size;                   /* 64 (latent H = W); FLUX 128   */
+    int use_post_quant_conv;           /* 1 (SD1.5); 0 for the FLUX VAE (16 latent channels) */
 } CsVaeConfig;
 
 typedef struct CsVae CsVae;

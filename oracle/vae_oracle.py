@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215)
+                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True)
 
 
 def vae_manifest(cfg):
@@ -30,8 +30,9 @@ def vae_manifest(cfg):
         if cin != cout:
             out.extend([(p + ".conv_shortcut.weight", (cout, cin, 1, 1)), (p + ".conv_shortcut.bias", (cout,))])
 
-    out.extend([("post_quant_conv.weight", (L, L, 1, 1)), ("post_quant_conv.bias", (L,)),
-                ("decoder.conv_in.weight", (top, L, 3, 3)), ("decoder.conv_in.bias", (top,))])
+    if cfg.get("use_post_quant_conv", True):
+        out.extend([("post_quant_conv.weight", (L, L, 1, 1)), ("post_quant_conv.bias", (L,))])
+    out.extend([("decoder.conv_in.weight", (top, L, 3, 3)), ("decoder.conv_in.bias", (top,))])
     res("decoder.mid_block.resnets.0", top, top)
     a = "decoder.mid_block.attentions.0"
     out.extend([(a + ".group_norm.weight", (top,)), (a + ".group_norm.bias", (top,))])
@@ -96,7 +97,8 @@ class VaeOracle:
     def decode(self, z, return_dict=False):
         sd = self.sd
         z = z.float()
-        z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+        if "post_quant_conv.weight" in sd:
+            z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
         x = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
         x = self._resnet(x, "decoder.mid_block.resnets.0")
         x = self._attn(x, "decoder.mid_block.attentions.0")
@@ -121,3 +123,9 @@ def decode_latents(vae, latents, batch_size=1):
         img = vae.decode(latents[s:min(s + batch_size, latents.shape[0])], return_dict=False)[0]
         images.append((img / 2 + 0.5).clamp(0, 1))
     return torch.cat(images, dim=0)
+
+
+def flux_decode_latents(vae, latents_unpacked):
+    """edit_ppo/utils.py:22-25 after the unpack: latents / scaling_factor + shift_factor -> decode -> [0, 1]."""
+    z = latents_unpacked / vae.config.scaling_factor + vae.config.shift_factor
+    return (vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)

@@ -49,7 +49,7 @@ assert t == 2.0, t
 assert sum(c for c, _ in rep) == 37 and sum(s for _, s in rep) == sum(range(37)), rep
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f"rank{rank}.ok"), "w").write("ok")   # a file per rank: stdout of two processes interleaves
 '''
 
 
@@ -65,4 +65,4 @@ def test_two_process_gloo_launch(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").read_text() == "ok" and (tmp_path / "rank1.ok").read_text() == "ok"

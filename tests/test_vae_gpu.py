@@ -84,3 +84,28 @@ def test_product_path_has_no_cpu_fallback():
         config = vae_oracle._Cfg(dict(scaling_factor=0.18215, out_channels=3))
     with pytest.raises(RuntimeError):
         decode_latents(NotHip(), torch.zeros(1, 4, 16, 16), batch_size=1)
+
+
+def test_flux_vae_16_channel_latents_and_long_softmax_rows():
+    """FLUX-side decode (edit_ppo/utils.py:11-28): 16 latent channels, no post_quant_conv, scaling + shift, packed token latents.
+    Reduced depth; sample 32 -> 1024 tokens in the mid attention; a second config with 96 x 96 latents (9216 tokens) exercises the
+    long-row softmax kernel."""
+    from consolver_amd.vae import flux_decode_latents, FLUX_VAE_CONFIG
+    from consolver_amd.flux import pack_latents
+    cfg = dict(FLUX_VAE_CONFIG); cfg.update(layers_per_block=1, sample_size=32)
+    v, orc = build(cfg, seed=21)
+    g = torch.Generator().manual_seed(6)
+    lat = (torch.randn(2, 16, 32, 32, generator=g) * 0.3611).half()
+    packed = pack_latents(lat)                                       # [2, 256, 64] tokens like the sampling loop holds them
+    got = flux_decode_latents(v, packed.to(DEV), height=256, width=256)
+    want = vae_oracle.flux_decode_latents(orc, lat.float())
+    assert got.shape == (2, 3, 256, 256)
+    err = rel_l2(got, want)
+    print("flux vae rel l2", err)
+    assert err < 5e-3 and (got.float().cpu() - want).abs().max() < 2e-2
+    cfg.update(sample_size=96, block_out_channels=(128, 128, 128, 128))
+    v2, orc2 = build(cfg, seed=22)
+    lat2 = (torch.randn(1, 16, 96, 96, generator=g) * 0.3611).half()
+    got2 = v2.decode(lat2.to(DEV))[0]
+    want2 = orc2.decode(lat2.float())[0]
+    assert rel_l2(got2, want2) < 5e-3
