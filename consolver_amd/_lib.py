@@ -47,7 +47,8 @@ class CsUNetConfig(C.Structure):
 
 class CsVaeConfig(C.Structure):
     _fields_ = [("latent_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
-                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int), ("use_post_quant_conv", C.c_int)]
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int), ("sample_size", C.c_int), ("use_post_quant_conv", C.c_int),
+                ("with_encoder", C.c_int), ("use_quant_conv", C.c_int)]
 
 
 class CsClipConfig(C.Structure):
@@ -102,6 +103,8 @@ SYMBOLS = {
     "cs_vae_flops": (C.c_double, [C.c_void_p, C.c_int]),
     "cs_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
                                 C.c_void_p]),
+    "cs_vae_encode_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "cs_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cs_unet_create": (C.c_int, [C.POINTER(CsUNetConfig), C.POINTER(C.c_void_p)]),
     "cs_unet_destroy": (None, [C.c_void_p]),
     "cs_unet_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -38,6 +38,7 @@ struct IgemmParams {
     const f16* a0; const f16* a1; int c0, c1;
     int Hi, Wi, Ho, Wo, HoWo;
     int stride, upsample;
+    int pad_lo;         // zero rows / columns before the image (1 = symmetric pad 1; 0 = the VAE encoder's (0,1,0,1) pad before its stride-2 conv)
     int M, N, KT, cpt;   // KT = K / 64 ; cpt = chunks (of 64 channels) per tap
     int Ktot;            // row length of w
     const f16* w; const f16* bias; const f16* temb; int temb_stride; const f16* res; f16* out;
@@ -571,8 +572,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
             if (m < p.M) {
                 const int b = m / p.HoWo, rem = m - b * p.HoWo, yo = rem / p.Wo, xo = rem - yo * p.Wo;
                 a_row_base[j] = b * p.Hi * p.Wi;
-                a_y[j] = yo * p.stride - 1;
-                a_x[j] = xo * p.stride - 1;
+                a_y[j] = yo * p.stride - p.pad_lo;
+                a_x[j] = xo * p.stride - p.pad_lo;
             } else {
                 a_row_base[j] = 0; a_y[j] = -(1 << 20); a_x[j] = 0;
             }
@@ -699,7 +700,8 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     IgemmParams p;
     p.a0 = a.a0; p.a1 = a.a1; p.c0 = a.c0; p.c1 = a.c1;
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo; p.HoWo = a.Ho * a.Wo;
-    p.stride = a.stride; p.upsample = a.upsample;
+    p.stride = a.stride; p.upsample = a.upsample; p.pad_lo = a.pad_after_only ? 0 : 1;
+    if (a.pad_after_only && !(a.taps == 9 && a.stride == 2)) CS_FAIL(CS_E_ARG, "igemm: pad_after_only is the stride-2 3x3 form");
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
     p.debug = g_tune_debug;

@@ -265,6 +265,19 @@ __global__ __launch_bounds__(256) void row_softmax_block_kernel(f16* __restrict_
     }
 }
 
+__global__ void pixel_affine_kernel(const f16* __restrict__ x, int Cin, const f16* __restrict__ w, const f16* __restrict__ b, int Cout, f16* __restrict__ out,
+                                    int B, int HW, float out_scale, float out_shift) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int bi = (int)(i / HW), px = (int)(i - (long)bi * HW);
+    for (int o = 0; o < Cout; ++o) {
+        float acc;
+        if (w) { acc = (float)b[o]; for (int c = 0; c < Cin; ++c) acc += (float)w[o * Cin + c] * (float)x[((size_t)bi * Cin + c) * HW + px]; }
+        else acc = (float)x[((size_t)bi * Cin + o) * HW + px];
+        out[((size_t)bi * Cout + o) * HW + px] = (f16)((acc - out_shift) * out_scale);
+    }
+}
+
 __global__ void pixel_linear_kernel(const f16* __restrict__ x, const f16* __restrict__ w, const f16* __restrict__ b, f16* __restrict__ out,
                                     int B, int C, int HW, float in_scale, float in_shift) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +443,29 @@ int launch_latent_to_nhwc64(const f16* x, const f16* w, const f16* b, f16* out, 
     const long n = (long)B * HW;
     if (n <= 0) return CS_OK;
     hipLaunchKernelGGL(latent_to_nhwc64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, out, B, C, HW, in_scale, in_shift);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s) {
+    if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out_small: null pointer");
+    if (H % 16 || W % 16 || Cin % 64) CS_FAIL(CS_E_SHAPE, "conv_out_small: H, W must be multiples of 16 and Cin of 64");
+    if (B <= 0) return CS_OK;
+    const dim3 grid((H / 16) * (W / 16), B);
+    if (Cout == 4) hipLaunchKernelGGL(conv_out_patch_kernel<4>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+    else if (Cout == 8) hipLaunchKernelGGL(conv_out_patch_kernel<8>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+    else if (Cout == 16) hipLaunchKernelGGL(conv_out_patch_kernel<16>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+    else CS_FAIL(CS_E_UNSUPPORTED, "conv_out_small: %d output channels not built", Cout);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_pixel_affine_nchw(const f16* x, int Cin, const f16* w, const f16* bias, int Cout, f16* out, int B, int HW, float out_scale, float out_shift, hipStream_t s) {
+    if (!x || !out || (w && !bias)) CS_FAIL(CS_E_ARG, "pixel_affine: null pointer");
+    if (!w && Cout > Cin) CS_FAIL(CS_E_SHAPE, "pixel_affine: identity form needs Cout <= Cin");
+    const long n = (long)B * HW;
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(pixel_affine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, Cin, w, bias, Cout, out, B, HW, out_scale, out_shift);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

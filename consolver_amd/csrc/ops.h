@@ -11,6 +11,7 @@ struct IgemmArgs {
     int taps;               // 1 = 1x1 conv / linear, 9 = 3x3 conv (pad 1)
     int stride;             // 1 or 2 (3x3 only)
     int upsample;           // 1: nearest x2 upsample fused into the gather
+    int pad_after_only;     // stride 2 only: pad (0,1,0,1) instead of 1 on every side (AutoencoderKL encoder downsample)
     int N;                  // output channels (rows of w)
     const f16* w;           // [N][taps*(c0+c1)] K contiguous, tap-major / channel-minor
     const f16* bias;        // [N] or null
@@ -104,3 +105,7 @@ int launch_embed_tokens(const int64_t* ids, const f16* tok, const f16* pos, f16*
 int launch_quick_gelu(f16* x, long n, hipStream_t s);
 // latents with up to 64 channels: z = x * scale + shift [-> 1x1 post_quant when w != null], NHWC with channels zero-padded to 64
 int launch_latent_to_nhwc64(const f16* x, const f16* w, const f16* b, f16* out, int B, int C, int HW, float in_scale, float in_shift, hipStream_t s);
+// conv 3x3 (pad 1) to a few output channels (Cout in {4, 8, 16}), NHWC in -> NCHW out (VAE encoder moments)
+int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s);
+// out[b][o][px] = (sum_c w[o][c] x[b][c][px] + bias[o] - out_shift) * out_scale ; w == null: identity on the first Cout channels
+int launch_pixel_affine_nchw(const f16* x, int Cin, const f16* w, const f16* bias, int Cout, f16* out, int B, int HW, float out_scale, float out_shift, hipStream_t s);

@@ -26,6 +26,7 @@ struct HostT { std::vector<int64_t> shape; std::vector<f16> data; };
 struct VConv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; };
 struct VNorm { f16* g = nullptr; f16* b = nullptr; int c = 0; };
 struct VResnet { VNorm n1, n2; VConv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
+struct VAttn { VNorm gn; f16 *wq = nullptr, *bq = nullptr, *wk = nullptr, *bk = nullptr, *wv = nullptr, *bv = nullptr, *wo = nullptr, *bo = nullptr; };
 
 struct VArena {   // bump allocator with explicit stack discipline (mark / rewind)
     char* base = nullptr; size_t cap = 0, top = 0, peak = 0; bool dry = false;
@@ -51,8 +52,12 @@ struct CsVae {
     f16 *pq_w = nullptr, *pq_b = nullptr;
     VConv conv_in, conv_out; VNorm norm_out;
     VResnet mid_res[2];
-    VNorm att_gn; f16 *wq = nullptr, *bq = nullptr, *wk = nullptr, *bk = nullptr, *wv = nullptr, *bv = nullptr, *wo = nullptr, *bo = nullptr;
+    VAttn att;
     std::vector<VResnet> up_res[4]; VConv up_samp[4];
+    // encoder (optional, cfg.with_encoder): images -> mode of the latent distribution
+    VConv e_conv_in, e_conv_out; VNorm e_norm_out; VResnet e_mid_res[2]; VAttn e_att;
+    std::vector<VResnet> e_down_res[4]; VConv e_down_samp[4];
+    f16 *q_w = nullptr, *q_b = nullptr;            // quant_conv rows of the mean half [L][2L], [L]
     VArena arena; double dry_flops = 0;
 };
 
@@ -67,15 +72,35 @@ void expect_resnet(CsVae* v, const std::string& p, int cin, int cout) {
     if (cin != cout) { expect_tensor(v, p + ".conv_shortcut.weight", {cout, cin, 1, 1}); expect_tensor(v, p + ".conv_shortcut.bias", {cout}); }
 }
 
+void expect_attn(CsVae* v, const std::string& a, int top) {
+    expect_tensor(v, a + ".group_norm.weight", {top}); expect_tensor(v, a + ".group_norm.bias", {top});
+    for (const char* q : {".to_q", ".to_k", ".to_v", ".to_out.0"}) { expect_tensor(v, a + q + ".weight", {top, top}); expect_tensor(v, a + q + ".bias", {top}); }
+}
+
 void build_manifest(CsVae* v) {
     const CsVaeConfig& c = v->cfg;
     const int L = c.latent_channels, top = c.block_out_channels[3];
+    if (c.with_encoder) {
+        expect_tensor(v, "encoder.conv_in.weight", {c.block_out_channels[0], c.out_channels, 3, 3}); expect_tensor(v, "encoder.conv_in.bias", {c.block_out_channels[0]});
+        int prev = c.block_out_channels[0];
+        for (int i = 0; i < 4; ++i) {
+            const int out = c.block_out_channels[i];
+            const std::string b = "encoder.down_blocks." + std::to_string(i);
+            for (int j = 0; j < c.layers_per_block; ++j) expect_resnet(v, b + ".resnets." + std::to_string(j), j == 0 ? prev : out, out);
+            if (i < 3) { expect_tensor(v, b + ".downsamplers.0.conv.weight", {out, out, 3, 3}); expect_tensor(v, b + ".downsamplers.0.conv.bias", {out}); }
+            prev = out;
+        }
+        expect_resnet(v, "encoder.mid_block.resnets.0", top, top);
+        expect_attn(v, "encoder.mid_block.attentions.0", top);
+        expect_resnet(v, "encoder.mid_block.resnets.1", top, top);
+        expect_tensor(v, "encoder.conv_norm_out.weight", {top}); expect_tensor(v, "encoder.conv_norm_out.bias", {top});
+        expect_tensor(v, "encoder.conv_out.weight", {2 * L, top, 3, 3}); expect_tensor(v, "encoder.conv_out.bias", {2 * L});
+        if (c.use_quant_conv) { expect_tensor(v, "quant_conv.weight", {2 * L, 2 * L, 1, 1}); expect_tensor(v, "quant_conv.bias", {2 * L}); }
+    }
     if (c.use_post_quant_conv) { expect_tensor(v, "post_quant_conv.weight", {L, L, 1, 1}); expect_tensor(v, "post_quant_conv.bias", {L}); }
     expect_tensor(v, "decoder.conv_in.weight", {top, L, 3, 3}); expect_tensor(v, "decoder.conv_in.bias", {top});
     expect_resnet(v, "decoder.mid_block.resnets.0", top, top);
-    const std::string a = "decoder.mid_block.attentions.0";
-    expect_tensor(v, a + ".group_norm.weight", {top}); expect_tensor(v, a + ".group_norm.bias", {top});
-    for (const char* q : {".to_q", ".to_k", ".to_v", ".to_out.0"}) { expect_tensor(v, a + q + ".weight", {top, top}); expect_tensor(v, a + q + ".bias", {top}); }
+    expect_attn(v, "decoder.mid_block.attentions.0", top);
     expect_resnet(v, "decoder.mid_block.resnets.1", top, top);
     int prev = top;
     for (int i = 0; i < 4; ++i) {
@@ -126,6 +151,25 @@ bool make_resnet(CsVae* v, const std::string& p, VResnet& r) {
     return ok;
 }
 
+bool make_attn(CsVae* v, const std::string& a, VAttn& t) {
+    bool ok = make_norm(v, a + ".group_norm", t.gn);
+    t.wq = upload(v, T(v, a + ".to_q.weight").data); t.bq = upload(v, T(v, a + ".to_q.bias").data);
+    t.wk = upload(v, T(v, a + ".to_k.weight").data); t.bk = upload(v, T(v, a + ".to_k.bias").data);
+    t.wv = upload(v, T(v, a + ".to_v.weight").data); t.bv = upload(v, T(v, a + ".to_v.bias").data);
+    t.wo = upload(v, T(v, a + ".to_out.0.weight").data); t.bo = upload(v, T(v, a + ".to_out.0.bias").data);
+    return ok && t.wq && t.bq && t.wk && t.bk && t.wv && t.bv && t.wo && t.bo;
+}
+// 3x3 conv whose few input channels are zero-padded to 64 (the operand then arrives as NHWC-64): [co][ci][3][3] -> [co][9][64]
+bool make_conv_padded64(CsVae* v, const std::string& p, VConv& c) {
+    const HostT& w = T(v, p + ".weight");
+    const int64_t co = w.shape[0], ci = w.shape[1];
+    std::vector<f16> o((size_t)co * 9 * 64, (f16)0.f);
+    for (int64_t n = 0; n < co; ++n) for (int64_t ch = 0; ch < ci; ++ch) for (int64_t k = 0; k < 9; ++k) o[(n * 9 + k) * 64 + ch] = w.data[(n * ci + ch) * 9 + k];
+    c.cout = (int)co; c.cin = 64; c.taps = 9;
+    c.w = upload(v, o); c.b = upload(v, T(v, p + ".bias").data);
+    return c.w && c.b;
+}
+
 struct Run {
     CsVae* v; hipStream_t s; bool dry; int B; int rc = CS_OK;
     float* gn_ws = nullptr;
@@ -143,6 +187,12 @@ struct Run {
         IgemmArgs a{};
         a.a0 = x; a.c0 = c.cin; a.B = B; a.Hi = H; a.Wi = W; a.Ho = up ? 2 * H : H; a.Wo = up ? 2 * W : W; a.taps = c.taps; a.stride = 1;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.res = res; a.out = out;
+        launch(igemm_flops(a), [&] { return launch_igemm(a, s); });
+    }
+    void conv_down(const VConv& c, const f16* x, int H, int W, f16* out) {       // pad (0,1,0,1) + 3x3 stride 2 (encoder downsample)
+        IgemmArgs a{};
+        a.a0 = x; a.c0 = c.cin; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H / 2; a.Wo = W / 2; a.taps = 9; a.stride = 2; a.pad_after_only = 1;
+        a.N = c.cout; a.w = c.w; a.bias = c.b; a.out = out;
         launch(igemm_flops(a), [&] { return launch_igemm(a, s); });
     }
     void gemm(const f16* x, int M, int K, const f16* w, const f16* b, int N, const f16* res, f16* out) {
@@ -165,6 +215,29 @@ struct Run {
         const f16* res = x;
         if (r.has_sc) { conv(r.sc, x, H, W, 0, nullptr, out); res = out; }
         conv(r.c2, n, H, W, 0, res, out);
+    }
+    // single-head attention of the mid block: x [B,HW,C] -> y (= x + to_out(softmax(q k^T / sqrt C) v)); n, h scratch
+    void mid_attention(const VAttn& t, const f16* x, f16* y, f16* n, f16* h, int HW, int C) {
+        const size_t M = (size_t)B * HW;
+        group_norm(t.gn, x, HW, false, n);
+        f16* q = h;                       // [M][C]
+        f16* k = y;                       // [M][C]
+        gemm(n, (int)M, C, t.wq, t.bq, C, nullptr, q);
+        gemm(n, (int)M, C, t.wk, t.bk, C, nullptr, k);
+        const size_t mark = v->arena.top;
+        f16* scores = alloc((size_t)HW * HW);
+        f16* vt = alloc((size_t)C * HW);
+        f16* att = alloc(M * C);
+        if (rc != CS_OK) return;
+        for (int b = 0; b < B; ++b) {
+            const f16* qb = q + (size_t)b * HW * C; const f16* kb = k + (size_t)b * HW * C; const f16* nb = n + (size_t)b * HW * C;
+            gemm(qb, HW, C, kb, nullptr, HW, nullptr, scores);                       // S = Q K^T          [HW][HW]
+            launch(0, [&] { return launch_row_softmax(scores, HW, HW, 1.0f / sqrtf((float)C), s); });
+            gemm(t.wv, C, C, nb, nullptr, HW, nullptr, vt);                          // V^T = Wv X^T       [C][HW]
+            gemm(scores, HW, HW, vt, t.bv, C, nullptr, att + (size_t)b * HW * C);     // O = P V + bv       [HW][C]
+        }
+        gemm(att, (int)M, C, t.wo, t.bo, C, x, y);                                   // to_out + residual
+        v->arena.top = mark;
     }
 };
 
@@ -210,29 +283,8 @@ int run_decode(CsVae* v, bool dry, const f16* latents, int B, float in_scale, fl
 
     // ---- mid block
     R.resnet(v->mid_res[0], x, H, W, n, h, y); std::swap(x, y);
-    {
-        const int HW = H * W, C = top; const size_t M = (size_t)B * HW;
-        R.group_norm(v->att_gn, x, HW, false, n);
-        f16* q = h;                       // [M][C]
-        f16* k = y;                       // [M][C]
-        R.gemm(n, (int)M, C, v->wq, v->bq, C, nullptr, q);
-        R.gemm(n, (int)M, C, v->wk, v->bk, C, nullptr, k);
-        const size_t mark = v->arena.top;
-        f16* scores = R.alloc((size_t)HW * HW);
-        f16* vt = R.alloc((size_t)C * HW);
-        f16* att = R.alloc(M * C);
-        if (R.rc != CS_OK) return R.rc;
-        for (int b = 0; b < B; ++b) {
-            const f16* qb = q + (size_t)b * HW * C; const f16* kb = k + (size_t)b * HW * C; const f16* nb = n + (size_t)b * HW * C;
-            R.gemm(qb, HW, C, kb, nullptr, HW, nullptr, scores);                       // S = Q K^T          [HW][HW]
-            R.launch(0, [&] { return launch_row_softmax(scores, HW, HW, 1.0f / sqrtf((float)C), s); });
-            R.gemm(v->wv, C, C, nb, nullptr, HW, nullptr, vt);                         // V^T = Wv X^T       [C][HW]
-            R.gemm(scores, HW, HW, vt, v->bv, C, nullptr, att + (size_t)b * HW * C);    // O = P V + bv       [HW][C]
-        }
-        R.gemm(att, (int)M, C, v->wo, v->bo, C, x, y);                                  // to_out + residual
-        std::swap(x, y);
-        v->arena.top = mark;
-    }
+    R.mid_attention(v->att, x, y, n, h, H * W, top); std::swap(x, y);
+    if (R.rc != CS_OK) return R.rc;
     R.resnet(v->mid_res[1], x, H, W, n, h, y); std::swap(x, y);
 
     // ---- up blocks
@@ -244,6 +296,45 @@ int run_decode(CsVae* v, bool dry, const f16* latents, int B, float in_scale, fl
     const int c0 = c.block_out_channels[0];
     R.launch(2.0 * B * H * W * 9.0 * c0 * c.out_channels,
              [&] { return launch_conv_out3(n, B, c0, H, W, v->conv_out.w, v->conv_out.b, out, postprocess, s); });
+    return R.rc;
+}
+
+
+int run_encode(CsVae* v, bool dry, const f16* images, int B, float out_scale, float out_shift, f16* latents, char* ws, size_t ws_bytes, hipStream_t s) {
+    const CsVaeConfig& c = v->cfg;
+    Run R{v, s, dry, B};
+    v->dry_flops = 0;
+    size_t off = 0;
+    if (!dry) {
+        if (ws_bytes < gn_ws_bytes(v, B)) CS_FAIL(CS_E_ARG, "vae: workspace too small");
+        R.gn_ws = (float*)ws; off = gn_ws_bytes(v, B);
+    }
+    v->arena.base = dry ? (char*)256 : ws + off; v->arena.cap = dry ? 0 : ws_bytes - off; v->arena.top = 0; v->arena.peak = 0; v->arena.dry = dry;
+    int H = 8 * c.sample_size, W = 8 * c.sample_size;
+    const int top = c.block_out_channels[3], L = c.latent_channels;
+    size_t maxact = 0;
+    { int h = H; for (int i = 0; i < 4; ++i) { const int ch = c.block_out_channels[i], cin = i ? c.block_out_channels[i - 1] : c.block_out_channels[0];
+          maxact = std::max(maxact, (size_t)h * h * std::max(std::max(ch, cin), 64)); if (i < 3) h /= 2; } }
+    f16* bufs[4];
+    for (auto& b : bufs) b = R.alloc((size_t)B * maxact);
+    const int mo = c.use_quant_conv ? 2 * L : L;
+    f16* mom = R.alloc((size_t)B * mo * c.sample_size * c.sample_size);
+    if (R.rc != CS_OK) return R.rc;
+    f16 *x = bufs[0], *y = bufs[1], *n = bufs[2], *h = bufs[3];
+    R.launch(0, [&] { return launch_latent_to_nhwc64(images, nullptr, nullptr, n, B, c.out_channels, H * W, 1.0f, 0.0f, s); });
+    R.conv(v->e_conv_in, n, H, W, 0, nullptr, x);
+    for (int i = 0; i < 4; ++i) {
+        for (auto& r : v->e_down_res[i]) { R.resnet(r, x, H, W, n, h, y); std::swap(x, y); }
+        if (i < 3) { R.conv_down(v->e_down_samp[i], x, H, W, y); std::swap(x, y); H /= 2; W /= 2; }
+    }
+    R.resnet(v->e_mid_res[0], x, H, W, n, h, y); std::swap(x, y);
+    R.mid_attention(v->e_att, x, y, n, h, H * W, top); std::swap(x, y);
+    if (R.rc != CS_OK) return R.rc;
+    R.resnet(v->e_mid_res[1], x, H, W, n, h, y); std::swap(x, y);
+    R.group_norm(v->e_norm_out, x, H * W, true, n);
+    R.launch(2.0 * B * H * W * 9.0 * top * mo, [&] { return launch_conv_out_small(n, B, top, H, W, v->e_conv_out.w, v->e_conv_out.b, mo, mom, s); });
+    // mode of the distribution = mean [= quant_conv rows of the mean half]; (mean - shift) * scale folded into the same pass
+    R.launch(0, [&] { return launch_pixel_affine_nchw(mom, mo, v->q_w, v->q_b, L, latents, B, H * W, out_scale, out_shift, s); });
     return R.rc;
 }
 
@@ -261,6 +352,7 @@ int cs_vae_create(const CsVaeConfig* cfg, CsVae** out) {
     if (cfg->sample_size <= 0 || (cfg->sample_size * cfg->sample_size) % 128 || cfg->sample_size * cfg->sample_size > 65536)
         CS_FAIL(CS_E_SHAPE, "vae: latent sample_size %d unsupported (tokens must be a multiple of 128 and <= 65536)", cfg->sample_size);
     if (cfg->layers_per_block < 1 || cfg->norm_num_groups < 1) CS_FAIL(CS_E_ARG, "vae: bad layers_per_block / norm_num_groups");
+    if (cfg->with_encoder && cfg->sample_size % 2) CS_FAIL(CS_E_SHAPE, "vae: the encoder needs an even latent size");
     CsVae* v = new CsVae();
     v->cfg = *cfg;
     build_manifest(v);
@@ -307,31 +399,43 @@ int cs_vae_finalize(CsVae* v) {
     for (auto& n : v->names) if (!v->host.count(n)) CS_FAIL(CS_E_STATE, "missing weight '%s'", n.c_str());
     bool ok = true;
     if (v->cfg.use_post_quant_conv) { v->pq_w = upload(v, T(v, "post_quant_conv.weight").data); v->pq_b = upload(v, T(v, "post_quant_conv.bias").data); ok = v->pq_w && v->pq_b; }
-    if (v->cfg.latent_channels != 4) {           // conv_in weights [top][L][3][3] -> [top][9][64], zero beyond L
-        const HostT& w = T(v, "decoder.conv_in.weight");
-        const int64_t co = w.shape[0], ci = w.shape[1];
-        std::vector<f16> o((size_t)co * 9 * 64, (f16)0.f);
-        for (int64_t n = 0; n < co; ++n) for (int64_t c = 0; c < ci; ++c) for (int64_t k = 0; k < 9; ++k) o[(n * 9 + k) * 64 + c] = w.data[(n * ci + c) * 9 + k];
-        v->conv_in.cout = (int)co; v->conv_in.cin = 64; v->conv_in.taps = 9;
-        v->conv_in.w = upload(v, o); v->conv_in.b = upload(v, T(v, "decoder.conv_in.bias").data);
-        ok = ok && v->conv_in.w && v->conv_in.b;
-    } else ok = ok && make_conv(v, "decoder.conv_in", v->conv_in);
+    if (v->cfg.latent_channels != 4) ok = ok && make_conv_padded64(v, "decoder.conv_in", v->conv_in);
+    else ok = ok && make_conv(v, "decoder.conv_in", v->conv_in);
     ok = ok && make_conv(v, "decoder.conv_out", v->conv_out) && make_norm(v, "decoder.conv_norm_out", v->norm_out);
     ok = ok && make_resnet(v, "decoder.mid_block.resnets.0", v->mid_res[0]) && make_resnet(v, "decoder.mid_block.resnets.1", v->mid_res[1]);
-    const std::string a = "decoder.mid_block.attentions.0";
-    ok = ok && make_norm(v, a + ".group_norm", v->att_gn);
-    v->wq = upload(v, T(v, a + ".to_q.weight").data); v->bq = upload(v, T(v, a + ".to_q.bias").data);
-    v->wk = upload(v, T(v, a + ".to_k.weight").data); v->bk = upload(v, T(v, a + ".to_k.bias").data);
-    v->wv = upload(v, T(v, a + ".to_v.weight").data); v->bv = upload(v, T(v, a + ".to_v.bias").data);
-    v->wo = upload(v, T(v, a + ".to_out.0.weight").data); v->bo = upload(v, T(v, a + ".to_out.0.bias").data);
+    ok = ok && make_attn(v, "decoder.mid_block.attentions.0", v->att);
     for (int i = 0; i < 4 && ok; ++i) {
         const std::string b = "decoder.up_blocks." + std::to_string(i);
         v->up_res[i].resize(v->cfg.layers_per_block + 1);
         for (size_t j = 0; j < v->up_res[i].size() && ok; ++j) ok = ok && make_resnet(v, b + ".resnets." + std::to_string(j), v->up_res[i][j]);
         if (i < 3) ok = ok && make_conv(v, b + ".upsamplers.0.conv", v->up_samp[i]);
     }
-    if (!ok || !v->wq || !v->bq || !v->wk || !v->bk || !v->wv || !v->bv || !v->wo || !v->bo)
-        CS_FAIL(CS_E_HIP, "vae: weight upload failed (hipMalloc/hipMemcpy)");
+    if (v->cfg.with_encoder && ok) {
+        const int L = v->cfg.latent_channels;
+        ok = make_conv_padded64(v, "encoder.conv_in", v->e_conv_in) && make_norm(v, "encoder.conv_norm_out", v->e_norm_out) &&
+             make_resnet(v, "encoder.mid_block.resnets.0", v->e_mid_res[0]) && make_resnet(v, "encoder.mid_block.resnets.1", v->e_mid_res[1]) &&
+             make_attn(v, "encoder.mid_block.attentions.0", v->e_att);
+        for (int i = 0; i < 4 && ok; ++i) {
+            const std::string b = "encoder.down_blocks." + std::to_string(i);
+            v->e_down_res[i].resize(v->cfg.layers_per_block);
+            for (size_t j = 0; j < v->e_down_res[i].size() && ok; ++j) ok = ok && make_resnet(v, b + ".resnets." + std::to_string(j), v->e_down_res[i][j]);
+            if (i < 3) ok = ok && make_conv(v, b + ".downsamplers.0.conv", v->e_down_samp[i]);
+        }
+        // conv_out: with quant_conv every one of the 2L moments feeds the mean; without it only the mean half is needed
+        const HostT& w = T(v, "encoder.conv_out.weight"); const HostT& bb = T(v, "encoder.conv_out.bias");
+        const int rows = v->cfg.use_quant_conv ? 2 * L : L;
+        HostT wt; wt.shape = {rows, w.shape[1], 3, 3}; wt.data.assign(w.data.begin(), w.data.begin() + (size_t)rows * w.shape[1] * 9);
+        v->e_conv_out.cout = rows; v->e_conv_out.cin = (int)w.shape[1]; v->e_conv_out.taps = 9;
+        v->e_conv_out.w = upload(v, pack_conv(wt)); v->e_conv_out.b = upload(v, std::vector<f16>(bb.data.begin(), bb.data.begin() + rows));
+        ok = ok && v->e_conv_out.w && v->e_conv_out.b;
+        if (v->cfg.use_quant_conv) {
+            const HostT& qw = T(v, "quant_conv.weight"); const HostT& qb = T(v, "quant_conv.bias");
+            v->q_w = upload(v, std::vector<f16>(qw.data.begin(), qw.data.begin() + (size_t)L * 2 * L));
+            v->q_b = upload(v, std::vector<f16>(qb.data.begin(), qb.data.begin() + L));
+            ok = ok && v->q_w && v->q_b;
+        }
+    }
+    if (!ok) CS_FAIL(CS_E_HIP, "vae: weight upload failed (hipMalloc/hipMemcpy)");
     v->host.clear();
     v->finalized = true;
     return CS_OK;
@@ -360,6 +464,24 @@ int cs_vae_decode(CsVae* v, const void* latents, int batch, float in_scale, floa
     if (!latents || !images || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
     return run_decode(v, false, (const f16*)latents, batch, in_scale, in_shift, (f16*)images, postprocess, (char*)workspace, workspace_bytes,
                       (hipStream_t)stream);
+}
+
+size_t cs_vae_encode_workspace_bytes(const CsVae* cv, int batch) {
+    CsVae* v = const_cast<CsVae*>(cv);
+    if (!v || !v->finalized || !v->cfg.with_encoder || batch <= 0) return 0;
+    run_encode(v, true, nullptr, batch, 1.f, 0.f, nullptr, nullptr, 0, nullptr);
+    return gn_ws_bytes(v, batch) + v->arena.peak + 4096;
+}
+
+int cs_vae_encode(CsVae* v, const void* images, int batch, float out_scale, float out_shift, void* latents, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    if (!v) CS_FAIL(CS_E_ARG, "vae is NULL");
+    if (!v->finalized) CS_FAIL(CS_E_STATE, "cs_vae_finalize has not been called");
+    if (!v->cfg.with_encoder) CS_FAIL(CS_E_STATE, "vae: created without the encoder (cfg.with_encoder = 0)");
+    if (batch < 0) CS_FAIL(CS_E_ARG, "negative batch");
+    if (batch == 0) return CS_OK;
+    if (!images || !latents || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
+    return run_encode(v, false, (const f16*)images, batch, out_scale, out_shift, (f16*)latents, (char*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,12 @@ CLIP_L_CONFIG = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, 
                      max_position_embeddings=77, layer_norm_eps=1e-5)
 
 
+class _ClipOutput(tuple):
+    """tuple (last_hidden_state, pooler_output) with the transformers attribute names"""
+    last_hidden_state = property(lambda self: self[0])
+    pooler_output = property(lambda self: self[1])
+
+
 class HipCLIPTextModel:
     is_consolver_hip = True
     dtype = torch.float16
@@ -77,7 +83,9 @@ class HipCLIPTextModel:
         return float(L.lib().cs_clip_flops(self._h, batch, seq_len))
 
     def __call__(self, input_ids, attention_mask=None, **_ignored):
-        """-> (last_hidden_state [B, L, hidden] fp16,)   (the reference indexes [0])"""
+        """-> (last_hidden_state [B, L, hidden] fp16, pooler_output [B, hidden] fp16): the SD path indexes [0]
+        (denoise_ppo.py:31); the FLUX path reads ``.pooler_output`` of the same tower (edit_ppo/pipeline.py:330-345) = the final
+        hidden state at the end-of-text position (highest token id of each row, as transformers does)."""
         if not self._finalized:
             raise RuntimeError("weights not loaded")
         L.require_cuda(input_ids, "input_ids")
@@ -87,13 +95,14 @@ class HipCLIPTextModel:
         B, Lq = ids.shape
         out = torch.empty(B, Lq, self.config["hidden_size"], dtype=torch.float16, device=ids.device)
         if B == 0 or Lq == 0:
-            return (out,)
+            return _ClipOutput((out, out.new_empty(B, self.config["hidden_size"])))
         lib = L.lib()
         need = int(lib.cs_clip_workspace_bytes(self._h, B, Lq))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=ids.device)
         L.check(lib.cs_clip_encode(self._h, L.ptr(ids), B, Lq, L.ptr(out), L.ptr(self._ws), self._ws.numel(), L.stream_ptr(ids.device)))
-        return (out,)
+        pooled = out[torch.arange(B, device=ids.device), ids.argmax(dim=-1)]
+        return _ClipOutput((out, pooled))
 
 
 def tokenize(tokenizer, prompts, device):

@@ -14,10 +14,12 @@ import torch
 from . import _lib as L
 
 SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True)
+                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True,
+                       use_quant_conv=True, with_encoder=False)
 # FLUX.1 VAE: 16 latent channels, no quant convs, scaling / shift applied at edit_ppo/pipeline.py:623,1148
 FLUX_VAE_CONFIG = dict(latent_channels=16, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                       norm_num_groups=32, sample_size=128, scaling_factor=0.3611, shift_factor=0.1159, use_post_quant_conv=False)
+                       norm_num_groups=32, sample_size=128, scaling_factor=0.3611, shift_factor=0.1159, use_post_quant_conv=False,
+                       use_quant_conv=False, with_encoder=False)
 
 
 class HipAutoencoderKL:
@@ -35,6 +37,9 @@ class HipAutoencoderKL:
             c.block_out_channels[i] = cfg["block_out_channels"][i]
         c.layers_per_block, c.norm_num_groups, c.sample_size = cfg["layers_per_block"], cfg["norm_num_groups"], cfg["sample_size"]
         c.use_post_quant_conv = int(bool(cfg.get("use_post_quant_conv", True)))
+        c.with_encoder = int(bool(cfg.get("with_encoder", False)))
+        c.use_quant_conv = int(bool(cfg.get("use_quant_conv", True)))
+        self._ews = None
         h = C.c_void_p()
         L.check(L.lib().cs_vae_create(C.byref(c), C.byref(h)))
         self._h = h
@@ -107,6 +112,46 @@ class HipAutoencoderKL:
                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
         return out
 
+    def encode_into(self, images, out, out_scale=1.0, out_shift=0.0):
+        """images [B,3,8h,8w] in [-1,1] -> out [B,L,h,w] = (posterior mode - out_shift) * out_scale"""
+        if not self._finalized:
+            raise RuntimeError("weights not loaded")
+        if not self.config.with_encoder:
+            raise RuntimeError("this HipAutoencoderKL was created without the encoder (config with_encoder=True)")
+        L.require_cuda(images, "images")
+        x = images.to(torch.float16).contiguous()
+        B, C3, H, W = x.shape
+        S = self.config.sample_size
+        if C3 != self.config.out_channels or H != 8 * S or W != 8 * S:
+            raise ValueError(f"images {tuple(x.shape)} do not match the configured [*, 3, {8 * S}, {8 * S}]")
+        if out.shape != (B, self.config.latent_channels, S, S) or out.dtype != torch.float16 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp16 [B, L, h, w] tensor")
+        if B == 0:
+            return out
+        lib = L.lib()
+        need = int(lib.cs_vae_encode_workspace_bytes(self._h, B))
+        if self._ews is None or self._ews.numel() < need:
+            self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)
+        L.check(lib.cs_vae_encode(self._h, L.ptr(x), B, float(out_scale), float(out_shift), L.ptr(out), L.ptr(self._ews), self._ews.numel(),
+                                  L.stream_ptr(self.device)))
+        return out
+
+    def encode(self, images, return_dict=True, **_ignored):
+        """-> object with ``.latent_dist.mode()`` (= mean); ``sample()`` is not available: the path takes the argmax
+        (edit_ppo/pipeline.py:616,621 ``sample_mode="argmax"``) and the log-variance half is never computed."""
+        B = images.shape[0]
+        S = self.config.sample_size
+        mode = torch.empty(B, self.config.latent_channels, S, S, dtype=torch.float16, device=images.device)
+        self.encode_into(images, mode)
+
+        class _Dist:
+            def mode(self_inner):
+                return mode
+
+            def sample(self_inner, generator=None):
+                raise NotImplementedError("only the mode of the posterior is computed (sample_mode='argmax')")
+        return types.SimpleNamespace(latent_dist=_Dist())
+
     def decode(self, z, return_dict=False, **_ignored):
         B, _, h, w = z.shape
         out = torch.empty(B, self.config.out_channels, 8 * h, 8 * w, dtype=torch.float16, device=z.device)
@@ -129,6 +174,16 @@ def flux_decode_latents(vae, packed_latents, height=1024, width=1024, vae_scale_
         e = min(s + batch_size, N)
         vae.decode_into(lat[s:e], out[s:e], in_scale=1.0 / vae.config.scaling_factor, in_shift=vae.config.shift_factor, postprocess=True)
     return out
+
+
+def encode_image_latents(vae, image):
+    """edit_ppo/pipeline.py:613-623 ``_encode_vae_image``: ``(argmax of vae.encode(image) - shift_factor) * scaling_factor``
+    (shift and scale folded into the encoder's last kernel)."""
+    if not getattr(vae, "is_consolver_hip", False):
+        raise RuntimeError("encode_image_latents needs the HIP AutoencoderKL (no CPU fallback in the product path)")
+    B, S = image.shape[0], vae.config.sample_size
+    out = torch.empty(B, vae.config.latent_channels, S, S, dtype=torch.float16, device=image.device)
+    return vae.encode_into(image, out, out_scale=vae.config.scaling_factor, out_shift=vae.config.shift_factor)
 
 
 def decode_latents(vae, latents, batch_size=1):

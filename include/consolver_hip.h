@@ -232,6 +232,8 @@ typedef struct CsVaeConfig {
     int norm_num_groups;               /* 32                            */
     int sample_size;                   /* 64 (latent H = W); FLUX 128   */
     int use_post_quant_conv;           /* 1 (SD1.5); 0 for the FLUX VAE (16 latent channels) */
+    int with_encoder;                  /* 1: also load "encoder.*" [+ "quant_conv.*"] and enable cs_vae_encode */
+    int use_quant_conv;                /* 1 (SD1.5); 0 for the FLUX VAE */
 } CsVaeConfig;
 
 typedef struct CsVae CsVae;
@@ -252,6 +254,12 @@ double cs_vae_flops(const CsVae* v, int batch);
  * (x / 2 + 0.5).clamp(0, 1) (utils.py:29) in the last kernel. */
 int cs_vae_decode(CsVae* v, const void* latents, int batch, float in_scale, float in_shift, void* images,
                   int postprocess, void* workspace, size_t workspace_bytes, void* stream);
+/* Encoder (edit_ppo/pipeline.py:613-623, `retrieve_latents(vae.encode(image), sample_mode="argmax")`):
+ * images [batch, 3, 8h, 8w] NCHW fp16 in [-1, 1] -> latents [batch, L, h, w] fp16 =
+ * (mode of the posterior - out_shift) * out_scale   (FLUX: shift_factor, scaling_factor). */
+size_t cs_vae_encode_workspace_bytes(const CsVae* v, int batch);
+int cs_vae_encode(CsVae* v, const void* images, int batch, float out_scale, float out_shift, void* latents,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * PPO rollout consumer arithmetic (train_ppo.py:352-427)

@@ -35,11 +35,14 @@ def main():
     for name, (B, L) in {"full": (3, 77), "short": (2, 20)}.items():
         ids = torch.randint(0, 198, (B, L), generator=g)
         ids[:, 0] = 198
-        ids[:, -1] = 199                                  # eos = highest id (pooled output position; not used by the path)
+        ids[:, -1] = 199                                  # eos = highest id (pooled output position)
+        if name == "full":
+            ids[1, 40:] = 199                             # an early end-of-text followed by padding: pooled position 40
         with torch.no_grad():
-            out = m(input_ids=ids)[0]
+            res = m(input_ids=ids)
         fx[f"{name}_ids"] = ids.numpy()
-        fx[f"{name}_out"] = out.numpy()
+        fx[f"{name}_out"] = res[0].numpy()
+        fx[f"{name}_pooled"] = res.pooler_output.numpy()
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, "clip_text.npz"), **fx)
     print("clip fixtures written", {k: v.shape for k, v in fx.items() if not k.startswith("w_")})

@@ -15,7 +15,8 @@ import torch
 import torch.nn.functional as F
 
 SD15_VAE_CONFIG = dict(latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
-                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True)
+                       norm_num_groups=32, sample_size=64, scaling_factor=0.18215, shift_factor=0.0, use_post_quant_conv=True,
+                       use_quant_conv=True, with_encoder=False)
 
 
 def vae_manifest(cfg):
@@ -30,6 +31,28 @@ def vae_manifest(cfg):
         if cin != cout:
             out.extend([(p + ".conv_shortcut.weight", (cout, cin, 1, 1)), (p + ".conv_shortcut.bias", (cout,))])
 
+    if cfg.get("with_encoder", False):
+        c0 = cfg["block_out_channels"][0]
+        out.extend([("encoder.conv_in.weight", (c0, cfg["out_channels"], 3, 3)), ("encoder.conv_in.bias", (c0,))])
+        prev = c0
+        for i in range(4):
+            ch = cfg["block_out_channels"][i]
+            for j in range(cfg["layers_per_block"]):
+                res(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else ch, ch)
+            if i < 3:
+                out.extend([(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight", (ch, ch, 3, 3)),
+                            (f"encoder.down_blocks.{i}.downsamplers.0.conv.bias", (ch,))])
+            prev = ch
+        res("encoder.mid_block.resnets.0", top, top)
+        a = "encoder.mid_block.attentions.0"
+        out.extend([(a + ".group_norm.weight", (top,)), (a + ".group_norm.bias", (top,))])
+        for q in (".to_q", ".to_k", ".to_v", ".to_out.0"):
+            out.extend([(a + q + ".weight", (top, top)), (a + q + ".bias", (top,))])
+        res("encoder.mid_block.resnets.1", top, top)
+        out.extend([("encoder.conv_norm_out.weight", (top,)), ("encoder.conv_norm_out.bias", (top,)),
+                    ("encoder.conv_out.weight", (2 * L, top, 3, 3)), ("encoder.conv_out.bias", (2 * L,))])
+        if cfg.get("use_quant_conv", True):
+            out.extend([("quant_conv.weight", (2 * L, 2 * L, 1, 1)), ("quant_conv.bias", (2 * L,))])
     if cfg.get("use_post_quant_conv", True):
         out.extend([("post_quant_conv.weight", (L, L, 1, 1)), ("post_quant_conv.bias", (L,))])
     out.extend([("decoder.conv_in.weight", (top, L, 3, 3)), ("decoder.conv_in.bias", (top,))])
@@ -94,6 +117,27 @@ class VaeOracle:
         return x + a.transpose(1, 2).reshape(B, C, H, W)
 
     @torch.no_grad()
+    def encode_mode(self, x):
+        """mode (= mean) of ``vae.encode(x).latent_dist``: conv_in, four down blocks (two resnets each; pad (0,1,0,1) + 3x3
+        stride-2 conv after the first three), mid block, GroupNorm + SiLU, conv_out -> 2L moments [-> quant_conv] -> first L."""
+        sd = self.sd
+        h = F.conv2d(x.float(), sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+        for i in range(4):
+            for j in range(self.cfg["layers_per_block"]):
+                h = self._resnet(h, f"encoder.down_blocks.{i}.resnets.{j}")
+            if i < 3:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+        h = self._resnet(h, "encoder.mid_block.resnets.0")
+        h = self._attn(h, "encoder.mid_block.attentions.0")
+        h = self._resnet(h, "encoder.mid_block.resnets.1")
+        h = self._gn(h, "encoder.conv_norm_out", True)
+        m = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+        if "quant_conv.weight" in sd:
+            m = F.conv2d(m, sd["quant_conv.weight"], sd["quant_conv.bias"])
+        return m[:, :self.cfg["latent_channels"]]
+
+    @torch.no_grad()
     def decode(self, z, return_dict=False):
         sd = self.sd
         z = z.float()
@@ -129,3 +173,8 @@ def flux_decode_latents(vae, latents_unpacked):
     """edit_ppo/utils.py:22-25 after the unpack: latents / scaling_factor + shift_factor -> decode -> [0, 1]."""
     z = latents_unpacked / vae.config.scaling_factor + vae.config.shift_factor
     return (vae.decode(z, return_dict=False)[0] / 2 + 0.5).clamp(0, 1)
+
+
+def encode_image_latents(vae, image):
+    """edit_ppo/pipeline.py:613-623: (argmax of the posterior - shift_factor) * scaling_factor."""
+    return (vae.encode_mode(image) - vae.config.shift_factor) * vae.config.scaling_factor

@@ -31,8 +31,10 @@ def test_reduced_clip_matches_transformers_golden(golden):
     m.load_state_dict(sd)
     for name in ("full", "short"):
         ids = torch.from_numpy(np.asarray(g[f"{name}_ids"])).to(DEV)
-        out = m(ids)[0]
+        res = m(ids)
+        out = res[0]
         assert out.dtype == torch.float16 and out.shape == g[f"{name}_out"].shape
+        assert res.last_hidden_state is out and rel_l2(res.pooler_output.float().cpu().numpy(), g[f"{name}_pooled"]) < 5e-3
         err = rel_l2(out.float().cpu().numpy(), g[f"{name}_out"])
         print("clip reduced", name, err)
         assert err < 5e-3, err

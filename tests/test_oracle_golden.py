@@ -261,5 +261,8 @@ def test_clip_text_oracle_vs_transformers(golden):
         assert tuple(sd[n].shape) == shape
     orc = ClipTextOracle(sd, cfg, round_weights_to_f16=False)
     for name in ("full", "short"):
-        out = orc(torch.from_numpy(np.asarray(g[f"{name}_ids"])))[0].numpy()
+        ids = torch.from_numpy(np.asarray(g[f"{name}_ids"]))
+        out = orc(ids)[0].numpy()
         assert rel_l2(out, g[f"{name}_out"]) < 2e-6
+        pooled = out[np.arange(ids.shape[0]), ids.numpy().argmax(-1)]            # end-of-text position
+        assert rel_l2(pooled, g[f"{name}_pooled"]) < 2e-6

@@ -109,3 +109,32 @@ def test_flux_vae_16_channel_latents_and_long_softmax_rows():
     got2 = v2.decode(lat2.to(DEV))[0]
     want2 = orc2.decode(lat2.float())[0]
     assert rel_l2(got2, want2) < 5e-3
+
+
+@pytest.mark.parametrize("flavour", ["sd", "flux"])
+def test_vae_encoder_mode_matches_oracle(flavour):
+    """edit_ppo/pipeline.py:613-623 ``_encode_vae_image`` (argmax of the posterior, shift, scale): reduced depth, 128 x 128 images;
+    SD flavour (4 latent channels, quant_conv mixes the 8 moments) and FLUX flavour (16 channels, no quant convs);
+    then encode -> decode through the same handle."""
+    from consolver_amd.vae import encode_image_latents, FLUX_VAE_CONFIG, SD15_VAE_CONFIG
+    base = dict(SD15_VAE_CONFIG if flavour == "sd" else FLUX_VAE_CONFIG)
+    base.update(layers_per_block=1, sample_size=16, with_encoder=True)
+    v, orc = build(base, seed=31)
+    g = torch.Generator().manual_seed(8)
+    img = (torch.rand(3, 3, 128, 128, generator=g) * 2 - 1).half()
+    got = encode_image_latents(v, img.to(DEV))
+    want = vae_oracle.encode_image_latents(orc, img.float())
+    assert got.shape == (3, base["latent_channels"], 16, 16) and got.dtype == torch.float16
+    err = rel_l2(got, want)
+    print(flavour, "vae encoder rel l2", err)
+    assert err < 5e-3, err
+    mode = v.encode(img.to(DEV)).latent_dist.mode()
+    assert rel_l2(mode, orc.encode_mode(img.float())) < 5e-3
+    rec = v.decode(mode)[0]
+    assert rec.shape == (3, 3, 128, 128) and rel_l2(rec, orc.decode(mode.float().cpu())[0]) < 5e-3
+    with pytest.raises(NotImplementedError):
+        v.encode(img.to(DEV)).latent_dist.sample()
+    plain = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
+    plain.load_state_dict(synthetic_vae_state_dict(plain.manifest(), seed=1))
+    with pytest.raises(RuntimeError):
+        plain.encode(img.to(DEV))
