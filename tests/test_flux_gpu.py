@@ -3,6 +3,8 @@ oracle restatement (parity unpinned w.r.t. diffusers, see oracle/flux_oracle.py)
 
 Tolerance: bf16 storage (8-bit mantissa, eps 3.9e-3) of every activation through the blocks -> relative L2 of the
 velocity output <= 3e-2 for the reduced model in bf16, <= 6e-3 in f16 (stated here: looser than the solver gate)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -104,3 +106,55 @@ def test_flux_edit_loop_with_fmppo_scheduler():
     assert probs.shape == actions.shape == masks.shape == (1, 3, 1) and float(masks.min()) == 1.0
     sig = sch.sigmas.cpu()
     assert torch.allclose(conds["x"][0, :, 0].float().cpu(), sig[1:4].to(torch.bfloat16).float())      # bf16-rounded sigmas
+
+
+def test_flux_edit_driver_writes_the_reference_layout(tmp_path):
+    """edit_ppo/generate_ours.py end to end on reduced networks: JSONL entry -> VAE-encoded reference image -> 4-step FMPPO edit ->
+    VAE decode -> OUTPUT/<category>/<key>/{ref_image.jpg, instruction.txt, edited_image.jpg}; missing reference images are skipped;
+    the edited image equals decode(engine(encode(reference))) recomputed by hand."""
+    from PIL import Image
+    from safetensors import safe_open
+    from consolver_amd import generate_flux as gf
+    from consolver_amd.vae import HipAutoencoderKL, FLUX_VAE_CONFIG, encode_image_latents, flux_decode_latents
+    from consolver_amd.synth import synthetic_vae_state_dict
+    cfg = dict(SMALL, dtype=torch.bfloat16)
+    m = HipFluxTransformer2DModel(cfg, device=DEV)
+    m.load_state_dict(synthetic_flux_state_dict(m.manifest(), seed=4))
+    sch = consolver_amd.FMPPOScheduler.from_pretrained("x", subfolder="scheduler", order_dim=2, scaler_dim=0, mu_dim=0,
+                                                       factor_net_kwargs=dict(hidden_dim=64, num_actions=11))
+    sch.factor_net.to(DEV)
+    sch.factor_net.forced_action_idx = torch.zeros(1, 1, dtype=torch.long, device=DEV) + 3       # deterministic policy for the replay below
+    eng = FluxKontextSamplingEngine(m, sch, guidance_scale=2.5)
+    vcfg = dict(FLUX_VAE_CONFIG); vcfg.update(layers_per_block=1, sample_size=16, with_encoder=True)
+    vae = HipAutoencoderKL(vcfg, device=DEV)
+    vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=9))
+    img_dir, out_dir = tmp_path / "imgs", tmp_path / "out"
+    os.makedirs(img_dir)
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (96, 160, 3), dtype=np.uint8)).save(img_dir / "a.jpg")
+    entries = [dict(key="k1", category="style change", file_name="some/dir/a.jpg", instruction="make it red"),
+               dict(key="k2", category="x", file_name="missing.jpg", instruction="nothing")]
+    g = torch.Generator().manual_seed(5)
+    embeds = {e["key"]: (torch.randn(64, 256, generator=g), torch.randn(768, generator=g)) for e in entries}
+    gf.save_instruction_cache(str(tmp_path / "emb.safetensors"), embeds)
+    n = gf.worker(entries, eng, vae, str(tmp_path / "emb.safetensors"), str(img_dir), str(out_dir), torch.device(DEV), num_inference_steps=4)
+    assert n == 1
+    sub = out_dir / "style_change" / "k1"
+    assert sorted(os.listdir(sub)) == ["edited_image.jpg", "instruction.txt", "ref_image.jpg"]
+    assert open(sub / "instruction.txt").read() == "make it red" and not (out_dir / "x").exists()
+    edited = np.asarray(Image.open(sub / "edited_image.jpg").convert("RGB"))
+    assert edited.shape == (128, 128, 3)
+    # replay by hand
+    image = gf.preprocess_image(str(img_dir / "a.jpg"), 128).to(DEV, torch.float16)
+    il = pack_latents(encode_image_latents(vae, image)).to(torch.bfloat16)
+    noise = torch.randn(1, 16, 16, 16, generator=torch.Generator().manual_seed(0)).to(DEV)
+    with safe_open(str(tmp_path / "emb.safetensors"), framework="pt", device="cpu") as cache:
+        pe, pooled = gf.load_instruction_embeds(cache, "k1", torch.device(DEV))
+    out = eng.generate(pack_latents(noise).to(torch.bfloat16), il, pe, pooled, latent_hw=(8, 8), num_inference_steps=4)
+    want = flux_decode_latents(vae, out.to(torch.float16), height=128, width=128)[0]
+    want8 = (want.float().clamp(0, 1).permute(1, 2, 0) * 255).round().to(torch.uint8).cpu().numpy()
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(want8).save(buf, format="JPEG")                          # the same lossy step the driver applies
+    via_jpeg = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    assert np.abs(edited.astype(np.float32) - via_jpeg.astype(np.float32)).mean() < 1.0

@@ -199,3 +199,26 @@ def test_evaluation_harness_files_pairs_statistics(tmp_path):
     assert st["clip"] == {"mean": 0.0, "std": 0.0, "min": 0.0, "max": 0.0, "median": 0.0, "count": 0}
     out = ev.write_results(str(tmp_path / "r.json"), {"image_psnr": [1.0, 2.0]}, {"dir1": "a", "dir2": "b", "num_pairs": 2})
     assert sorted(json.load(open(tmp_path / "r.json")).keys()) == ["config", "raw_scores", "statistics"] and out["statistics"]["image_psnr"]["count"] == 2
+
+
+def test_flux_driver_host_logic(tmp_path):
+    """edit_ppo/generate_ours.py: JSONL loading (invalid lines skipped), ceil chunking, unique paths, folder names"""
+    from consolver_amd import generate_flux as gf
+    from oracle import solver_oracle as so
+    p = tmp_path / "d.jsonl"
+    p.write_text('{"key": "a", "category": "c/1", "file_name": "x.jpg", "instruction": "i"}\nnot json\n{"key": "b", "category": "c", "file_name": "y.jpg", "instruction": "j"}\n')
+    data = gf.load_jsonl(str(p))
+    assert [e["key"] for e in data] == ["a", "b"]
+    for n, world in [(10, 4), (7, 8), (16, 8), (0, 4), (5, 1)]:
+        chunks = gf.chunk_entries(list(range(n)), world)
+        assert sum(chunks, []) == list(range(n)) and len(chunks) <= world
+        for r in range(world):
+            lo, hi = so.shard_bounds_ceil(n, world, r)
+            assert gf.shard_for_rank(list(range(n)), world, r) == list(range(lo, hi))
+    assert gf.sanitize_folder_name(" style/change: x-1 ") == "style_change__x_1" and gf.sanitize_folder_name("") == "Unknown"
+    f = tmp_path / "edited_image.jpg"
+    assert gf.ensure_unique_path(str(f)) == str(f)
+    f.write_text("x")
+    assert gf.ensure_unique_path(str(f)).endswith("edited_image_1.jpg")
+    (tmp_path / "edited_image_1.jpg").write_text("x")
+    assert gf.ensure_unique_path(str(f)).endswith("edited_image_2.jpg")
