@@ -73,3 +73,13 @@ def gather_report(dist, count, checksum, device="cpu"):
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return [(int(o[0].item()), float(o[1].item())) for o in out]
+
+
+def average_gradients(dist, grads):
+    """What DistributedDataParallel does to the policy's gradients in the PPO trainer (train_ppo.py:262-266, 8 ranks x 75 k
+    parameters = one ~300 KB all-reduce): sum over ranks / world size, in place on the packed gradient vector."""
+    if dist is None:
+        return grads
+    dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+    grads.div_(dist.get_world_size())
+    return grads

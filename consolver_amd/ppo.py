@@ -172,9 +172,14 @@ class PolicyTrainer:
                                         self._ws.numel(), L.stream_ptr(x.device)))
         return self._out[0]
 
-    def step(self, conds, actions, old_probs, advantages):
-        """one PPO epoch iteration (train_ppo.py:408-437) -> (loss, total grad norm before clipping), both 0-d tensors."""
+    def step(self, conds, actions, old_probs, advantages, dist=None):
+        """one PPO epoch iteration (train_ppo.py:408-437) -> (loss, total grad norm before clipping), both 0-d tensors.
+        ``dist``: a torch.distributed module whose default group spans the data-parallel ranks; the local gradients are then
+        averaged over the ranks before clipping, which is what DDP does for the reference (one ~300 KB all-reduce over RCCL)."""
         loss = self.compute_grads(conds, actions, old_probs, advantages).clone()
+        if dist is not None:
+            from .launch import average_gradients
+            average_gradients(dist, self.grads)
         lib, st = L.lib(), L.stream_ptr(self.grads.device)
         L.check(lib.cs_clip_grad_norm(L.ptr(self.grads), self.grads.numel(), self.max_grad_norm, L.ptr(self._out[1:]), st))
         self.step_count += 1
@@ -201,3 +206,22 @@ class PolicyTrainer:
             for k, v in self.net.state_dict().items():
                 v.copy_(sd[k].to(v.device, v.dtype))
         return self
+
+
+def train_iteration(trainer, text_encoder, noise_scheduler, unet, vae, batch, tokenizer, cfg=3.0, num_inference_steps=None, ppo_epochs=4,
+                    reward_type="image_psnr", dist=None, prompt_embeds=None, negative_prompt_embeds=None, rng=None):
+    """One iteration of the training loop body (train_ppo.py:322-437): ``repeat_random_sample`` -> random step count in [2, 15]
+    (:345) -> rollout, decode, reward, advantages (``collect_rollout``) -> ``ppo_epochs`` optimisation steps on the collected
+    batch.  ``batch`` = (text list, noise [B,4,64,64], teacher latents [B,4,64,64]) already on the GPU.
+    Returns dict(loss, norm, reward, num_inference_steps)."""
+    import random
+    from .ppo_data import repeat_random_sample
+    rng = rng or random
+    text, noise, tch = repeat_random_sample(batch)
+    n = num_inference_steps or rng.choice(list(range(2, 16)))
+    roll = collect_rollout(text_encoder, noise_scheduler, unet, vae, noise, text, tokenizer, tch, cfg=cfg, num_inference_steps=n,
+                           reward_type=reward_type, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+    loss = norm = None
+    for _ in range(ppo_epochs):
+        loss, norm = trainer.step(roll["conds"], roll["actions"], roll["probs"], roll["advantages"], dist=dist)
+    return dict(loss=loss, norm=norm, reward=roll["rewards"].mean(), num_inference_steps=n)

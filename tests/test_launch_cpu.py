@@ -46,6 +46,8 @@ dist.barrier()
 t = launch.reduce_max_seconds(dist, 1.0 + rank)
 rep = launch.gather_report(dist, hi - lo, float(sum(range(lo, hi))))
 assert t == 2.0, t
+g = launch.average_gradients(dist, torch.arange(6, dtype=torch.float32) * (rank + 1))      # DDP-style mean of the policy gradients
+assert torch.equal(g, torch.arange(6, dtype=torch.float32) * 1.5), g
 assert sum(c for c, _ in rep) == 37 and sum(s for _, s in rep) == sum(range(37)), rep
 dist.barrier()
 dist.destroy_process_group()

