@@ -440,10 +440,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
 // layers were bound by L2->LDS traffic (the activation panel was re-staged N/160 times), not MFMA.
 // Two LDS stages (144 KB), one workgroup per CU, 9 DMA issues per wave per 80 MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <bool GEGLU>
+template <bool GEGLU, int BNX>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
-    constexpr int BMX = 256, BNX = 320, NT = 10, MT = 4;
+    // BNX = 320: wave tile 64 x 160 (every SD1.5 width >= 320 with enough rows); BNX = 160: wave tile 64 x 80 for the 1280-wide layers
+    // at 16 x 16 (M = 8192: 32 x 8 = 256 tiles = one per CU, where 256 x 320 tiles would leave half the chip idle)
+    constexpr int BMX = 256, NT = BNX / 32, NH = NT / (NT % 2 == 0 ? 2 : 1), MT = 4, NBP = BNX / 8;
     constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int BPW = (NBP + 7) / 8;                       // weight-tile DMA pieces per wave (40 -> 5; 20 -> 3 for waves 0-3, 2 for 4-7)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -466,10 +469,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         a_chunk[j] = (pch ^ ((r >> 1) & 7)) * 8;
         a_row[j] = (m < p.M) ? m : -1;
     }
-    const f16* b_src[5];
+    const f16* b_src[BPW];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int r = 8 * (w * 5 + j) + (lane >> 3);
+    for (int j = 0; j < BPW; ++j) {
+        const int q = w + 8 * j;                             // piece index; pieces >= NBP are never issued
+        const int r = 8 * (q < NBP ? q : 0) + (lane >> 3);
         b_src[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 7)) * 8;
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
@@ -486,9 +490,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
             const uintptr_t msk = (uintptr_t)0 - (uintptr_t)ok;
             glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), la + j * 1024);
         }
-        char* lb = smem + buf * STAGE + A_BYTES + (w * 5) * 1024;
+        char* lb = smem + buf * STAGE + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
+        for (int j = 0; j < BPW; ++j)
+            if (NBP % 8 == 0 || w + 8 * j < NBP) glds16(b_src[j] + (size_t)kt * BK, lb + (w + 8 * j) * 1024);
     };
 
     f32x4 acc[NT][MT];
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         const int buf = kt & 1;
         if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
-        const char* tb = smem + buf * STAGE + A_BYTES + (wn * 160) * 128;
+        const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? frag_off1 : frag_off0;
@@ -518,23 +523,23 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
 #pragma unroll
             for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                f16x8 fw[5];
+            for (int half = 0; half < NT / NH; ++half) {
+                f16x8 fw[NH];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+                for (int i = 0; i < NH; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * NH + i) * 2048 + fo);
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                for (int i = 0; i < NH; ++i)
 #pragma unroll
                     for (int j = 0; j < MT; ++j)
-                        acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+                        acc[half * NH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * NH + i][j], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
-    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, 10>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
-    else igemm_epilogue<GEGLU, NT, MT, 10, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * 160, lane, smem + w * 11264);
+    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, (BNX == 320 ? 2 : 1)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -776,12 +781,27 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
             constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
             static bool configured = false;
             if (!configured) {
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            if (a.geglu) hipLaunchKernelGGL(gemm_big_kernel<true>, dim3(p.nblk), dim3(512), lds, s, p);
-            else hipLaunchKernelGGL(gemm_big_kernel<false>, dim3(p.nblk), dim3(512), lds, s, p);
+            if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320>), dim3(p.nblk), dim3(512), lds, s, p);
+            else hipLaunchKernelGGL((gemm_big_kernel<false, 320>), dim3(p.nblk), dim3(512), lds, s, p);
+            CS_CHECK_LAUNCH();
+            return CS_OK;
+        }
+    }
+    if (g_tune_biggemm && !conv3 && !a.geglu && a.N % 160 == 0) {       // too few 256 x 320 tiles: 256 x 160 tiles, same 8-wave structure
+        const int tiles_m = (p.M + 255) / 256, tn = a.N / 160;
+        if (tiles_m * tn >= 192 || g_tune_biggemm == 3) {
+            p.tiles_n = tn; p.nblk = tiles_m * tn;
+            constexpr size_t lds = 2 * (256 * BK * 2 + 160 * BK * 2);
+            static bool configured = false;
+            if (!configured) {
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                configured = true;
+            }
+            hipLaunchKernelGGL((gemm_big_kernel<false, 160>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();
             return CS_OK;
         }

@@ -173,6 +173,19 @@ def test_linear_big_tile_kernel(M, K, N, geglu):
     assert rel_l2(out.float(), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("M,K,N", [(256, 64, 160), (1000, 320, 480), (8192, 1280, 1280), (513, 128, 1280)])
+def test_linear_big_tile_kernel_160(M, K, N):
+    """256x160 variant of the 8-wave kernel (the 1280-wide layers at 16x16), forced on small and ragged shapes"""
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.2), rnd(M, N, seed=4)
+    ops.set_tuning("gemm_big", 3)
+    try:
+        out = ops.linear(x, w, b, res=r)
+    finally:
+        ops.set_tuning("gemm_big", 1)
+    ref = F.linear(x.float(), w.float(), b.float()) + r.float()
+    assert rel_l2(out.float(), ref) < 1.5e-3
+
+
 @pytest.mark.parametrize("M,C", [(128, 64), (300, 320), (64, 1280)])
 def test_linear_geglu(M, C):
     x = rnd(M, C, seed=1)
