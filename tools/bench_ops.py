@@ -60,6 +60,10 @@ if which in ("all", "conv"):
 if which in ("all", "attn"):
     attn(4096, 320, tag="self L0"); attn(1024, 640, tag="self L1"); attn(256, 1280, tag="self L2"); attn(64, 1280, tag="self L3")
     attn(4096, 320, 77, tag="cross L0")
+    # FLUX shape (dh 128, 24 heads, 8704 tokens), f16 instance of the kernel the bf16 DiT uses
+    qf, kf, vf = rnd(1, 8704, 3072), rnd(1, 8704, 3072), rnd(1, 8704, 3072)
+    ms = timeit(lambda: ops.attention(qf, kf, vf, 24))
+    rows.append(("attention dh=128 FLUX", 8704, 8704, 3072, ms, 4.0 * 8704 * 8704 * 3072 / ms / 1e9))
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
 for r in rows:
     print(f"{r[0]:40s} {r[1]:8d} {r[2]:8d} {r[3]:6d} {r[4]:9.3f} {r[5] / 1e3:9.1f}")
