@@ -43,6 +43,7 @@ struct IgemmParams {
     int Ktot;            // row length of w
     const f16* w; const f16* bias; const f16* temb; int temb_stride; const f16* res; f16* out;
     int tiles_n, nblk;
+    float* partial;     // split-K scratch of the generic kernel ([splits][M][N] fp32) or null
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
 };
 
@@ -639,13 +640,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;        // ks = 0
     const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;    // ks = 1
 
-    stage(0, 0);
+    // split-K (gridDim.y > 1): this workgroup covers k-steps [kt0, kt1) and leaves raw fp32 partial sums for splitk_reduce_kernel
+    const int ksplit = gridDim.y, kper = p.KT / ksplit, kt0 = blockIdx.y * kper, kt1 = kt0 + kper;
+    stage(kt0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int kt = 0; kt < p.KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
         const char* ta = lA + buf * A_BYTES + (wm * 64) * 128;
         const char* tb = lB + buf * B_BYTES + (wn * (BN / 2)) * 128;
 #pragma unroll
@@ -666,11 +669,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
+    if (ksplit > 1) {
+        float* dst = p.partial + (size_t)blockIdx.y * p.M * p.N;
+        const int g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m_blk + wm * 64 + j * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * p.N + n_blk + wn * (BN / 2) + i * 16 + g * 4) = acc[i][j];
+        }
+        return;
+    }
     igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
-int launch_variant(const IgemmParams& p, hipStream_t s) {
+int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
     constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
     static bool configured = false;
     auto kfn = igemm_kernel<BN, CONV3, GEGLU>;
@@ -678,8 +694,14 @@ int launch_variant(const IgemmParams& p, hipStream_t s) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(p.nblk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kfn, dim3(p.nblk, splits), dim3(256), lds, s, p);
     CS_CHECK_LAUNCH();
+    if (splits > 1) {
+        const long total = (long)p.M * (p.N / 8);
+        int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid2), dim3(256), 0, s, p, (const float*)p.partial, splits);
+        CS_CHECK_LAUNCH();
+    }
     return CS_OK;
 }
 
@@ -709,7 +731,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (a.pad_after_only && !(a.taps == 9 && a.stride == 2)) CS_FAIL(CS_E_ARG, "igemm: pad_after_only is the stride-2 3x3 form");
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
-    p.debug = g_tune_debug;
+    p.debug = g_tune_debug; p.partial = nullptr;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
     if (a.N % 128 == 0) bn = 128;
@@ -809,6 +831,13 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (a.geglu) {
         return launch_variant<128, false, true>(p, s);
     }
-    if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s) : launch_variant<128, false, false>(p, s);
-    return conv3 ? launch_variant<160, true, false>(p, s) : launch_variant<160, false, false>(p, s);
+    // few tiles and a long k loop (stride-2 convs into the 16 x 16 / 8 x 8 levels, the 8 x 8 linears): split K to fill the chip
+    int splits = 1;
+    if (a.splitk_ws && !a.geglu && p.nblk < 192) {
+        while (splits < 8 && p.nblk * splits < 256 && p.KT % (splits * 2) == 0 && p.KT / (splits * 2) >= 8 &&
+               (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
+        if (splits > 1) p.partial = a.splitk_ws;
+    }
+    if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
+    return conv3 ? launch_variant<160, true, false>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
 }

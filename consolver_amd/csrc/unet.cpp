@@ -305,6 +305,7 @@ struct Run {
     void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, const f16* res, f16* out, int geglu) {
         IgemmArgs a{};
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res; a.out = out; a.geglu = geglu;
+        a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * (res ? 2 : 1));
         launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
