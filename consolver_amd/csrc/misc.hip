@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const f16* __restric
     }
 }
 
-// conv_in: thread = (pixel, 8 output channels).  weights [Cout][9][Cin] staged in LDS as [9*Cin][Cout].
+// conv_in: thread = output pixel: its 3x3xCIN input patch is loaded ONCE into registers (the (pixel, 8-channel) mapping it replaces
+// re-read every input value Cout/8 times and was bound by those scalar loads), then the thread walks the output channels 8 at a time
+// against the weights [9*CIN][Cout] staged in LDS (wave-uniform addresses: broadcast reads) and stores 16 bytes per group.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ lat, int n_lat, int B, int H, int W,
                                                       const f16* __restrict__ w, const f16* __restrict__ bias, int Cout,
@@ -56,32 +58,35 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ la
     }
     __syncthreads();
     const int NG = Cout >> 3;
-    const long total = (long)B * H * W * NG;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ng = (int)(i % NG);
-        const long m = i / NG;
+    const long total = (long)B * H * W;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (long)gridDim.x * blockDim.x) {
         const int xo = (int)(m % W), yo = (int)((m / W) % H), b = (int)(m / ((long)W * H));
         const f16* src = lat + (size_t)(b % n_lat) * CIN * H * W;
-        float acc[8];
-        const f16x8 bv = *reinterpret_cast<const f16x8*>(bias + ng * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = (float)bv[k];
+        float patch[KK];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yi = yo + tap / 3 - 1, xi = xo + tap % 3 - 1;
-            if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+            const bool ok = yi >= 0 && yi < H && xi >= 0 && xi < W;
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) {
-                const float v = (float)src[((size_t)c * H + yi) * W + xi];
-                const f16x8 wv = *reinterpret_cast<const f16x8*>(ws + (tap * CIN + c) * Cout + ng * 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] += v * (float)wv[k];
-            }
+            for (int c = 0; c < CIN; ++c) patch[tap * CIN + c] = ok ? (float)src[((size_t)c * H + yi) * W + xi] : 0.f;
         }
-        f16x8 o;
+        f16* o = out + (size_t)m * Cout;
+        for (int ng = 0; ng < NG; ++ng) {
+            float acc[8];
+            const f16x8 bv = *reinterpret_cast<const f16x8*>(bias + ng * 8);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
-        *reinterpret_cast<f16x8*>(out + (size_t)m * Cout + ng * 8) = o;
+            for (int k = 0; k < 8; ++k) acc[k] = (float)bv[k];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const f16x8 wv = *reinterpret_cast<const f16x8*>(ws + kk * Cout + ng * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += patch[kk] * (float)wv[k];
+            }
+            f16x8 r;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = (f16)acc[k];
+            *reinterpret_cast<f16x8*>(o + ng * 8) = r;
+        }
     }
 }
 
@@ -396,7 +401,7 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
     if (!lat || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_in: null pointer");
     if (Cin != 4 || Cout % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_in: built for 4 input channels (got %d)", Cin);
     if (B <= 0) return CS_OK;
-    const long total = (long)B * H * W * (Cout / 8);
+    const long total = (long)B * H * W;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(conv_in_kernel<4>, dim3(grid), dim3(256), (size_t)36 * Cout * sizeof(f16), s, lat, n_lat, B, H, W, w, bias, Cout, out);
     CS_CHECK_LAUNCH();
