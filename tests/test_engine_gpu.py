@@ -154,3 +154,35 @@ def test_generate_imgs_driver_writes_sharded_files(tmp_path):
     assert torch.equal(noise, gen.prepare_latents(3, (4, 16, 16), seed + 1, torch.device(DEV)))
     img = ev.load_image_tensor(str(tmp_path / "1_00000004.png"), "cpu")
     assert img.shape == (3, 128, 128) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and float(img.std()) > 0.01
+
+
+def test_pipeline_call_surface():
+    """gen_ppo.py:289-312 call: pipeline(prompt_embeds=..., num_inference_steps, generator, guidance_scale, height, width).images"""
+    from consolver_amd.pipeline import ConsistencySolverPipeline
+    from consolver_amd.vae import HipAutoencoderKL
+    from consolver_amd.synth import synthetic_vae_state_dict
+    unet, sd, sch, w = make(dict(layers_per_block=1, sample_size=16))
+    vae = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
+    vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=3))
+    pipe = ConsistencySolverPipeline(unet, sch, vae)
+    B = 2
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half().to(DEV), synthetic_prompt_embeds(B, seed=1002).half().to(DEV)
+    idx = [torch.zeros(B, 3, dtype=torch.long, device=DEV) + 4 for _ in range(3)]
+    gen = torch.Generator(device=DEV).manual_seed(43)
+    pipe.scheduler.factor_net.forced_action_idx = list(idx)
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=3, generator=gen, guidance_scale=3.0, height=128, width=128)
+    assert len(out.images) == B and out.images[0].size == (128, 128)
+    gen = torch.Generator(device=DEV).manual_seed(43)
+    pipe.scheduler.factor_net.forced_action_idx = list(idx)
+    pt = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=3, generator=gen, guidance_scale=3.0, output_type="pt").images
+    assert pt.shape == (B, 3, 128, 128)
+    assert np.array_equal(np.asarray(out.images[1]), (pt[1].float().clamp(0, 1).permute(1, 2, 0) * 255).round().to(torch.uint8).cpu().numpy())
+    gen = torch.Generator(device=DEV).manual_seed(43)
+    pipe.scheduler.factor_net.forced_action_idx = list(idx)
+    lat = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=3, generator=gen, guidance_scale=3.0, output_type="latent").images
+    from consolver_amd.vae import decode_latents
+    assert torch.equal(decode_latents(vae, lat, B), pt)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, negative_prompt_embeds=ne, height=512, width=512)
+    with pytest.raises(RuntimeError):
+        pipe(prompt="a cat")
