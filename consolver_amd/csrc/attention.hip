@@ -29,6 +29,7 @@ struct AttnParams {
     int q_stride, k_stride, v_stride, out_stride;
     int H, Nq, Nk;
     float c;   // scale * log2(e)
+    const float* bias;   // [H][Nq][Nk] fp32, times log2(e), or null
 };
 
 typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -52,7 +53,7 @@ __device__ __forceinline__ float xor32_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int DH, int QT, bool CAUSAL>
+template <typename T, int DH, int QT, bool CAUSAL, bool BIAS>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     typedef typename El<T>::frag frag;
     constexpr int DK = (DH + 31) / 32 * 32;
@@ -196,6 +197,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
                     s[kt][t] = El<T>::mfma(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t]);
+            }
+        }
+        if (BIAS) {     // T5 relative-position bias: four consecutive keys of one query per load
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                const int qi = q0 + t * 16 + i16;
+                const float* brow = p.bias + ((size_t)h * p.Nq + (qi < p.Nq ? qi : 0)) * p.Nk + tile * 64 + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    if (tile * 64 + kt * 16 + 4 * g + 3 < p.Nk) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + kt * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kt][t][r] += bv[r];
+                    }
+                }
             }
         }
         if (CAUSAL) {   // text-encoder attention: key j is visible to query i iff j <= i (Nq == Nk)
@@ -356,13 +372,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <typename T, int DH, int QT, bool CAUSAL = false>
+template <typename T, int DH, int QT, bool CAUSAL = false, bool BIAS = false>
 int launch_attn(const AttnParams& p, int B, hipStream_t s) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
     constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
     constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
-    auto kfn = attn_kernel<T, DH, QT, CAUSAL>;
+    auto kfn = attn_kernel<T, DH, QT, CAUSAL, BIAS>;
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -386,6 +402,12 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     p.q_stride = a.q_stride; p.k_stride = a.k_stride; p.v_stride = a.v_stride; p.out_stride = a.out_stride;
     p.H = a.H; p.Nq = a.Nq; p.Nk = a.Nk;
     p.c = a.scale * 1.4426950408889634f;
+    p.bias = a.bias;
+    if (a.bias) {
+        if (a.dh != 64 || a.causal || a.Nk % 4) CS_FAIL(CS_E_UNSUPPORTED, "attention: the biased form is built for head dim 64, no mask, Nk %% 4 == 0");
+        if (a.dtype == CS_BF16) return launch_attn<bf16_el, 64, 2, false, true>(p, a.B, s);
+        return launch_attn<f16, 64, 2, false, true>(p, a.B, s);
+    }
     if (a.causal) {
         if (a.dh != 64 || a.dtype == CS_BF16 || a.Nq != a.Nk) CS_FAIL(CS_E_UNSUPPORTED, "attention: the causal form is built for f16, head dim 64, Nq == Nk");
         return launch_attn<f16, 64, 2, true>(p, a.B, s);

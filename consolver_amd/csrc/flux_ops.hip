@@ -129,6 +129,65 @@ __global__ void add3_kernel(const float* a, const float* b, const float* c, floa
     if (i < n) out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
 }
 
+
+// T5LayerNorm: y = x * rsqrt(mean(x^2) + eps) * w   (no mean subtraction, no bias); one wave per row, row in registers
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const u16* __restrict__ x, const u16* __restrict__ wt, u16* __restrict__ y, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + w;
+    if (row >= M) return;
+    const int CV = C >> 3;
+    float v[MAXV][8];
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const u32x4 t = *reinterpret_cast<const u32x4*>(x + (size_t)row * C + cv * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[j][2 * k] = El<T>::tof((u16)(t[k] & 0xffff)); v[j][2 * k + 1] = El<T>::tof((u16)(t[k] >> 16)); }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sq += v[j][k] * v[j][k];
+        }
+    }
+    const float r = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int cv = lane + 64 * j;
+        if (cv < CV) {
+            const u32x4 g = *reinterpret_cast<const u32x4*>(wt + cv * 8);
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[2 * k] = v[j][2 * k] * r * El<T>::tof((u16)(g[k] & 0xffff));
+                o[2 * k + 1] = v[j][2 * k + 1] * r * El<T>::tof((u16)(g[k] >> 16));
+            }
+            const u32x4 pk = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
+            *reinterpret_cast<u32x4*>(y + (size_t)row * C + cv * 8) = pk;
+        }
+    }
+}
+
+template <typename T> __global__ void gated_mul_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ out, long nv) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    const u32x4 x = *reinterpret_cast<const u32x4*>(a + i * 8), y = *reinterpret_cast<const u32x4*>(b + i * 8);
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = pack2<T>(El<T>::tof((u16)(x[k] & 0xffff)) * El<T>::tof((u16)(y[k] & 0xffff)), El<T>::tof((u16)(x[k] >> 16)) * El<T>::tof((u16)(y[k] >> 16)));
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
+}
+
+__global__ void embed_rows_kernel(const int64_t* __restrict__ ids, const u16* __restrict__ table, u16* __restrict__ out, long rows, int C, int vocab) {
+    const int CV = C >> 3;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * CV) return;
+    const long r = i / CV; const int cv = (int)(i - r * CV);
+    long id = ids[r]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    *reinterpret_cast<u32x4*>(out + r * C + cv * 8) = *reinterpret_cast<const u32x4*>(table + id * C + cv * 8);
+}
+
 template <typename T> __global__ void cast_kernel(const float* x, u16* out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = El<T>::fromf(x[i]);
@@ -188,6 +247,43 @@ int launch_cast_f32(const float* x, void* out, long n, int dtype, hipStream_t s)
     if (dtype == CS_BF16) hipLaunchKernelGGL(cast_kernel<bf16_el>, grid, block, 0, s, x, (u16*)out, n);
     else if (dtype == CS_F16) hipLaunchKernelGGL(cast_kernel<f16>, grid, block, 0, s, x, (u16*)out, n);
     else CS_FAIL(CS_E_DTYPE, "cast: dtype");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_rms_norm(const void* x, const void* w, void* y, int M, int C, float eps, int dtype, hipStream_t s) {
+    if (!x || !w || !y) CS_FAIL(CS_E_ARG, "rms_norm: null pointer");
+    if (C % 8 || C > 8 * 64 * 8) CS_FAIL(CS_E_SHAPE, "rms_norm: C=%d unsupported", C);
+    if (M <= 0) return CS_OK;
+    const dim3 grid((M + 3) / 4), block(256);
+    const int nv = (C / 8 + 63) / 64;
+#define RMS(T, V) hipLaunchKernelGGL((rms_norm_kernel<T, V>), grid, block, 0, s, (const u16*)x, (const u16*)w, (u16*)y, M, C, eps)
+    if (dtype == CS_BF16) { if (nv <= 1) RMS(bf16_el, 1); else if (nv <= 2) RMS(bf16_el, 2); else if (nv <= 4) RMS(bf16_el, 4); else RMS(bf16_el, 8); }
+    else if (dtype == CS_F16) { if (nv <= 1) RMS(f16, 1); else if (nv <= 2) RMS(f16, 2); else if (nv <= 4) RMS(f16, 4); else RMS(f16, 8); }
+    else CS_FAIL(CS_E_DTYPE, "rms_norm: dtype");
+#undef RMS
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_gated_mul(const void* a, const void* b, void* out, long n, int dtype, hipStream_t s) {
+    if (!a || !b || !out) CS_FAIL(CS_E_ARG, "gated_mul: null pointer");
+    if (n % 8) CS_FAIL(CS_E_SHAPE, "gated_mul: element count must be a multiple of 8");
+    if (n <= 0) return CS_OK;
+    const dim3 grid((unsigned)((n / 8 + 255) / 256)), block(256);
+    if (dtype == CS_BF16) hipLaunchKernelGGL(gated_mul_kernel<bf16_el>, grid, block, 0, s, (const u16*)a, (const u16*)b, (u16*)out, n / 8);
+    else if (dtype == CS_F16) hipLaunchKernelGGL(gated_mul_kernel<f16>, grid, block, 0, s, (const u16*)a, (const u16*)b, (u16*)out, n / 8);
+    else CS_FAIL(CS_E_DTYPE, "gated_mul: dtype");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int launch_embed_rows(const int64_t* ids, const void* table, void* out, long rows, int C, int vocab, hipStream_t s) {
+    if (!ids || !table || !out) CS_FAIL(CS_E_ARG, "embed_rows: null pointer");
+    if (C % 8 || vocab <= 0) CS_FAIL(CS_E_SHAPE, "embed_rows: bad dims");
+    if (rows <= 0) return CS_OK;
+    const long n = rows * (C / 8);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, (const u16*)table, (u16*)out, rows, C, vocab);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -33,6 +33,7 @@ struct AttnArgs {
     float scale;
     int dtype;               // CS_F16 (default 0 is treated as f16) or CS_BF16
     int causal;              // 1: key j visible to query i iff j <= i (CLIP text encoder; f16, dh 64, Nq == Nk)
+    const float* bias;       // additive score bias [H][Nq][Nk] fp32, already multiplied by log2(e) (T5 relative positions; bf16, dh 64), or null
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -109,3 +110,8 @@ int launch_latent_to_nhwc64(const f16* x, const f16* w, const f16* b, f16* out, 
 int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s);
 // out[b][o][px] = (sum_c w[o][c] x[b][c][px] + bias[o] - out_shift) * out_scale ; w == null: identity on the first Cout channels
 int launch_pixel_affine_nchw(const f16* x, int Cin, const f16* w, const f16* bias, int Cout, f16* out, int B, int HW, float out_scale, float out_shift, hipStream_t s);
+
+// ---- T5 encoder ops (f16 / bf16) -------------------------------------------------------------------------------
+int launch_rms_norm(const void* x, const void* w, void* y, int M, int C, float eps, int dtype, hipStream_t s);
+int launch_gated_mul(const void* a, const void* b, void* out, long n, int dtype, hipStream_t s);
+int launch_embed_rows(const int64_t* ids, const void* table, void* out, long rows, int C, int vocab, hipStream_t s);

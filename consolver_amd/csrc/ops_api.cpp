@@ -83,6 +83,24 @@ int cs_op_attention_causal(const void* q, int q_stride, const void* k, int k_str
     return launch_attention(a, (hipStream_t)stream);
 }
 
+int cs_op_rms_norm(const void* x, const void* weight, void* out, int M, int C, float eps, int dtype, void* stream) {
+    return launch_rms_norm(x, weight, out, M, C, eps, dtype, (hipStream_t)stream);
+}
+int cs_op_gated_mul(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    return launch_gated_mul(a, b, out, (long)n, dtype, (hipStream_t)stream);
+}
+int cs_op_embed_rows(const int64_t* ids, const void* table, void* out, int64_t rows, int C, int vocab, void* stream) {
+    return launch_embed_rows(ids, table, out, (long)rows, C, vocab, (hipStream_t)stream);
+}
+int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                         int B, int H, int N, int dh, float scale, const float* bias_log2e, int dtype, void* stream) {
+    if (!bias_log2e) CS_FAIL(CS_E_ARG, "attention_bias: bias is NULL");
+    AttnArgs a{};
+    a.q = (const f16*)q; a.q_stride = q_stride; a.k = (const f16*)k; a.k_stride = k_stride; a.v = (const f16*)v; a.v_stride = v_stride;
+    a.out = (f16*)out; a.out_stride = out_stride; a.B = B; a.H = H; a.Nq = N; a.Nk = N; a.dh = dh; a.scale = scale; a.dtype = dtype; a.bias = bias_log2e;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 size_t cs_op_group_norm_workspace(int B, int C) { return (size_t)B * (GN_SPLITS + 1) * C * 2 * sizeof(float); }
 
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,

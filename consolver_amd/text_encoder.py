@@ -141,3 +141,151 @@ def load_prompt_cache(path, device="cpu", start=None, end=None):
         pe = f.get_slice("prompt_embeds")[sl]
         ne = f.get_slice("negative_prompt_embeds")[sl] if "negative_prompt_embeds" in f.keys() else None
     return prompts[sl], pe, ne
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# T5 v1.1 encoder (FLUX ``text_encoder_2``; edit_ppo/pipeline.py:279-330 ``prompt_embeds = text_encoder_2(ids)[0]``)
+# ---------------------------------------------------------------------------------------------------------------------
+T5_XXL_CONFIG = dict(vocab_size=32128, d_model=4096, d_kv=64, num_heads=64, d_ff=10240, num_layers=24,
+                     relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+
+
+def _t5_bucket(rel, num_buckets, max_distance):
+    import math
+    nb = num_buckets // 2
+    ret = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return ret + torch.where(n < max_exact, n, large)
+
+
+class HipT5EncoderModel:
+    """``text_encoder_2(input_ids)[0]`` -> [B, L, d_model].  Every matmul runs in the 256x256 LDS-staged MFMA GEMM (gemm2.hip), the
+    attention in the flash kernel's biased head-64 form (relative-position bias [H, L, L] precomputed once per sequence length,
+    no 1/sqrt(d) scaling), RMSNorm / gated GELU(tanh) / embedding gather as 16-byte-per-lane streaming kernels.  The layer
+    sequence is driven from Python over the op-level C ABI (a once-per-prompt step, not part of the solver loop)."""
+    is_consolver_hip = True
+
+    def __init__(self, config=None, device="cuda:0", dtype=torch.bfloat16):
+        cfg = dict(T5_XXL_CONFIG)
+        cfg.update(config or {})
+        if cfg["d_kv"] != 64:
+            raise ValueError("the biased attention kernel is built for head dim 64")
+        if cfg["d_model"] % 64 or cfg["d_ff"] % 64 or (cfg["num_heads"] * 64) % 64:
+            raise ValueError("d_model and d_ff must be multiples of 64")
+        self.config, self.device, self.dtype = cfg, torch.device(device), dtype
+        self._dt = L.dtype_code(dtype)
+        self.w = None
+        self._bias = {}
+
+    def manifest(self):
+        c = self.config
+        D, I, inner = c["d_model"], c["d_ff"], c["num_heads"] * c["d_kv"]
+        out = [("shared.weight", (c["vocab_size"], D)),
+               ("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", (c["relative_attention_num_buckets"], c["num_heads"]))]
+        for l in range(c["num_layers"]):
+            p = f"encoder.block.{l}"
+            out += [(f"{p}.layer.0.SelfAttention.{q}.weight", (inner, D)) for q in ("q", "k", "v")]
+            out += [(f"{p}.layer.0.SelfAttention.o.weight", (D, inner)), (f"{p}.layer.0.layer_norm.weight", (D,)),
+                    (f"{p}.layer.1.DenseReluDense.wi_0.weight", (I, D)), (f"{p}.layer.1.DenseReluDense.wi_1.weight", (I, D)),
+                    (f"{p}.layer.1.DenseReluDense.wo.weight", (D, I)), (f"{p}.layer.1.layer_norm.weight", (D,))]
+        out.append(("encoder.final_layer_norm.weight", (D,)))
+        return out
+
+    @staticmethod
+    def _pad_rows(t):
+        """gemm2 weight panels are read in 256-row tiles: pad the row count up with zeros"""
+        n = t.shape[0]
+        pad = (-n) % 256
+        return t if pad == 0 else torch.cat([t, t.new_zeros(pad, t.shape[1])])
+
+    def load_state_dict(self, sd, strict=True):
+        if "shared.weight" not in sd and "encoder.embed_tokens.weight" in sd:
+            sd = dict(sd, **{"shared.weight": sd["encoder.embed_tokens.weight"]})
+        want = dict(self.manifest())
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"missing {len(missing)} tensors, e.g. {missing[:3]}")
+        for k, shape in want.items():
+            if tuple(sd[k].shape) != shape:
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shape}")
+        dev, dt = self.device, self.dtype
+        put = lambda t: t.detach().to(dev, dt).contiguous()
+        w = {"shared": put(sd["shared.weight"]), "final_ln": put(sd["encoder.final_layer_norm.weight"]),
+             "rel": sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].detach().float().to(dev), "blocks": []}
+        for l in range(self.config["num_layers"]):
+            p = f"encoder.block.{l}"
+            qkv = torch.cat([sd[f"{p}.layer.0.SelfAttention.{q}.weight"] for q in ("q", "k", "v")])
+            w["blocks"].append(dict(
+                ln0=put(sd[f"{p}.layer.0.layer_norm.weight"]), qkv=self._pad_rows(put(qkv)), o=self._pad_rows(put(sd[f"{p}.layer.0.SelfAttention.o.weight"])),
+                ln1=put(sd[f"{p}.layer.1.layer_norm.weight"]), wi0=self._pad_rows(put(sd[f"{p}.layer.1.DenseReluDense.wi_0.weight"])),
+                wi1=self._pad_rows(put(sd[f"{p}.layer.1.DenseReluDense.wi_1.weight"])), wo=self._pad_rows(put(sd[f"{p}.layer.1.DenseReluDense.wo.weight"]))))
+        self.w = w
+        self._bias = {}
+        return self
+
+    def _position_bias(self, Lq):
+        """[H, L, L] fp32, already times log2(e) (the softmax runs in base 2); cached per sequence length"""
+        if Lq not in self._bias:
+            c = self.config
+            ctx = torch.arange(Lq, device=self.device)[:, None]
+            mem = torch.arange(Lq, device=self.device)[None, :]
+            b = _t5_bucket(mem - ctx, c["relative_attention_num_buckets"], c["relative_attention_max_distance"])
+            self._bias[Lq] = (self.w["rel"][b].permute(2, 0, 1) * 1.4426950408889634).contiguous()
+        return self._bias[Lq]
+
+    def _gemm(self, x, w, N, out=None, res=None, act=0):
+        M, K = x.shape
+        if out is None:
+            out = torch.empty(M, N, dtype=self.dtype, device=x.device)
+        L.check(L.lib().cs_op_gemm2(L.ptr(x), M, K, L.ptr(w), L.ptr(None), N, L.ptr(res), L.ptr(None), 0, 0, act, L.ptr(out), N, 0, self._dt,
+                                    L.stream_ptr(x.device)))
+        return out
+
+    def flops(self, batch, seq_len):
+        c = self.config
+        D, I, inner = c["d_model"], c["d_ff"], c["num_heads"] * c["d_kv"]
+        rows = batch * seq_len
+        return c["num_layers"] * (2.0 * rows * D * (4 * inner + 3 * I) + 4.0 * batch * seq_len * seq_len * inner)
+
+    @torch.no_grad()
+    def __call__(self, input_ids, attention_mask=None, **_ignored):
+        if self.w is None:
+            raise RuntimeError("weights not loaded")
+        if attention_mask is not None:
+            raise NotImplementedError("the FLUX pipeline calls text_encoder_2 without an attention mask (edit_ppo/pipeline.py:322)")
+        L.require_cuda(input_ids, "input_ids")
+        ids = input_ids.to(torch.int64).contiguous()
+        B, Lq = ids.shape
+        c, w, lib, st = self.config, self.w, L.lib(), L.stream_ptr(ids.device)
+        D, I, H, eps = c["d_model"], c["d_ff"], c["num_heads"], c["layer_norm_epsilon"]
+        inner, M = H * 64, B * Lq
+        if Lq % 4:
+            raise ValueError("sequence length must be a multiple of 4")
+        h = torch.empty(M, D, dtype=self.dtype, device=ids.device)
+        if M == 0:
+            return (h.view(B, Lq, D),)
+        L.check(lib.cs_op_embed_rows(L.ptr(ids), L.ptr(w["shared"]), L.ptr(h), M, D, c["vocab_size"], st))
+        bias = self._position_bias(Lq)
+        n = torch.empty_like(h)
+        qkv = torch.empty(M, 3 * inner, dtype=self.dtype, device=ids.device)
+        att = torch.empty(M, inner, dtype=self.dtype, device=ids.device)
+        g = torch.empty(M, I, dtype=self.dtype, device=ids.device)
+        u = torch.empty_like(g)
+        for blk in w["blocks"]:
+            L.check(lib.cs_op_rms_norm(L.ptr(h), L.ptr(blk["ln0"]), L.ptr(n), M, D, eps, self._dt, st))
+            self._gemm(n, blk["qkv"], 3 * inner, out=qkv)
+            L.check(lib.cs_op_attention_bias(L.ptr(qkv), 3 * inner, C.c_void_p(qkv.data_ptr() + 2 * inner), 3 * inner,
+                                             C.c_void_p(qkv.data_ptr() + 4 * inner), 3 * inner, L.ptr(att), inner, B, H, Lq, 64, 1.0,
+                                             L.ptr(bias), self._dt, st))
+            self._gemm(att, blk["o"], D, out=h, res=h)
+            L.check(lib.cs_op_rms_norm(L.ptr(h), L.ptr(blk["ln1"]), L.ptr(n), M, D, eps, self._dt, st))
+            self._gemm(n, blk["wi0"], I, out=g, act=1)                       # gelu_new == GELU(tanh)
+            self._gemm(n, blk["wi1"], I, out=u)
+            L.check(lib.cs_op_gated_mul(L.ptr(g), L.ptr(u), L.ptr(g), M * I, self._dt, st))
+            self._gemm(g, blk["wo"], D, out=h, res=h)
+        out = torch.empty_like(h)
+        L.check(lib.cs_op_rms_norm(L.ptr(h), L.ptr(w["final_ln"]), L.ptr(out), M, D, eps, self._dt, st))
+        return (out.view(B, Lq, D),)

@@ -63,6 +63,14 @@ int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride,
 int cs_op_attention_causal(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                            int B, int H, int N, int dh, float scale, void* stream);
 
+/* T5 encoder pieces (dtype = CS_F16 1 | CS_BF16 2) */
+int cs_op_rms_norm(const void* x, const void* weight, void* out, int M, int C, float eps, int dtype, void* stream);
+int cs_op_gated_mul(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int cs_op_embed_rows(const int64_t* ids, const void* table, void* out, int64_t rows, int C, int vocab, void* stream);
+/* softmax(scale q k^T + bias) v with bias_log2e = bias * log2(e) as fp32 [H][N][N]; head dim 64, no mask */
+int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                         int B, int H, int N, int dh, float scale, const float* bias_log2e, int dtype, void* stream);
+
 /* kernel-selection knobs (tests / tuning): "conv_halo" = 0 never, 1 auto (default), 2 whenever the shape allows */
 int cs_set_tuning(const char* key, int value);
 

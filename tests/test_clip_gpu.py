@@ -89,3 +89,51 @@ def test_prompt_cache_roundtrip(tmp_path):
     assert load_prompt_cache(path)[2] is None
     with pytest.raises(ValueError):
         save_prompt_cache(path, prompts[:2], pe)
+
+
+def test_t5_encoder_matches_transformers_golden(golden):
+    """FLUX text_encoder_2 (edit_ppo/pipeline.py:279-330): HIP T5 encoder vs the golden vectors of the installed third-party
+    transformers.T5EncoderModel (reduced config, 64- and 200-token sequences).  bf16 storage: rel L2 <= 2e-2 (f16: 3e-3)."""
+    from consolver_amd.text_encoder import HipT5EncoderModel
+    from oracle.t5_oracle import t5_manifest
+    g = golden["t5_encoder"]
+    V, D, dk, H, I, NL, NB, MD = [int(v) for v in g["cfg"]]
+    cfg = dict(vocab_size=V, d_model=D, d_kv=dk, num_heads=H, d_ff=I, num_layers=NL, relative_attention_num_buckets=NB,
+               relative_attention_max_distance=MD)
+    sd = {k[2:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("w_")}
+    for dt, tol in ((torch.float16, 3e-3), (torch.bfloat16, 2e-2)):
+        m = HipT5EncoderModel(cfg, device=DEV, dtype=dt)
+        assert m.manifest() == t5_manifest(cfg)
+        m.load_state_dict(sd)
+        for name in ("short", "long"):
+            ids = torch.from_numpy(np.asarray(g[f"{name}_ids"])).to(DEV)
+            out = m(ids)[0]
+            assert out.dtype == dt and out.shape == g[f"{name}_out"].shape
+            err = rel_l2(out.float().cpu().numpy(), g[f"{name}_out"])
+            print("t5", dt, name, err)
+            assert err < tol, (dt, name, err)
+
+
+def test_t5_xxl_width_two_blocks_matches_oracle():
+    """full T5-XXL widths (d_model 4096, 64 heads, d_ff 10240), two blocks, 512 tokens, synthetic weights, bf16"""
+    from consolver_amd.text_encoder import HipT5EncoderModel
+    from oracle.t5_oracle import T5EncoderOracle
+    cfg = dict(num_layers=2, vocab_size=1000)
+    m = HipT5EncoderModel(cfg, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for name, shape in m.manifest():
+        if name.endswith("layer_norm.weight"):
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif "relative_attention_bias" in name or name == "shared.weight":
+            sd[name] = torch.randn(shape, generator=g)
+        else:
+            sd[name] = torch.randn(shape, generator=g) * ((0.3 if name.endswith("SelfAttention.q.weight") else 1.0) / shape[1] ** 0.5)
+    m.load_state_dict(sd)
+    ids = torch.randint(0, 1000, (1, 512), generator=g)
+    out = m(ids.to(DEV))[0]
+    torch.set_num_threads(16)
+    want = T5EncoderOracle(sd, m.config)(ids)[0]
+    err = rel_l2(out.float().cpu().numpy(), want.numpy())
+    print("t5-xxl width rel l2", err)
+    assert out.shape == (1, 512, 4096) and err < 2e-2, err

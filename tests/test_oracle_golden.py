@@ -266,3 +266,20 @@ def test_clip_text_oracle_vs_transformers(golden):
         assert rel_l2(out, g[f"{name}_out"]) < 2e-6
         pooled = out[np.arange(ids.shape[0]), ids.numpy().argmax(-1)]            # end-of-text position
         assert rel_l2(pooled, g[f"{name}_pooled"]) < 2e-6
+
+
+def test_t5_encoder_oracle_vs_transformers(golden):
+    """oracle/t5_oracle.py against the installed third-party transformers.T5EncoderModel (reduced config, seeded weights,
+    sequences inside and beyond the 128-position bucket range)"""
+    import torch
+    from oracle.t5_oracle import T5EncoderOracle, t5_manifest
+    g = golden["t5_encoder"]
+    V, D, dk, H, I, NL, NB, MD = [int(v) for v in g["cfg"]]
+    cfg = dict(vocab_size=V, d_model=D, d_kv=dk, num_heads=H, d_ff=I, num_layers=NL, relative_attention_num_buckets=NB,
+               relative_attention_max_distance=MD)
+    sd = {k[2:]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith("w_")}
+    assert sorted(sd.keys()) == sorted(n for n, _ in t5_manifest(cfg))
+    orc = T5EncoderOracle(sd, cfg, round_weights_to_bf16=False)
+    for name in ("short", "long"):
+        out = orc(torch.from_numpy(np.asarray(g[f"{name}_ids"])))[0].numpy()
+        assert rel_l2(out, g[f"{name}_out"]) < 3e-6
