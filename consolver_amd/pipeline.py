@@ -78,3 +78,72 @@ class ConsistencySolverPipeline:
         if not return_dict:
             return (out, None)
         return types.SimpleNamespace(images=out, nsfw_content_detected=None)
+
+
+class FluxKontextEditPipeline:
+    """The ``FluxKontextPipeline`` call the FLUX driver uses (edit_ppo/generate_ours.py:87-93):
+    ``pipe(image=ref_image, prompt=instruction, num_inference_steps=8, guidance_scale=2.5, generator=torch.manual_seed(0)).images[0]``
+    on the HIP components: T5 + CLIP text encoders -> VAE encoder of the reference image -> FMPPOScheduler loop around the DiT ->
+    VAE decoder.  Token ids (``input_ids_t5`` / ``input_ids_clip``) or precomputed ``prompt_embeds`` / ``pooled_prompt_embeds`` replace
+    ``prompt`` when the tokenizers' asset files are not at hand."""
+
+    def __init__(self, transformer, scheduler, vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, guidance_scale=2.5):
+        from .flux import FluxKontextSamplingEngine
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self.text_encoder, self.text_encoder_2, self.tokenizer, self.tokenizer_2 = text_encoder, text_encoder_2, tokenizer, tokenizer_2
+        self._engine = FluxKontextSamplingEngine(transformer, scheduler, guidance_scale=guidance_scale)
+
+    def encode_prompt(self, prompt=None, input_ids_t5=None, input_ids_clip=None, max_sequence_length=512):
+        """edit_ppo/pipeline.py:279-345: T5 last_hidden_state (512 tokens) + CLIP pooler_output"""
+        dev = self.vae.device
+        if input_ids_t5 is None or input_ids_clip is None:
+            if prompt is None or self.tokenizer is None or self.tokenizer_2 is None:
+                raise RuntimeError("a text prompt needs both tokenizers; without them pass token ids or prompt_embeds / pooled_prompt_embeds")
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            input_ids_clip = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                                            return_tensors="pt").input_ids
+            input_ids_t5 = self.tokenizer_2(prompts, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                            return_tensors="pt").input_ids
+        if self.text_encoder is None or self.text_encoder_2 is None:
+            raise RuntimeError("text encoders are not attached to this pipeline")
+        pooled = self.text_encoder(input_ids_clip.to(dev)).pooler_output
+        embeds = self.text_encoder_2(input_ids_t5.to(dev))[0]
+        return embeds, pooled
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt=None, num_inference_steps=28, guidance_scale=None, generator=None, prompt_embeds=None,
+                 pooled_prompt_embeds=None, input_ids_t5=None, input_ids_clip=None, output_type="pil", return_dict=True, **_ignored):
+        from .flux import pack_latents
+        from .vae import encode_image_latents, flux_decode_latents
+        dev, S = self.vae.device, self.vae.config.sample_size
+        if guidance_scale is not None:
+            self._engine.guidance_scale = float(guidance_scale)
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            prompt_embeds, pooled_prompt_embeds = self.encode_prompt(prompt, input_ids_t5, input_ids_clip)
+        B = prompt_embeds.shape[0]
+        image_latents = None
+        if image is not None:
+            if not isinstance(image, torch.Tensor):                               # PIL image -> [1, 3, 8S, 8S] in [-1, 1]
+                import numpy as np
+                from PIL import Image
+                arr = np.asarray(image.convert("RGB").resize((8 * S, 8 * S), Image.LANCZOS), dtype=np.uint8)
+                image = (torch.from_numpy(arr.copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1)[None]
+            image = image.to(dev, torch.float16)
+            if image.shape[0] == 1 and B > 1:
+                image = image.expand(B, -1, -1, -1)
+            image_latents = pack_latents(encode_image_latents(self.vae, image.contiguous())).to(torch.bfloat16)
+        noise = torch.randn(B, self.vae.config.latent_channels, S, S, generator=generator,
+                            device=generator.device if generator is not None else dev).to(dev)
+        out = self._engine.generate(pack_latents(noise).to(torch.bfloat16), image_latents, prompt_embeds.to(dev, torch.bfloat16),
+                                    pooled_prompt_embeds.to(dev, torch.bfloat16), latent_hw=(S // 2, S // 2), num_inference_steps=num_inference_steps)
+        if output_type == "latent":
+            images = out
+        else:
+            images = flux_decode_latents(self.vae, out.to(torch.float16), height=8 * S, width=8 * S)
+            if output_type == "pil":
+                from PIL import Image
+                from .evaluation import tensor_to_uint8_hwc
+                images = [Image.fromarray(tensor_to_uint8_hwc(img)) for img in images]
+            elif output_type != "pt":
+                raise ValueError(f"unknown output_type {output_type!r}")
+        return types.SimpleNamespace(images=images) if return_dict else (images,)

@@ -158,3 +158,37 @@ def test_flux_edit_driver_writes_the_reference_layout(tmp_path):
     Image.fromarray(want8).save(buf, format="JPEG")                          # the same lossy step the driver applies
     via_jpeg = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
     assert np.abs(edited.astype(np.float32) - via_jpeg.astype(np.float32)).mean() < 1.0
+
+
+def test_flux_kontext_pipeline_call_surface():
+    """generate_ours.py:87-93: pipe(image=..., prompt/ids=..., num_inference_steps, guidance_scale, generator).images[0] on reduced
+    HIP components incl. the T5 and CLIP encoders (token ids in place of a prompt string)."""
+    from PIL import Image
+    from consolver_amd.pipeline import FluxKontextEditPipeline
+    from consolver_amd.vae import HipAutoencoderKL, FLUX_VAE_CONFIG
+    from consolver_amd.synth import synthetic_vae_state_dict, synthetic_clip_state_dict
+    from consolver_amd.text_encoder import HipCLIPTextModel, HipT5EncoderModel
+    cfg = dict(SMALL, dtype=torch.bfloat16)                       # joint_attention_dim 256 = the reduced T5's d_model
+    m = HipFluxTransformer2DModel(cfg, device=DEV)
+    m.load_state_dict(synthetic_flux_state_dict(m.manifest(), seed=4))
+    sch = consolver_amd.FMPPOScheduler.from_pretrained("x", subfolder="scheduler", order_dim=2, scaler_dim=0, mu_dim=0,
+                                                       factor_net_kwargs=dict(hidden_dim=64, num_actions=11))
+    sch.factor_net.to(DEV)
+    vcfg = dict(FLUX_VAE_CONFIG); vcfg.update(layers_per_block=1, sample_size=16, with_encoder=True)
+    vae = HipAutoencoderKL(vcfg, device=DEV); vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=9))
+    clip = HipCLIPTextModel(dict(num_hidden_layers=1, vocab_size=500), device=DEV)
+    clip.load_state_dict(synthetic_clip_state_dict(clip.manifest(), seed=2))
+    t5 = HipT5EncoderModel(dict(num_layers=1, vocab_size=300, d_model=256, num_heads=4, d_ff=512), device=DEV)
+    g = torch.Generator().manual_seed(3)
+    t5.load_state_dict({n: (1.0 + 0.1 * torch.randn(s, generator=g)) if n.endswith("layer_norm.weight") else torch.randn(s, generator=g) * (0.5 / s[-1] ** 0.5)
+                        for n, s in t5.manifest()})
+    pipe = FluxKontextEditPipeline(m, sch, vae, text_encoder=clip, text_encoder_2=t5)
+    ref = Image.fromarray(np.random.default_rng(0).integers(0, 255, (90, 120, 3), dtype=np.uint8))
+    ids_t5 = torch.randint(0, 300, (1, 64), generator=g)
+    ids_clip = torch.randint(0, 499, (1, 77), generator=g); ids_clip[:, -1] = 499
+    out = pipe(image=ref, input_ids_t5=ids_t5, input_ids_clip=ids_clip, num_inference_steps=4, guidance_scale=2.5, generator=torch.manual_seed(0))
+    assert out.images[0].size == (128, 128)
+    pt = pipe(image=ref, input_ids_t5=ids_t5, input_ids_clip=ids_clip, num_inference_steps=4, generator=torch.manual_seed(0), output_type="pt").images
+    assert pt.shape == (1, 3, 128, 128) and torch.isfinite(pt).all() and float(pt.std()) > 0.01
+    with pytest.raises(RuntimeError):
+        pipe(image=ref, prompt="make it red")
