@@ -288,6 +288,45 @@ static void run_4wave(const f16* d, const f16* stream, long rows, unsigned long 
            flops / (ms * 1e-3) / 1e12, ghz[blocks / 2], (double)s[0] / iters);
 }
 
+// Does a store stream on the same CUs slow the staged k loop down?  store_stream writes 16 B per lane to a large buffer (HBM bound);
+// it is launched on a second stream next to probe_dma<1> (144 KB of LDS per workgroup leaves room for LDS-free workgroups on every CU).
+__global__ __launch_bounds__(256) void store_stream(uint4* __restrict__ dst, long n16, int reps) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    uint4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (int r = 0; r < reps; ++r)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) { v.x += (unsigned)r; dst[i] = v; }
+}
+
+static void run_overlap(const f16* d, unsigned long long* st, float* sink) {
+    const long rows = 16L * 1024 * 1024 / 128;
+    f16* stream; hipMalloc(&stream, rows * 128);
+    for (long o = 0; o < rows * 64; o += 4L * 576 * 64) hipMemcpy(stream + o, d, std::min(4L * 576 * 64, rows * 64 - o) * sizeof(f16), hipMemcpyDeviceToDevice);
+    const long n16 = 1L << 26;                       // 1 GiB of stores per rep
+    uint4* dst; hipMalloc(&dst, n16 * 16);
+    hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
+    hipFuncSetAttribute((const void*)probe_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    auto timed = [&](bool loop, bool stores) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(a, 0);
+            hipStreamWaitEvent(s1, a, 0); hipStreamWaitEvent(s2, a, 0);
+            if (loop) hipLaunchKernelGGL(probe_dma<1>, dim3(256), dim3(512), 2 * 73728, s1, d, stream, rows, 16000, st, sink);
+            if (stores) hipLaunchKernelGGL(store_stream, dim3(1024), dim3(256), 0, s2, dst, n16, 24);
+            hipEventRecord(b, s1); hipStreamWaitEvent(0, b, 0);
+            hipEventRecord(b, s2); hipStreamWaitEvent(0, b, 0);
+            hipEventRecord(b, 0); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b); best = std::min(best, ms);
+        }
+        return best;
+    };
+    const float tl = timed(true, false), ts = timed(false, true), tb = timed(true, true);
+    printf("k loop alone %.2f ms, store stream alone %.2f ms (%.2f TB/s), both at once %.2f ms  (sum %.2f, max %.2f)\n", tl, ts,
+           24.0 * n16 * 16 / (ts * 1e-3) / 1e12, tb, tl + ts, std::max(tl, ts));
+    hipFree(dst); hipFree(stream);
+}
+
 int main() {
     const int blocks = 256, iters = 20000;
     const size_t n = 4 * 576 * 64;
@@ -333,5 +372,6 @@ int main() {
         run_4wave<1>(d, stream, rows, st, sink);
         hipFree(stream);
     }
+    run_overlap(d, st, sink);
     return 0;
 }
