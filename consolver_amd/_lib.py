@@ -56,6 +56,12 @@ class CsClipConfig(C.Structure):
                 ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("layer_norm_eps", C.c_float)]
 
 
+class CsGemm2Problem(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("M", C.c_int), ("K", C.c_int), ("w", C.c_void_p), ("bias", C.c_void_p), ("N", C.c_int),
+                ("res", C.c_void_p), ("gate", C.c_void_p), ("gate_stride", C.c_long), ("rows_per_sample", C.c_int), ("act", C.c_int),
+                ("out", C.c_void_p), ("ldc", C.c_long), ("col_off", C.c_int)]
+
+
 # every symbol declared in include/consolver_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "cs_abi_version": (C.c_int, []),
@@ -132,6 +138,7 @@ SYMBOLS = {
     # include/consolver_hip_ops.h
     "cs_op_gemm2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
                               C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "cs_op_gemm2_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cs_op_attention_causal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "cs_op_rms_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),

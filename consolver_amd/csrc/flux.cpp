@@ -132,17 +132,30 @@ struct FRun {
         if (!p && rc == CS_OK) { cs_set_error("flux: workspace too small"); rc = CS_E_ARG; }
         return p;
     }
+    static Gemm2Args gargs(const Lin& L, const void* a, long lda, int M, void* out, long ldc, int col_off, int act, const void* res,
+                           const float* gate, long gate_stride, int rows_per_sample, int a_seg, int a_stride, long a_off, int c_seg, int c_stride, long c_off) {
+        Gemm2Args g{};
+        g.a = a; g.lda = lda; g.a_seg_rows = a_seg; g.a_seg_stride = a_stride; g.a_row_off = a_off;
+        g.w = L.w; g.bias = L.b; g.M = M; g.N = L.n; g.K = L.k;
+        g.out = out; g.res = res; g.ldc = ldc; g.c_col_off = col_off; g.c_seg_rows = c_seg; g.c_seg_stride = c_stride; g.c_row_off = c_off;
+        g.gate = gate; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample; g.act = act;
+        return g;
+    }
     void gemm(const Lin& L, const void* a, long lda, int M, void* out, long ldc, int col_off = 0, int act = 0, const void* res = nullptr,
               const float* gate = nullptr, long gate_stride = 0, int rows_per_sample = 0,
               int a_seg = 0, int a_stride = 0, long a_off = 0, int c_seg = 0, int c_stride = 0, long c_off = 0) {
         if (dry) { f->dry_flops += 2.0 * M * (double)L.n * L.k; return; }
         if (rc != CS_OK) return;
-        Gemm2Args g{};
-        g.a = a; g.lda = lda; g.a_seg_rows = a_seg; g.a_seg_stride = a_stride; g.a_row_off = a_off;
-        g.w = L.w; g.bias = L.b; g.M = M; g.N = L.n; g.K = L.k;
-        g.out = out; g.res = res; g.ldc = ldc; g.c_col_off = col_off; g.c_seg_rows = c_seg; g.c_seg_stride = c_stride; g.c_row_off = c_off;
-        g.gate = gate; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample; g.act = act; g.dtype = dt;
+        Gemm2Args g = gargs(L, a, lda, M, out, ldc, col_off, act, res, gate, gate_stride, rows_per_sample, a_seg, a_stride, a_off, c_seg, c_stride, c_off);
+        g.dtype = dt;
         rc = launch_gemm2(g, s);
+    }
+    // the image-stream and text-stream linears of one stage in a single grouped launch
+    void gemm_pair(Gemm2Args x, Gemm2Args y) {
+        if (dry) { f->dry_flops += 2.0 * x.M * (double)x.N * x.K + 2.0 * y.M * (double)y.N * y.K; return; }
+        if (rc != CS_OK) return;
+        x.dtype = y.dtype = dt;
+        rc = launch_gemm2_pair(x, y, s);
     }
     void small(const float* x, int Rr, int K, const u16* w, const u16* b, long N, float* out, int silu_in, int silu_out) {
         if (dry) { f->dry_flops += 2.0 * Rr * (double)N * K; return; }
@@ -177,7 +190,8 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     u16* img = (u16*)Rn.alloc((size_t)B * I * D * e); u16* ctx = (u16*)Rn.alloc((size_t)B * T * D * e);
     u16* nimg = (u16*)Rn.alloc((size_t)B * I * D * e); u16* nctx = (u16*)Rn.alloc((size_t)B * T * D * e);
     u16* qkv = (u16*)Rn.alloc((size_t)B * S * 3 * D * e); u16* att = (u16*)Rn.alloc((size_t)B * S * D * e);
-    u16* mlp = (u16*)Rn.alloc((size_t)B * I * 4 * D * e);            // double blocks: FF hidden ; reused below
+    u16* mlp = (u16*)Rn.alloc((size_t)B * I * 4 * D * e);            // double blocks: FF hidden of the image stream
+    u16* cmlp = (u16*)Rn.alloc((size_t)B * T * 4 * D * e);           // ... and of the text stream (both FFs run in one grouped launch)
     u16* hs = (u16*)Rn.alloc((size_t)B * S * D * e); u16* nhs = (u16*)Rn.alloc((size_t)B * S * D * e);
     u16* cat = (u16*)Rn.alloc((size_t)B * S * 5 * D * e);
     if (Rn.rc != CS_OK) return Rn.rc;
@@ -204,16 +218,18 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     for (auto& k : f->dbl) {
         const float* mi = mod + k.mod_img; const float* mc = mod + k.mod_ctx;      // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp]
         Rn.lnmod(img, nimg, B * I, D, I, mi, mi + D, MS); Rn.lnmod(ctx, nctx, B * T, D, T, mc, mc + D, MS);
-        Rn.gemm(k.add_qkv, nctx, D, B * T, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, T, S, 0);
-        Rn.gemm(k.qkv, nimg, D, B * I, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I, S, T);
+        Rn.gemm_pair(FRun::gargs(k.qkv, nimg, D, B * I, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I, S, T),
+                     FRun::gargs(k.add_qkv, nctx, D, B * T, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, T, S, 0));
         if (!dry && Rn.rc == CS_OK)
             Rn.rc = launch_qk_norm_rope(qkv, 3 * D, B * S, S, H, dh, 0, D, k.nq, k.nk, k.naq, k.nak, T, rcos, rsin, 1e-6f, c.dtype, s);
         Rn.attn(qkv, B, S, att, D);
-        Rn.gemm(k.out, att, D, B * I, img, D, 0, 0, img, mi + 2 * D, MS, I, I, S, T);
-        Rn.gemm(k.add_out, att, D, B * T, ctx, D, 0, 0, ctx, mc + 2 * D, MS, T, T, S, 0);
+        Rn.gemm_pair(FRun::gargs(k.out, att, D, B * I, img, D, 0, 0, img, mi + 2 * D, MS, I, I, S, T, 0, 0, 0),
+                     FRun::gargs(k.add_out, att, D, B * T, ctx, D, 0, 0, ctx, mc + 2 * D, MS, T, T, S, 0, 0, 0, 0));
         Rn.lnmod(img, nimg, B * I, D, I, mi + 3 * D, mi + 4 * D, MS); Rn.lnmod(ctx, nctx, B * T, D, T, mc + 3 * D, mc + 4 * D, MS);
-        Rn.gemm(k.ff1, nimg, D, B * I, mlp, 4 * D, 0, 1); Rn.gemm(k.ff2, mlp, 4 * D, B * I, img, D, 0, 0, img, mi + 5 * D, MS, I);
-        Rn.gemm(k.cff1, nctx, D, B * T, mlp, 4 * D, 0, 1); Rn.gemm(k.cff2, mlp, 4 * D, B * T, ctx, D, 0, 0, ctx, mc + 5 * D, MS, T);
+        Rn.gemm_pair(FRun::gargs(k.ff1, nimg, D, B * I, mlp, 4 * D, 0, 1, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0),
+                     FRun::gargs(k.cff1, nctx, D, B * T, cmlp, 4 * D, 0, 1, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0));
+        Rn.gemm_pair(FRun::gargs(k.ff2, mlp, 4 * D, B * I, img, D, 0, 0, img, mi + 5 * D, MS, I, 0, 0, 0, 0, 0, 0),
+                     FRun::gargs(k.cff2, cmlp, 4 * D, B * T, ctx, D, 0, 0, ctx, mc + 5 * D, MS, T, 0, 0, 0, 0, 0, 0));
     }
     // ---- joint sequence [context | image] ---------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK) {

@@ -43,8 +43,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
+// Up to two independent problems per launch (grouped GEMM): workgroups [0, nblk0) compute tiles of p[0], the rest tiles of p[1].
+// FLUX's double-stream blocks run the image-token and text-token linears of one stage side by side: the 512 text rows alone fill 24-96
+// of the 256 CUs for a whole tile time, appended to the image problem's tile list they ride in its last, partly empty round.
+struct G2Pair { G2Params p[2]; int nblk0, nblk; };
+
 template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Params p) {
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
     constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
     typedef typename El<T>::frag frag;
@@ -55,9 +60,12 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Params p) {
     const int wm = w >> 1, wn = w & 1;
     int id;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        const int bid = blockIdx.x, xcd = bid & 7, q = pp.nblk >> 3, r = pp.nblk & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int second = id >= pp.nblk0;
+    const G2Params& p = pp.p[second];
+    if (second) id -= pp.nblk0;
     const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
     const int m_blk = tm * BMX, n_blk = tn * BNX;
 
@@ -101,34 +109,58 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Params p) {
     const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
     const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
 
+    // Software-pipelined k loop.  A k-step is four groups g = (ks, half) of 16 MFMAs; the fragments of group g+1 are read from LDS
+    // while group g's MFMAs issue (two register sets each for the A and W fragments), so no MFMA waits on a ds_read it just issued.
+    // The per-step barrier sits between groups 2 and 3: by then every wave has read all of this stage's fragments (group 3's are
+    // already in registers) and the next stage has landed, so group 3 re-fills this stage's buffer by LDS-DMA and prefetches
+    // group 0 of the next k-step from the other buffer.
+    auto ldfa = [&](frag (&fa)[MT], const char* ta, int fo) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const frag*>(ta + j * 2048 + fo);
+    };
+    auto ldfw = [&](frag (&fw)[4], const char* tb, int half, int fo) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag*>(tb + (half * 4 + i) * 2048 + fo);
+    };
+    auto mm = [&](int half, const frag (&fw)[4], const frag (&fa)[MT]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[half * 4 + i][j] = El<T>::mfma(fw[i], fa[j], acc[half * 4 + i][j]);
+    };
+    frag faA[MT], faB[MT], fwA[4], fwB[4];
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (p.KT > 1) stage(1, 1);
+    ldfa(faA, smem + (wm * 64) * 128, frag_off0); ldfw(fwA, smem + A_BYTES + (wn * 128) * 128, 0, frag_off0);
     for (int kt = 0; kt < p.KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
         const char* tb = smem + buf * STAGE + A_BYTES + (wn * 128) * 128;
+        const char* tan = smem + (buf ^ 1) * STAGE + (wm * 64) * 128;
+        const char* tbn = smem + (buf ^ 1) * STAGE + A_BYTES + (wn * 128) * 128;
+        // group 0
+        ldfw(fwB, tb, 1, frag_off0); mm(0, fwA, faA);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fo = ks ? frag_off1 : frag_off0;
-            frag fa[MT];
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+        // group 1
+        ldfa(faB, ta, frag_off1); ldfw(fwA, tb, 0, frag_off1); mm(1, fwB, faA);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const frag*>(ta + j * 2048 + fo);
+        for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
+        // group 2
+        ldfw(fwB, tb, 1, frag_off1); mm(0, fwA, faB);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                frag fw[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const frag*>(tb + (half * 4 + i) * 2048 + fo);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) acc[half * 4 + i][j] = El<T>::mfma(fw[i], fa[j], acc[half * 4 + i][j]);
-            }
-        }
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // group 3
+        if (kt + 2 < p.KT) stage(kt + 2, buf);
+        ldfa(faA, tan, frag_off0); ldfw(fwA, tbn, 0, frag_off0); mm(1, fwB, faB);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
     }
+    __syncthreads();
 
     // ---- epilogue: per wave 64 rows x 128 cols in two passes of 64 cols through an LDS patch --------------
     constexpr int COLS = 64, ROWB = (COLS + 8) * 2, CH = COLS / 8;
@@ -228,13 +260,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 
 }  // namespace
 
-int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
+static int g2_fill(const Gemm2Args& a, G2Params& p) {
     if (!a.a || !a.w || !a.out) CS_FAIL(CS_E_ARG, "gemm2: null pointer");
     if (a.K % BK) CS_FAIL(CS_E_SHAPE, "gemm2: K=%d must be a multiple of 64", a.K);
     if (a.N % 8 || a.ldc % 8 || a.c_col_off % 8 || a.lda % 8) CS_FAIL(CS_E_SHAPE, "gemm2: N, lda, ldc, col offset must be multiples of 8");
-    if (a.M <= 0 || a.N <= 0) return (a.M < 0 || a.N < 0) ? CS_E_SHAPE : CS_OK;
     if (a.gate && a.rows_per_sample <= 0) CS_FAIL(CS_E_ARG, "gemm2: rows_per_sample required with gate");
-    G2Params p;
     p.a = (const u16*)a.a; p.lda = a.lda ? a.lda : a.K; p.a_seg = a.a_seg_rows; p.a_stride = a.a_seg_stride; p.a_off = a.a_row_off;
     p.w = (const u16*)a.w; p.bias = (const u16*)a.bias; p.M = a.M; p.N = a.N; p.K = a.K; p.KT = a.K / BK;
     p.out = (u16*)a.out; p.res = (const u16*)a.res; p.ldc = a.ldc ? a.ldc : a.N; p.c_col = a.c_col_off;
@@ -242,6 +272,10 @@ int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
     p.gate = (const float*)a.gate; p.gate_stride = a.gate_stride; p.rows_per_sample = a.rows_per_sample; p.act = a.act;
     p.tiles_n = (a.N + 255) / 256;            // the packed weight has tiles_n * 256 rows (zero padded)
     p.nblk = ((a.M + 255) / 256) * p.tiles_n;
+    return CS_OK;
+}
+
+static int g2_launch(const G2Pair& pp, int dtype, hipStream_t s) {
     constexpr size_t lds = 2 * (256 * BK * 2 + 256 * BK * 2);
     static bool configured = false;
     if (!configured) {
@@ -249,11 +283,32 @@ int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<bf16_el>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    if (a.dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, dim3(p.nblk), dim3(512), lds, s, p);
-    else if (a.dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, dim3(p.nblk), dim3(512), lds, s, p);
+    if (dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, dim3(pp.nblk), dim3(512), lds, s, pp);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, dim3(pp.nblk), dim3(512), lds, s, pp);
     else CS_FAIL(CS_E_DTYPE, "gemm2: dtype must be f16 or bf16");
     CS_CHECK_LAUNCH();
     return CS_OK;
+}
+
+int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return (a.M < 0 || a.N < 0) ? CS_E_SHAPE : CS_OK;
+    G2Pair pp;
+    const int rc = g2_fill(a, pp.p[0]);
+    if (rc != CS_OK) return rc;
+    pp.p[1] = pp.p[0]; pp.nblk0 = pp.nblk = pp.p[0].nblk;
+    return g2_launch(pp, a.dtype, s);
+}
+
+int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) {
+    if (a.dtype != b.dtype) CS_FAIL(CS_E_DTYPE, "gemm2 pair: both problems must have the same dtype");
+    if (a.M <= 0 || a.N <= 0) return launch_gemm2(b, s);
+    if (b.M <= 0 || b.N <= 0) return launch_gemm2(a, s);
+    G2Pair pp;
+    int rc = g2_fill(a, pp.p[0]);
+    if (rc == CS_OK) rc = g2_fill(b, pp.p[1]);
+    if (rc != CS_OK) return rc;
+    pp.nblk0 = pp.p[0].nblk; pp.nblk = pp.p[0].nblk + pp.p[1].nblk;
+    return g2_launch(pp, a.dtype, s);
 }
 
 int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,

@@ -77,6 +77,8 @@ struct Gemm2Args {
     int dtype;
 };
 int launch_gemm2(const Gemm2Args& a, hipStream_t s);
+// two independent problems (same dtype) in one launch: b's tiles are appended to a's tile list
+int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s);
 int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,
                         int dtype, hipStream_t s);
 // y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b] ; x,y [M][C] (dtype), scale/shift fp32 rows of stride mod_stride

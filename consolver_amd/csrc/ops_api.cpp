@@ -67,6 +67,17 @@ int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, in
     return launch_gemm2(g, (hipStream_t)stream);
 }
 
+static Gemm2Args g2_from(const CsGemm2Problem& q, int dtype) {
+    Gemm2Args g{};
+    g.a = q.x; g.lda = q.K; g.w = q.w; g.bias = q.bias; g.M = q.M; g.N = q.N; g.K = q.K; g.out = q.out; g.res = q.res; g.ldc = q.ldc ? q.ldc : q.N;
+    g.c_col_off = q.col_off; g.gate = q.gate; g.gate_stride = q.gate_stride; g.rows_per_sample = q.rows_per_sample; g.act = q.act; g.dtype = dtype;
+    return g;
+}
+int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype, void* stream) {
+    if (!a || !b) CS_FAIL(CS_E_ARG, "gemm2 pair: null problem");
+    return launch_gemm2_pair(g2_from(*a, dtype), g2_from(*b, dtype), (hipStream_t)stream);
+}
+
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream) {
     AttnArgs a{};

@@ -55,6 +55,15 @@ int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* o
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
 int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
                 int rows_per_sample, int act, void* out, long ldc, int col_off, int dtype, void* stream);
+/* Grouped form: two independent cs_op_gemm2 problems of the same dtype in ONE launch (problem b's tiles are appended to problem a's tile
+ * list).  FLUX's double-stream blocks (reference: diffusers FluxTransformerBlock, called from FLUX/train_ppo_flux.py:150-163 through
+ * pipe.transformer) run the image-token and the text-token linear of each stage this way. */
+typedef struct CsGemm2Problem {
+    const void* x; int M, K; const void* w; const void* bias; int N;
+    const void* res; const float* gate; long gate_stride; int rows_per_sample; int act;
+    void* out; long ldc; int col_off;
+} CsGemm2Problem;
+int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype, void* stream);
 /* cs_op_attention with an explicit dtype (bf16: head dim 128) */
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream);

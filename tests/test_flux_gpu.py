@@ -50,6 +50,34 @@ def test_gemm2_and_bf16_attention_ops():
         assert rel_l2(o.float(), ref) < (2e-2 if dt == torch.bfloat16 else 3e-3), dt
 
 
+def test_gemm2_pair_matches_two_single_launches():
+    """grouped launch (image-stream + text-stream linear of one FLUX stage) == the two problems launched one by one, bit for bit"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(1)
+    dt, code = torch.bfloat16, 2
+    K = 512
+    probs, keep = [], []
+    for M, N, act, gated in ((1100, 768, 1, False), (300, 512, 0, True)):
+        x = torch.randn(M, K, generator=g).to(dt).to(DEV); w = torch.zeros((N + 255) // 256 * 256, K, dtype=dt, device=DEV)
+        w[:N] = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+        b = torch.randn(N, generator=g).to(dt).to(DEV)
+        res = torch.randn(M, N, generator=g).to(dt).to(DEV) if gated else None
+        gate = torch.randn(3, N, generator=g).to(DEV) if gated else None
+        out1, out2 = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
+        keep.append((x, w, b, res, gate, out1, out2))
+        L.check(L.lib().cs_op_gemm2(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, L.ptr(res), L.ptr(gate), N, 100, act,
+                                    out1.data_ptr(), N, 0, code, L.stream_ptr(x.device)))
+        probs.append(L.CsGemm2Problem(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, res.data_ptr() if gated else None,
+                                      gate.data_ptr() if gated else None, N, 100, act, out2.data_ptr(), N, 0))
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(probs[0]), C.byref(probs[1]), code, L.stream_ptr(DEV)))
+    torch.cuda.synchronize()
+    for (x, w, b, res, gate, out1, out2) in keep:
+        assert torch.equal(out1, out2)
+    x, w, b = keep[0][:3]
+    ref = torch.nn.functional.gelu(x.float() @ w[:768].float().T + b.float(), approximate="tanh")
+    assert rel_l2(keep[0][6].float(), ref) < 8e-3
+
+
 def test_layout_helpers_roundtrip():
     x = torch.arange(2 * 16 * 8 * 12, dtype=torch.float32).view(2, 16, 8, 12)
     p = pack_latents(x)

@@ -64,6 +64,19 @@ if which in ("all", "attn"):
     qf, kf, vf = rnd(1, 8704, 3072), rnd(1, 8704, 3072), rnd(1, 8704, 3072)
     ms = timeit(lambda: ops.attention(qf, kf, vf, 24))
     rows.append(("attention dh=128 FLUX", 8704, 8704, 3072, ms, 4.0 * 8704 * 8704 * 3072 / ms / 1e9))
+if which in ("gemm2",):
+    # FLUX-Kontext DiT linears (bf16, 8192 image + 512 text tokens, D = 3072) through the 256x256 transformer GEMM
+    from consolver_amd import _lib as L
+    def g2(M, K, N, tag, act=0, gated=False):
+        x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
+        res = torch.randn(M, N, device=dev).bfloat16() if gated else None; gate = torch.randn(1, N, device=dev) if gated else None
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16); st = L.stream_ptr(x.device)
+        fn = lambda: L.check(L.lib().cs_op_gemm2(L.ptr(x), M, K, L.ptr(w), L.ptr(b), N, L.ptr(res), L.ptr(gate), N, M, act, L.ptr(out), N, 0, 2, st))
+        ms = timeit(fn)
+        rows.append((f"gemm2 bf16 {tag}", M, K, N, ms, 2.0 * M * K * N / ms / 1e9))
+    g2(8192, 3072, 9216, "img qkv"); g2(512, 3072, 9216, "ctx qkv"); g2(8192, 3072, 3072, "img out", gated=True); g2(512, 3072, 3072, "ctx out", gated=True)
+    g2(8192, 3072, 12288, "img ff1", act=1); g2(8192, 12288, 3072, "img ff2", gated=True); g2(512, 3072, 12288, "ctx ff1", act=1); g2(512, 12288, 3072, "ctx ff2", gated=True)
+    g2(8704, 3072, 9216, "single qkv"); g2(8704, 3072, 12288, "single mlp", act=1); g2(8704, 15360, 3072, "single out", gated=True)
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
 for r in rows:
     print(f"{r[0]:40s} {r[1]:8d} {r[2]:8d} {r[3]:6d} {r[4]:9.3f} {r[5] / 1e3:9.1f}")

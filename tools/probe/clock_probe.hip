@@ -214,6 +214,84 @@ static void run_direct(const f16* d, const f16* stream, long rows, unsigned long
            ghz[blocks / 2], (double)s[0] / iters);
 }
 
+// MODE 5 experiment: REGISTER-staged operands: global_load_dwordx4 -> VGPR -> ds_write_b128 (9 pieces of 1 KiB per wave per k-step, written one
+// k-step after they were loaded, between the MFMA groups) instead of LDS-DMA.  Question: is the LDS write port cheaper for ds_write_b128
+// (128 B/clk) than for DMA pieces (~64 B/clk)?
+__global__ __launch_bounds__(512, 2) void probe_regstage(const f16* __restrict__ src, const f16* __restrict__ stream, long stream_rows, int iters,
+                                                         unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 72 KB
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 2 * 576 * 8; i += 512) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(i % (576 * 8)) * 8);
+    __syncthreads();
+    f32x4 acc[10][4];
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    long row = ((long)blockIdx.x * 577 + w * 72 + (lane >> 3)) % stream_rows;
+    const int wofs = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 4) & 7)) * 16);     // swizzled 16-B slot inside the piece
+    f16x8 stg[9];
+    auto gload = [&](int j) {
+        stg[j] = *reinterpret_cast<const f16x8*>(stream + (row * 64 + (lane & 7) * 8));
+        row += 8; if (row >= stream_rows) row -= stream_rows;
+    };
+#pragma unroll
+    for (int j = 0; j < 9; ++j) gload(j);
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const char* ta = smem + buf * 73728 + (wm * 64) * 128; const char* tb = smem + buf * 73728 + 256 * 128 + (wn * 160) * 128;
+        char* dst = smem + (buf ^ 1) * 73728 + w * 9 * 1024 + wofs;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            f16x8 fa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int q = ks * 2 + half;
+#pragma unroll
+                for (int j = 2 * q; j < (q == 3 ? 9 : 2 * q + 2); ++j) { *reinterpret_cast<f16x8*>(dst + j * 1024) = stg[j]; gload(j); }
+                f16x8 fw[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 5 + i) * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[half * 5 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * 5 + i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 10; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    for (int j = 0; j < 9; ++j) s += (float)stg[j][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+static void run_regstage(const f16* d, const f16* stream, long rows, unsigned long long* st, float* sink) {
+    const int blocks = 256, iters = 4000;
+    hipFuncSetAttribute((const void*)probe_regstage, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 73728);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe_regstage, dim3(blocks), dim3(512), 2 * 73728, 0, d, stream, rows, iters, st, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= 12;
+    }
+    std::vector<unsigned long long> s(blocks * 2);
+    hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flops = (double)blocks * iters * 8 * 80 * 16384.0;
+    printf("  register-staged (global_load -> ds_write_b128 one k-step later):  %.1f TFLOP/s, clock %.3f GHz, cycles per k-step per wave %.0f\n", flops / (ms * 1e-3) / 1e12,
+           ghz[blocks / 2], (double)s[0] / iters);
+}
+
 // MODE 4 experiment: the same 256 x 320 x 64 tile on FOUR waves (one per SIMD, 512 registers each): wave tile 128 x 160, so the
 // LDS fragment reads per k-step drop from 224 KB (8 waves x 28 KB) to 144 KB (4 x 36 KB); 18 DMA pieces per wave per k-step.
 template <int SPREAD>
@@ -367,6 +445,7 @@ int main() {
         run_dma<0>(d, stream, rows, "burst at top, vmcnt(0) + barrier (as shipped):", st, sink);
         run_dma<1>(d, stream, rows, "pieces spread between MFMA groups, vmcnt(0):", st, sink);
         run_dma<2>(d, stream, rows, "burst, vmcnt(9): one stage stays in flight:", st, sink);
+        run_regstage(d, stream, rows, st, sink);
         run_direct(d, stream, rows, st, sink);
         run_4wave<0>(d, stream, rows, st, sink);
         run_4wave<1>(d, stream, rows, st, sink);
