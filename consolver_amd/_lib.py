@@ -138,6 +138,9 @@ SYMBOLS = {
     # include/consolver_hip_ops.h
     "cs_op_gemm2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long,
                               C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "cs_op_attention_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cs_op_attention_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cs_op_gemm2_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cs_op_attention_causal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

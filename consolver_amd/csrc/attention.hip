@@ -30,6 +30,12 @@ struct AttnParams {
     int H, Nq, Nk;
     float c;   // scale * log2(e)
     const float* bias;   // [H][Nq][Nk] fp32, times log2(e), or null
+    // workgroup -> (query block, head, batch): lin = lin0 + blockIdx.x, query block fastest (the order a 3-D grid is dispatched in)
+    int nqb, lin0;
+    // split-KV tail (SPLIT kernels): blockIdx.y = key range, results go to the fp32 partial buffers instead of `out`
+    int splits, tiles_per_split, part_rows;
+    float* part_o;       // [splits][part_rows][DH] unnormalised O, relative to the partial's own reference maximum
+    float* part_ml;      // [splits][part_rows][2]  (reference maximum in log2 units, denominator)
 };
 
 typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -53,7 +59,7 @@ __device__ __forceinline__ float xor32_max(float v) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int DH, int QT, bool CAUSAL, bool BIAS>
+template <typename T, int DH, int QT, bool CAUSAL, bool BIAS, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     typedef typename El<T>::frag frag;
     constexpr int DK = (DH + 31) / 32 * 32;
@@ -75,8 +81,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (4 * QT * 16) + w * (QT * 16);
+    const int lin = p.lin0 + blockIdx.x;
+    const int qblk = lin % p.nqb, hb = lin / p.nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qblk * (4 * QT * 16) + w * (QT * 16);
+    // key range of this workgroup: everything, or (SPLIT) tiles [blockIdx.y * tiles_per_split, ...)
+    const int key0 = SPLIT ? blockIdx.y * p.tiles_per_split * 64 : 0;
+    const int Nk = SPLIT ? min(p.Nk - key0, p.tiles_per_split * 64) : p.Nk;
 
     // zero both buffers once: pad columns stay zero, tails are rewritten with zeros explicitly
     // (with the swizzled K layout the pad chunks 5..7 of a row land in permuted slots: still never written)
@@ -110,9 +121,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) { m_run[t] = 0.f; l_run[t] = 0.f; }
 
-    const int ntiles = (p.Nk + 63) / 64;
-    const f16* kbase = p.k + (size_t)b * p.Nk * p.k_stride + h * DH;
-    const f16* vbase = p.v + (size_t)b * p.Nk * p.v_stride + h * DH;
+    const int ntiles = (Nk + 63) / 64;
+    const f16* kbase = p.k + ((size_t)b * p.Nk + key0) * p.k_stride + h * DH;
+    const f16* vbase = p.v + ((size_t)b * p.Nk + key0) * p.v_stride + h * DH;
 
     u32x4 kreg[NCH], vreg[NCH];
     // per-thread staging slots (loop invariant): chunk id -> (row, 16-byte chunk) of the 64-key tile
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     auto load_tile = [&](int tile) {
         const f16* kt_base = kbase + (size_t)tile * 64 * p.k_stride;
         const f16* vt_base = vbase + (size_t)tile * 64 * p.v_stride;
-        const int rows_left = p.Nk - tile * 64;                   // >= 64 for every tile but a ragged last one
+        const int rows_left = Nk - tile * 64;                   // >= 64 for every tile but a ragged last one
         if (rows_left >= 64) {                                    // wave-uniform fast path: no per-lane guards
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (tile * 64 + kt * 16 + 4 * g + r >= p.Nk) {
+                    if (tile * 64 + kt * 16 + 4 * g + r >= Nk) {
 #pragma unroll
                         for (int t = 0; t < QT; ++t) s[kt][t][r] = -INFINITY;
                     }
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         if (tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     };
-    const int full_tiles = p.Nk / 64;
+    const int full_tiles = Nk / 64;
     auto run_tiles = [&](auto fast_tag) {
         if (full_tiles > 0) do_tile(0, std::false_type{}, std::true_type{}, fast_tag);
         else do_tile(0, std::true_type{}, std::true_type{}, fast_tag);
@@ -357,6 +368,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
         }
+        if constexpr (SPLIT) {
+            // partial result of this key range: O unnormalised (fp32), its reference maximum and denominator
+            const int prow = blockIdx.x * (4 * QT * 16) + w * (QT * 16) + t * 16 + i16;
+            float* po = p.part_o + ((size_t)blockIdx.y * p.part_rows + prow) * DH;
+#pragma unroll
+            for (int a = 0; a < DVT; ++a) *reinterpret_cast<f32x4*>(po + a * 16 + 4 * g) = o_acc[a][t];
+            if (g == 0) { float* pm = p.part_ml + ((size_t)blockIdx.y * p.part_rows + prow) * 2; pm[0] = m_run[t]; pm[1] = l; }
+            continue;
+        }
         const float inv = 1.0f / l;
         const int qrow = q0 + t * 16 + i16;
         if (qrow >= p.Nq) continue;
@@ -372,8 +392,39 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
+// out[row] = sum_i 2^(m_i - m) O_i / sum_i 2^(m_i - m) l_i over the key ranges of the split-KV tail; one thread per 8 channels
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int rows_per_wg) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int prow = idx / (DH / 8), d = (idx - prow * (DH / 8)) * 8;
+    if (prow >= p.part_rows) return;
+    const int lin = p.lin0 + prow / rows_per_wg;
+    const int qblk = lin % p.nqb, hb = lin / p.nqb, h = hb % p.H, b = hb / p.H;
+    const int qrow = qblk * rows_per_wg + prow % rows_per_wg;
+    if (qrow >= p.Nq) return;
+    float m = -INFINITY;
+    for (int i = 0; i < p.splits; ++i) m = fmaxf(m, p.part_ml[((size_t)i * p.part_rows + prow) * 2]);
+    float l = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < p.splits; ++i) {
+        const float* pm = p.part_ml + ((size_t)i * p.part_rows + prow) * 2;
+        const float sc = __builtin_amdgcn_exp2f(pm[0] - m);
+        l += sc * pm[1];
+        const float* po = p.part_o + ((size_t)i * p.part_rows + prow) * DH + d;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(po), c = *reinterpret_cast<const f32x4*>(po + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] += sc * a[k]; o[4 + k] += sc * c[k]; }
+    }
+    const float inv = 1.0f / l;
+    u32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = pack2<T>(o[2 * k] * inv, o[2 * k + 1] * inv);
+    *reinterpret_cast<u32x4*>(p.out + (size_t)(b * p.Nq + qrow) * p.out_stride + h * DH + d) = r;
+}
+
+constexpr int ATTN_SLOTS = 512;      // 256 CUs x 2 resident workgroups (launch_bounds(256, 2), <= 72 KB of LDS each)
+
 template <typename T, int DH, int QT, bool CAUSAL = false, bool BIAS = false>
-int launch_attn(const AttnParams& p, int B, hipStream_t s) {
+int launch_attn(AttnParams p, int B, hipStream_t s, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
     constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
@@ -384,13 +435,55 @@ int launch_attn(const AttnParams& p, int B, hipStream_t s) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    dim3 grid((p.Nq + 4 * QT * 16 - 1) / (4 * QT * 16), p.H, B);
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, p);
+    constexpr int ROWS = 4 * QT * 16;
+    p.nqb = (p.Nq + ROWS - 1) / ROWS; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    const long total = (long)p.nqb * p.H * B;
+    if (total > 0x7fffffffL) CS_FAIL(CS_E_SHAPE, "attention: too many workgroups");
+    long main_wgs = total;
+    if constexpr (DH == 128 && !CAUSAL && !BIAS) {
+        // Split-KV tail.  The grid runs in rounds of ATTN_SLOTS workgroups; a last round that fills under half of the chip (FLUX-Kontext: 1632
+        // workgroups = 3.19 rounds) costs a whole round.  Its workgroups are instead launched once per key range (the ranges run side by side)
+        // and a small kernel merges the partial softmaxes.
+        const long tail = total % ATTN_SLOTS;
+        const int tiles = (p.Nk + 63) / 64;
+        if (split_ws && total > ATTN_SLOTS && tail > 0 && tail * 2 <= ATTN_SLOTS && tiles >= 8) {
+            int splits = (int)std::min<long>(std::min<long>(ATTN_SLOTS / tail, 8), tiles / 4);
+            const int per = (tiles + splits - 1) / splits;
+            splits = (tiles + per - 1) / per;
+            const size_t rows = (size_t)tail * ROWS;
+            const size_t need = (size_t)splits * rows * (DH + 2) * sizeof(float);
+            if (splits >= 2 && need <= split_ws_bytes) {
+                main_wgs = total - tail;
+                hipLaunchKernelGGL(kfn, dim3((unsigned)main_wgs), dim3(256), lds, s, p);
+                AttnParams t = p;
+                t.lin0 = (int)main_wgs; t.splits = splits; t.tiles_per_split = per; t.part_rows = (int)rows;
+                t.part_o = (float*)split_ws; t.part_ml = t.part_o + (size_t)splits * rows * DH;
+                auto sfn = attn_kernel<T, DH, QT, CAUSAL, BIAS, true>;
+                static bool sconf = false;
+                if (!sconf) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    sconf = true;
+                }
+                hipLaunchKernelGGL(sfn, dim3((unsigned)tail, splits), dim3(256), lds, s, t);
+                hipLaunchKernelGGL((attn_combine_kernel<T, DH>), dim3((unsigned)((rows * (DH / 8) + 255) / 256)), dim3(256), 0, s, t, ROWS);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
+            }
+        }
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)main_wgs), dim3(256), lds, s, p);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
 
 }  // namespace
+
+size_t attention_split_workspace_bytes(int B, int H, int Nq, int Nk, int dh) {
+    if (dh != 128) return 0;
+    const long total = (long)((Nq + 127) / 128) * H * B, tail = total % ATTN_SLOTS;
+    if (total <= ATTN_SLOTS || tail == 0 || tail * 2 > ATTN_SLOTS || (Nk + 63) / 64 < 8) return 0;
+    return (size_t)8 * tail * 128 * (dh + 2) * sizeof(float);
+}
 
 int launch_attention(const AttnArgs& a, hipStream_t s) {
     if (!a.q || !a.k || !a.v || !a.out) CS_FAIL(CS_E_ARG, "attention: null pointer");
@@ -422,8 +515,8 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
         case 80: if (a.dtype == CS_BF16) break; return launch_attn<f16, 80, 2>(p, a.B, s);
         case 160: if (a.dtype == CS_BF16) break; return launch_attn<f16, 160, 1>(p, a.B, s);
         case 128:
-            if (a.dtype == CS_BF16) return launch_attn<bf16_el, 128, 2>(p, a.B, s);
-            return launch_attn<f16, 128, 2>(p, a.B, s);
+            if (a.dtype == CS_BF16) return launch_attn<bf16_el, 128, 2>(p, a.B, s, a.split_ws, a.split_ws_bytes);
+            return launch_attn<f16, 128, 2>(p, a.B, s, a.split_ws, a.split_ws_bytes);
         default: break;
     }
     CS_FAIL(CS_E_UNSUPPORTED, "attention: head dim %d / dtype %d not built (f16: 40/80/160/128, bf16: 128)", a.dh, a.dtype);

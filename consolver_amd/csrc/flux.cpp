@@ -127,6 +127,7 @@ u16* copy_vec(CsFlux* f, const std::string& n) {
 
 struct FRun {
     CsFlux* f; hipStream_t s; bool dry; int rc = CS_OK; int dt;
+    void* attn_ws = nullptr; size_t attn_ws_bytes = 0;      // scratch of the attention's split-KV tail
     void* alloc(size_t bytes) {
         void* p = f->arena.alloc(bytes);
         if (!p && rc == CS_OK) { cs_set_error("flux: workspace too small"); rc = CS_E_ARG; }
@@ -173,6 +174,7 @@ struct FRun {
         a.q = (const f16*)qkv; a.q_stride = 3 * D; a.k = (const f16*)(qkv + D); a.k_stride = 3 * D; a.v = (const f16*)(qkv + 2 * D); a.v_stride = 3 * D;
         a.out = (f16*)out; a.out_stride = (int)out_stride; a.B = B; a.H = c.num_heads; a.Nq = S; a.Nk = S; a.dh = c.head_dim;
         a.scale = 1.0f / sqrtf((float)c.head_dim); a.dtype = dt;
+        a.split_ws = attn_ws; a.split_ws_bytes = attn_ws_bytes;
         rc = launch_attention(a, s);
     }
 };
@@ -194,6 +196,8 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     u16* cmlp = (u16*)Rn.alloc((size_t)B * T * 4 * D * e);           // ... and of the text stream (both FFs run in one grouped launch)
     u16* hs = (u16*)Rn.alloc((size_t)B * S * D * e); u16* nhs = (u16*)Rn.alloc((size_t)B * S * D * e);
     u16* cat = (u16*)Rn.alloc((size_t)B * S * 5 * D * e);
+    Rn.attn_ws_bytes = attention_split_workspace_bytes(B, H, S, S, dh);
+    if (Rn.attn_ws_bytes) Rn.attn_ws = Rn.alloc(Rn.attn_ws_bytes);
     if (Rn.rc != CS_OK) return Rn.rc;
 
     // ---- conditioning vector and all adaLN modulations -----------------------------------------------------

@@ -34,8 +34,10 @@ struct AttnArgs {
     int dtype;               // CS_F16 (default 0 is treated as f16) or CS_BF16
     int causal;              // 1: key j visible to query i iff j <= i (CLIP text encoder; f16, dh 64, Nq == Nk)
     const float* bias;       // additive score bias [H][Nq][Nk] fp32, already multiplied by log2(e) (T5 relative positions; bf16, dh 64), or null
+    void* split_ws; size_t split_ws_bytes;   // optional scratch for the split-KV tail (head dim 128): attention_split_workspace_bytes()
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
+size_t attention_split_workspace_bytes(int B, int H, int Nq, int Nk, int dh);
 
 // GroupNorm over NHWC [B][HW][C0+C1] (two-source concat), 32 groups.
 // stats -> partial[B][S][C] (sum, sumsq); apply normalises (+SiLU) into out [B][HW][C].

@@ -67,6 +67,16 @@ int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, in
     return launch_gemm2(g, (hipStream_t)stream);
 }
 
+size_t cs_op_attention_workspace(int B, int H, int Nq, int Nk, int dh) { return attention_split_workspace_bytes(B, H, Nq, Nk, dh); }
+int cs_op_attention_ws(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                       int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    AttnArgs a{};
+    a.q = (const f16*)q; a.q_stride = q_stride; a.k = (const f16*)k; a.k_stride = k_stride; a.v = (const f16*)v; a.v_stride = v_stride;
+    a.out = (f16*)out; a.out_stride = out_stride; a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.dh = dh; a.scale = scale; a.dtype = dtype;
+    a.split_ws = workspace; a.split_ws_bytes = workspace_bytes;
+    return launch_attention(a, (hipStream_t)stream);
+}
+
 static Gemm2Args g2_from(const CsGemm2Problem& q, int dtype) {
     Gemm2Args g{};
     g.a = q.x; g.lda = q.K; g.w = q.w; g.bias = q.bias; g.M = q.M; g.N = q.N; g.K = q.K; g.out = q.out; g.res = q.res; g.ldc = q.ldc ? q.ldc : q.N;

@@ -68,6 +68,13 @@ int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream);
 
+/* cs_op_attention_ex with scratch memory for the split-KV tail: when the workgroup count leaves a last round that fills under half of the
+ * chip (head dim 128, e.g. FLUX-Kontext's 8704-token joint sequence), that round's query blocks are computed once per key range and merged.
+ * cs_op_attention_workspace returns the bytes to provide (0: the shape never splits); results equal cs_op_attention_ex up to fp32 rounding. */
+size_t cs_op_attention_workspace(int B, int H, int Nq, int Nk, int dh);
+int cs_op_attention_ws(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
+                       int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* causal form (key j visible to query i iff j <= i): f16, head dim 64, Nq == Nk = N (CLIP text encoder) */
 int cs_op_attention_causal(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                            int B, int H, int N, int dh, float scale, void* stream);

@@ -78,6 +78,32 @@ def test_gemm2_pair_matches_two_single_launches():
     assert rel_l2(keep[0][6].float(), ref) < 8e-3
 
 
+@pytest.mark.parametrize("dt,code,tol", [(torch.bfloat16, 2, 2e-2), (torch.float16, 1, 3e-3)])
+def test_attention_split_kv_tail_matches_unsplit(dt, code, tol):
+    """head dim 128 with a workgroup count that leaves a small last round: the split-KV tail (partial softmaxes over key ranges + merge)
+    must agree with the unsplit kernel and with an fp32 softmax; ragged Nq and Nk on purpose"""
+    g = torch.Generator().manual_seed(3)
+    B, H, S = 1, 9, 7717            # 61 query blocks x 9 heads = 549 workgroups = 512 + 37 -> the last 37 are split over key ranges
+    q, k, v = ((torch.randn(B, S, H * 128, generator=g) * (1.5 if i == 0 else 1.0)).to(dt).to(DEV) for i in range(3))
+    o0, o1 = torch.empty_like(q), torch.empty_like(q)
+    st = L.stream_ptr(q.device)
+    L.check(L.lib().cs_op_attention_ex(q.data_ptr(), H * 128, k.data_ptr(), H * 128, v.data_ptr(), H * 128, o0.data_ptr(), H * 128,
+                                       B, H, S, S, 128, 128 ** -0.5, code, st))
+    nb = L.lib().cs_op_attention_workspace(B, H, S, S, 128)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    L.check(L.lib().cs_op_attention_ws(q.data_ptr(), H * 128, k.data_ptr(), H * 128, v.data_ptr(), H * 128, o1.data_ptr(), H * 128,
+                                       B, H, S, S, 128, 128 ** -0.5, code, ws.data_ptr(), nb, st))
+    torch.cuda.synchronize()
+    assert rel_l2(o1.float(), o0.float()) < 2e-3
+    # the rows of the split workgroups against fp32 math: last head, last query blocks
+    hsel = H - 1
+    qf, kf, vf = (t[0, :, hsel * 128:(hsel + 1) * 128].float() for t in (q, k, v))
+    ref = torch.softmax(qf[-1500:] @ kf.T * 128 ** -0.5, -1) @ vf
+    assert rel_l2(o1[0, -1500:, hsel * 128:(hsel + 1) * 128].float(), ref) < tol
+    assert L.lib().cs_op_attention_workspace(B, 8, 4096, 4096, 128) == 0      # 32 x 8 = 256 workgroups: no tail to split
+
+
 def test_layout_helpers_roundtrip():
     x = torch.arange(2 * 16 * 8 * 12, dtype=torch.float32).view(2, 16, 8, 12)
     p = pack_latents(x)
