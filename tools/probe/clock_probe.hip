@@ -437,7 +437,7 @@ int main() {
     srand(1);
     for (size_t i = 0; i < n; ++i) h[i] = (f16)((rand() / (float)RAND_MAX - 0.5f) * 0.25f);
     hipMemcpy(d, h.data(), n * sizeof(f16), hipMemcpyHostToDevice);
-    for (long mb : {16L, 1024L}) {
+    for (long mb : {2L, 16L, 1024L}) {     // 2 MB: inside one XCD's 4 MB L2; 16 MB: Infinity Cache; 1 GB: HBM
         const long rows = mb * 1024 * 1024 / 128;
         f16* stream; hipMalloc(&stream, rows * 128);
         for (long o = 0; o < rows * 64; o += (long)n) hipMemcpy(stream + o, d, std::min((long)n, rows * 64 - o) * sizeof(f16), hipMemcpyDeviceToDevice);
@@ -445,10 +445,12 @@ int main() {
         run_dma<0>(d, stream, rows, "burst at top, vmcnt(0) + barrier (as shipped):", st, sink);
         run_dma<1>(d, stream, rows, "pieces spread between MFMA groups, vmcnt(0):", st, sink);
         run_dma<2>(d, stream, rows, "burst, vmcnt(9): one stage stays in flight:", st, sink);
-        run_regstage(d, stream, rows, st, sink);
-        run_direct(d, stream, rows, st, sink);
-        run_4wave<0>(d, stream, rows, st, sink);
-        run_4wave<1>(d, stream, rows, st, sink);
+        if (mb >= 16) {     // (these walk the table in strides that assume >= 16 MB)
+            run_regstage(d, stream, rows, st, sink);
+            run_direct(d, stream, rows, st, sink);
+            run_4wave<0>(d, stream, rows, st, sink);
+            run_4wave<1>(d, stream, rows, st, sink);
+        }
         hipFree(stream);
     }
     run_overlap(d, st, sink);
