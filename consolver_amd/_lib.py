@@ -141,7 +141,8 @@ SYMBOLS = {
     "cs_op_attention_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "cs_op_attention_ws": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cs_op_gemm2_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "cs_op_gemm2_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_op_gemm2_workspace": (C.c_size_t, [C.c_int, C.c_int]),
     "cs_op_attention_causal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "cs_op_rms_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),

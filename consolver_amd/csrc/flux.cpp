@@ -128,6 +128,7 @@ u16* copy_vec(CsFlux* f, const std::string& n) {
 struct FRun {
     CsFlux* f; hipStream_t s; bool dry; int rc = CS_OK; int dt;
     void* attn_ws = nullptr; size_t attn_ws_bytes = 0;      // scratch of the attention's split-KV tail
+    void* tail_ws = nullptr; size_t tail_ws_bytes = 0;      // scratch of the GEMMs' split-K tail
     void* alloc(size_t bytes) {
         void* p = f->arena.alloc(bytes);
         if (!p && rc == CS_OK) { cs_set_error("flux: workspace too small"); rc = CS_E_ARG; }
@@ -148,14 +149,14 @@ struct FRun {
         if (dry) { f->dry_flops += 2.0 * M * (double)L.n * L.k; return; }
         if (rc != CS_OK) return;
         Gemm2Args g = gargs(L, a, lda, M, out, ldc, col_off, act, res, gate, gate_stride, rows_per_sample, a_seg, a_stride, a_off, c_seg, c_stride, c_off);
-        g.dtype = dt;
+        g.dtype = dt; g.tail_ws = tail_ws; g.tail_ws_bytes = tail_ws_bytes;
         rc = launch_gemm2(g, s);
     }
     // the image-stream and text-stream linears of one stage in a single grouped launch
     void gemm_pair(Gemm2Args x, Gemm2Args y) {
         if (dry) { f->dry_flops += 2.0 * x.M * (double)x.N * x.K + 2.0 * y.M * (double)y.N * y.K; return; }
         if (rc != CS_OK) return;
-        x.dtype = y.dtype = dt;
+        x.dtype = y.dtype = dt; x.tail_ws = tail_ws; x.tail_ws_bytes = tail_ws_bytes;
         rc = launch_gemm2_pair(x, y, s);
     }
     void small(const float* x, int Rr, int K, const u16* w, const u16* b, long N, float* out, int silu_in, int silu_out) {
@@ -196,6 +197,13 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     u16* cmlp = (u16*)Rn.alloc((size_t)B * T * 4 * D * e);           // ... and of the text stream (both FFs run in one grouped launch)
     u16* hs = (u16*)Rn.alloc((size_t)B * S * D * e); u16* nhs = (u16*)Rn.alloc((size_t)B * S * D * e);
     u16* cat = (u16*)Rn.alloc((size_t)B * S * 5 * D * e);
+    {   // long-K launches whose last round is partly empty: image + text FF2 (K = 4 D), single-stream proj_out (K = 5 D)
+        const int tD = (D + 255) / 256;
+        const size_t t1 = gemm2_tail_workspace_bytes(((B * I + 255) / 256 + (B * T + 255) / 256) * tD, 4 * D);
+        const size_t t2 = gemm2_tail_workspace_bytes(((B * S + 255) / 256) * tD, 5 * D);
+        Rn.tail_ws_bytes = t1 > t2 ? t1 : t2;
+        if (Rn.tail_ws_bytes) Rn.tail_ws = Rn.alloc(Rn.tail_ws_bytes);
+    }
     Rn.attn_ws_bytes = attention_split_workspace_bytes(B, H, S, S, dh);
     if (Rn.attn_ws_bytes) Rn.attn_ws = Rn.alloc(Rn.attn_ws_bytes);
     if (Rn.rc != CS_OK) return Rn.rc;

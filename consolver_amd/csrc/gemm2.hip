@@ -13,6 +13,7 @@
 // single-stream block write attention output and MLP activation side by side.
 #include "ops.h"
 #include "el.h"
+#include <algorithm>
 
 namespace {
 
@@ -46,7 +47,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // Up to two independent problems per launch (grouped GEMM): workgroups [0, nblk0) compute tiles of p[0], the rest tiles of p[1].
 // FLUX's double-stream blocks run the image-token and text-token linears of one stage side by side: the 512 text rows alone fill 24-96
 // of the 256 CUs for a whole tile time, appended to the image problem's tile list they ride in its last, partly empty round.
-struct G2Pair { G2Params p[2]; int nblk0, nblk; };
+// Split-K tail (single-problem launches): the launch covers tiles [id0, id0 + nblk) and, when splits > 1, blockIdx.y picks the k range;
+// the fp32 partial tiles go to `partial` ([tile - id0][split][256][256]) and g2_tail_reduce_kernel applies the epilogue.
+struct G2Pair { G2Params p[2]; int nblk0, nblk; int id0, splits; float* partial; };
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
@@ -63,9 +66,17 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         const int bid = blockIdx.x, xcd = bid & 7, q = pp.nblk >> 3, r = pp.nblk & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int tail_tile = id;                 // index into the partial buffer (split-K tail)
+    id += pp.id0;
     const int second = id >= pp.nblk0;
     const G2Params& p = pp.p[second];
     if (second) id -= pp.nblk0;
+    // k range of this workgroup (all of K unless this is a split-K tail launch)
+    int kt0 = 0, KT = p.KT;
+    if (pp.splits > 1) {
+        const int per = (p.KT + pp.splits - 1) / pp.splits;
+        kt0 = blockIdx.y * per; KT = min(per, p.KT - kt0);
+    }
     // Tile order: bands of GM row-tiles, row-tile fastest inside a band.  The ~32 tiles an XCD runs at once (consecutive ids) then
     // cover GM x (32 / GM) tiles: GM activation panels + 32/GM weight panels per k-step through that XCD's L2 instead of 1 + 32 in plain
     // row-major order (FLUX: 36-84 column tiles per row), which is what the fabric can feed at the k-step rate.
@@ -83,13 +94,13 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         const int r = 8 * (w * 4 + j) + (lane >> 3);
         const int m = m_blk + r;
         a_ok[j] = m < p.M;
-        a_src[j] = p.a + rowmap(a_ok[j] ? m : 0, p.a_seg, p.a_stride, p.a_off) * p.lda + (pch ^ ((r >> 1) & 7)) * 8;
+        a_src[j] = p.a + rowmap(a_ok[j] ? m : 0, p.a_seg, p.a_stride, p.a_off) * p.lda + (size_t)kt0 * BK + (pch ^ ((r >> 1) & 7)) * 8;
     }
     const u16* b_src[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * (w * 4 + j) + (lane >> 3);
-        b_src[j] = p.w + (size_t)(n_blk + r) * p.K + (pch ^ ((r >> 1) & 7)) * 8;
+        b_src[j] = p.w + (size_t)(n_blk + r) * p.K + (size_t)kt0 * BK + (pch ^ ((r >> 1) & 7)) * 8;
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page2) + pch * 16;
 
@@ -139,9 +150,9 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.KT > 1) stage(1, 1);
+    if (KT > 1) stage(1, 1);
     ldfa(faA, smem + (wm * 64) * 128, frag_off0); ldfw(fwA, smem + A_BYTES + (wn * 128) * 128, 0, frag_off0);
-    for (int kt = 0; kt < p.KT; ++kt) {
+    for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
         const char* tb = smem + buf * STAGE + A_BYTES + (wn * 128) * 128;
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         __syncthreads();
         // group 3 (the DMA pieces are issued unconditionally -- past the end they re-load the last stage into a buffer nobody reads
         // again -- so that the whole group stays one scheduling region and the pieces interleave with the MFMAs)
-        stage(kt + 2 < p.KT ? kt + 2 : p.KT - 1, buf);
+        stage(kt + 2 < KT ? kt + 2 : KT - 1, buf);
         ldfa(faA, tan, frag_off0); ldfw(fwA, tbn, 0, frag_off0); mm(1, fwB, faB);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -172,6 +183,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     }
     __syncthreads();
 
+    if (pp.splits > 1) {      // raw fp32 partial tile; the reduce kernel owns bias / gate / residual / rounding
+        float* dst = pp.partial + ((size_t)tail_tile * pp.splits + blockIdx.y) * (BMX * BNX);
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<f32x4*>(dst + (wm * 64 + j * 16 + (lane & 15)) * BNX + wn * 128 + i * 16 + (lane >> 4) * 4) = acc[i][j];
+        return;
+    }
     // ---- epilogue: per wave 64 rows x 128 cols in two passes of 64 cols through an LDS patch --------------
     constexpr int COLS = 64, ROWB = (COLS + 8) * 2, CH = COLS / 8;
     char* patch = smem + w * (64 * ROWB);
@@ -238,6 +258,54 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     }
 }
 
+// split-K tail: out tile = epilogue(sum of the fp32 partial tiles); one thread per 8 output columns (no activation: the long-K layers have none)
+template <typename T>
+__global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tile = (int)(idx / (256 * 32));
+    if (tile >= pp.nblk) return;
+    const int splits = pp.splits;
+    const float* __restrict__ partial = pp.partial;
+    const int rem = (int)(idx - (long)tile * (256 * 32)), r = rem >> 5, c = (rem & 31) * 8;
+    int id = pp.id0 + tile;
+    const int second = id >= pp.nblk0;
+    const G2Params& p = pp.p[second];
+    if (second) id -= pp.nblk0;
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;      // plain row-major order (tiles_n < 24)
+    const int m = tm * 256 + r, n = tn * 256 + c;
+    if (m >= p.M || n >= p.N) return;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < splits; ++sp) {
+        const float* src = partial + ((size_t)tile * splits + sp) * (256 * 256) + r * 256 + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[k] += a[k]; f[4 + k] += b[k]; }
+    }
+    if (p.bias) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(p.bias + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(t[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(t[k] >> 16)); }
+    }
+    // same rounding points as the in-kernel epilogue: the biased value is rounded to T before gate / residual
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = El<T>::tof(El<T>::fromf(f[k]));
+    const size_t off = (size_t)rowmap(m, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + n;
+    if (p.gate) {
+        const float* gp = p.gate + (size_t)(m / p.rows_per_sample) * p.gate_stride + n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] *= gp[k];
+    }
+    if (p.res) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(rv[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(rv[k] >> 16)); }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (unsigned)El<T>::fromf(f[2 * k]) | ((unsigned)El<T>::fromf(f[2 * k + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p.out + off) = o;
+}
+
 // tiny-M linear: out[r][n] = act(sum_k x[r][k] w[n][k] + b[n]); x/out fp32, weights T.  One wave per n.
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int R, int K, const u16* __restrict__ w,
@@ -286,7 +354,9 @@ static int g2_fill(const Gemm2Args& a, G2Params& p) {
     return CS_OK;
 }
 
-static int g2_launch(const G2Pair& pp, int dtype, hipStream_t s) {
+constexpr int G2_CUS = 256;
+
+static int g2_launch(G2Pair pp, int dtype, hipStream_t s, dim3 grid) {
     constexpr size_t lds = 2 * (256 * BK * 2 + 256 * BK * 2);
     static bool configured = false;
     if (!configured) {
@@ -294,32 +364,72 @@ static int g2_launch(const G2Pair& pp, int dtype, hipStream_t s) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<bf16_el>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    if (dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, dim3(pp.nblk), dim3(512), lds, s, pp);
-    else if (dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, dim3(pp.nblk), dim3(512), lds, s, pp);
+    if (dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, grid, dim3(512), lds, s, pp);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, grid, dim3(512), lds, s, pp);
     else CS_FAIL(CS_E_DTYPE, "gemm2: dtype must be f16 or bf16");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// Tail split: one tile per CU per round; when the last round is partly empty and K is long, its tiles are computed as `splits` k ranges side by
+// side (ceil(tail * splits / 256) rounds of 1/splits the length) and summed by the reduce kernel.  Returns 0 when it does not pay.
+static int g2_tail_splits(int nblk, int min_kt, bool plain, int* tail_out) {
+    const int tail = nblk % G2_CUS;
+    *tail_out = tail;
+    if (nblk <= G2_CUS || tail == 0 || min_kt < 96 || !plain) return 0;
+    int best = 0; double best_cost = 0.93;       // fraction of a full round; the partial write + reduce pass costs the rest
+    for (int sp = 2; sp <= 6; ++sp) {
+        const double cost = (double)((tail * sp + G2_CUS - 1) / G2_CUS) / sp + 0.035 * sp;
+        if (cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+static bool g2_plain(const G2Params& p) { return p.act == 0 && p.tiles_n < 24; }
+
+size_t gemm2_tail_workspace_bytes(int tiles, int K) {
+    int tail; const int sp = g2_tail_splits(tiles, K / BK, true, &tail);
+    return sp ? (size_t)tail * sp * 256 * 256 * sizeof(float) : 0;
+}
+
+static int g2_run(G2Pair pp, int dtype, void* tail_ws, size_t tail_ws_bytes, hipStream_t s) {
+    pp.id0 = 0; pp.splits = 1; pp.partial = nullptr;
+    const bool two = pp.nblk > pp.nblk0;
+    int tail = 0;
+    const int sp = tail_ws ? g2_tail_splits(pp.nblk, two ? std::min(pp.p[0].KT, pp.p[1].KT) : pp.p[0].KT, g2_plain(pp.p[0]) && (!two || g2_plain(pp.p[1])), &tail) : 0;
+    if (!sp || (size_t)tail * sp * 256 * 256 * sizeof(float) > tail_ws_bytes) return g2_launch(pp, dtype, s, dim3(pp.nblk));
+    const int main_tiles = pp.nblk - tail;
+    pp.nblk = main_tiles;
+    int rc = g2_launch(pp, dtype, s, dim3(main_tiles));
+    if (rc != CS_OK) return rc;
+    pp.nblk = tail; pp.id0 = main_tiles; pp.splits = sp; pp.partial = (float*)tail_ws;
+    rc = g2_launch(pp, dtype, s, dim3(tail, sp));
+    if (rc != CS_OK) return rc;
+    const unsigned blocks = (unsigned)(((long)tail * 256 * 32 + 255) / 256);
+    if (dtype == CS_F16) hipLaunchKernelGGL(g2_tail_reduce_kernel<f16>, dim3(blocks), dim3(256), 0, s, pp);
+    else hipLaunchKernelGGL(g2_tail_reduce_kernel<bf16_el>, dim3(blocks), dim3(256), 0, s, pp);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
 
 int launch_gemm2(const Gemm2Args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return (a.M < 0 || a.N < 0) ? CS_E_SHAPE : CS_OK;
-    G2Pair pp;
+    G2Pair pp{};
     const int rc = g2_fill(a, pp.p[0]);
     if (rc != CS_OK) return rc;
     pp.p[1] = pp.p[0]; pp.nblk0 = pp.nblk = pp.p[0].nblk;
-    return g2_launch(pp, a.dtype, s);
+    return g2_run(pp, a.dtype, a.tail_ws, a.tail_ws_bytes, s);
 }
 
 int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) {
     if (a.dtype != b.dtype) CS_FAIL(CS_E_DTYPE, "gemm2 pair: both problems must have the same dtype");
     if (a.M <= 0 || a.N <= 0) return launch_gemm2(b, s);
     if (b.M <= 0 || b.N <= 0) return launch_gemm2(a, s);
-    G2Pair pp;
+    G2Pair pp{};
     int rc = g2_fill(a, pp.p[0]);
     if (rc == CS_OK) rc = g2_fill(b, pp.p[1]);
     if (rc != CS_OK) return rc;
     pp.nblk0 = pp.p[0].nblk; pp.nblk = pp.p[0].nblk + pp.p[1].nblk;
-    return g2_launch(pp, a.dtype, s);
+    return g2_run(pp, a.dtype, a.tail_ws, a.tail_ws_bytes, s);
 }
 
 int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,

@@ -77,8 +77,10 @@ struct Gemm2Args {
     const float* gate; long gate_stride; int rows_per_sample;   // out = res + gate[m / rows_per_sample][n] * v
     int act;                               // 0 none, 1 GELU(tanh)
     int dtype;
+    void* tail_ws; size_t tail_ws_bytes;   // optional scratch for the split-K tail (gemm2_tail_workspace_bytes)
 };
 int launch_gemm2(const Gemm2Args& a, hipStream_t s);
+size_t gemm2_tail_workspace_bytes(int tiles, int K);   // tiles = 256 x 256 output tiles of the launch (both problems of a pair); 0: never splits
 // two independent problems (same dtype) in one launch: b's tiles are appended to a's tile list
 int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s);
 int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,

@@ -83,10 +83,14 @@ static Gemm2Args g2_from(const CsGemm2Problem& q, int dtype) {
     g.c_col_off = q.col_off; g.gate = q.gate; g.gate_stride = q.gate_stride; g.rows_per_sample = q.rows_per_sample; g.act = q.act; g.dtype = dtype;
     return g;
 }
-int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype, void* stream) {
-    if (!a || !b) CS_FAIL(CS_E_ARG, "gemm2 pair: null problem");
-    return launch_gemm2_pair(g2_from(*a, dtype), g2_from(*b, dtype), (hipStream_t)stream);
+int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a) CS_FAIL(CS_E_ARG, "gemm2 pair: null problem");
+    Gemm2Args ga = g2_from(*a, dtype);
+    ga.tail_ws = workspace; ga.tail_ws_bytes = workspace_bytes;
+    if (!b) return launch_gemm2(ga, (hipStream_t)stream);
+    return launch_gemm2_pair(ga, g2_from(*b, dtype), (hipStream_t)stream);
 }
+size_t cs_op_gemm2_workspace(int tiles, int K) { return gemm2_tail_workspace_bytes(tiles, K); }
 
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream) {

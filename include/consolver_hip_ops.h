@@ -63,7 +63,12 @@ typedef struct CsGemm2Problem {
     const void* res; const float* gate; long gate_stride; int rows_per_sample; int act;
     void* out; long ldc; int col_off;
 } CsGemm2Problem;
-int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b, int dtype, void* stream);
+int cs_op_gemm2_pair(const CsGemm2Problem* a, const CsGemm2Problem* b /* may be NULL */, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* Scratch for the split-K tail of a launch of `tiles` 256 x 256 output tiles (both problems together) with inner dimension K: when the last
+ * round of tiles (one per CU) is partly empty and K >= 6144, that round's tiles are computed as 2-6 k ranges side by side into fp32 partial
+ * tiles and summed (same rounding points as the unsplit epilogue; the fp32 summation order differs).  0: the launch never splits;
+ * workspace may be NULL (no split). */
+size_t cs_op_gemm2_workspace(int tiles, int K);
 /* cs_op_attention with an explicit dtype (bf16: head dim 128) */
 int cs_op_attention_ex(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* stream);

@@ -69,13 +69,51 @@ def test_gemm2_pair_matches_two_single_launches():
                                     out1.data_ptr(), N, 0, code, L.stream_ptr(x.device)))
         probs.append(L.CsGemm2Problem(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, res.data_ptr() if gated else None,
                                       gate.data_ptr() if gated else None, N, 100, act, out2.data_ptr(), N, 0))
-    L.check(L.lib().cs_op_gemm2_pair(C.byref(probs[0]), C.byref(probs[1]), code, L.stream_ptr(DEV)))
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(probs[0]), C.byref(probs[1]), code, None, 0, L.stream_ptr(DEV)))
     torch.cuda.synchronize()
     for (x, w, b, res, gate, out1, out2) in keep:
         assert torch.equal(out1, out2)
     x, w, b = keep[0][:3]
     ref = torch.nn.functional.gelu(x.float() @ w[:768].float().T + b.float(), approximate="tanh")
     assert rel_l2(keep[0][6].float(), ref) < 8e-3
+
+
+def test_gemm2_split_k_tail_matches_unsplit():
+    """long-K launch whose last round of tiles is partly empty (image + text problem: 272 + 8 tiles): the split-K tail (fp32 partial tiles +
+    reduce kernel with bias / gate / residual) must match the unsplit launch up to the fp32 summation order"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(2)
+    dt, code, K, N = torch.bfloat16, 2, 6144, 2048
+    probs1, probs2, outs = [], [], []
+    keep = []
+    for M in (34 * 256 - 100, 200):
+        x = torch.randn(M, K, generator=g).to(dt).to(DEV); w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+        b = torch.randn(N, generator=g).to(dt).to(DEV); res = torch.randn(M, N, generator=g).to(dt).to(DEV); gate = torch.randn(1, N, generator=g).to(DEV)
+        o1, o2 = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
+        keep.append((x, w, b, res, gate, o1, o2))
+        mk = lambda o: L.CsGemm2Problem(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, res.data_ptr(), gate.data_ptr(), N, M, 0, o.data_ptr(), N, 0)
+        probs1.append(mk(o1)); probs2.append(mk(o2))
+    tiles = 34 * 8 + 8
+    nb = L.lib().cs_op_gemm2_workspace(tiles, K)
+    assert nb > 0 and L.lib().cs_op_gemm2_workspace(tiles, 3072) == 0 and L.lib().cs_op_gemm2_workspace(512, K) == 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    st = L.stream_ptr(DEV)
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(probs1[0]), C.byref(probs1[1]), code, None, 0, st))
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(probs2[0]), C.byref(probs2[1]), code, ws.data_ptr(), nb, st))
+    torch.cuda.synchronize()
+    for (x, w, b, res, gate, o1, o2) in keep:
+        assert rel_l2(o2.float(), o1.float()) < 2e-3
+        ref = res.float() + gate * (x.float() @ w.float().T + b.float())
+        assert rel_l2(o2.float(), ref) < 8e-3
+    # single problem through the same entry point (b = NULL)
+    o3 = torch.empty_like(keep[0][5])
+    x, w, b, res, gate = keep[0][:5]
+    pr = L.CsGemm2Problem(x.data_ptr(), x.shape[0], K, w.data_ptr(), b.data_ptr(), N, res.data_ptr(), gate.data_ptr(), N, x.shape[0], 0, o3.data_ptr(), N, 0)
+    nb1 = L.lib().cs_op_gemm2_workspace(34 * 8, K)
+    assert 0 < nb1 <= nb
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(pr), None, code, ws.data_ptr(), nb, st))
+    torch.cuda.synchronize()
+    assert rel_l2(o3.float(), keep[0][5].float()) < 2e-3
 
 
 @pytest.mark.parametrize("dt,code,tol", [(torch.bfloat16, 2, 2e-2), (torch.float16, 1, 3e-3)])
