@@ -366,6 +366,100 @@ static void run_4wave(const f16* d, const f16* stream, long rows, unsigned long 
            flops / (ms * 1e-3) / 1e12, ghz[blocks / 2], (double)s[0] / iters);
 }
 
+// MODE 6 experiment: FOUR waves (one per SIMD, 512 registers each) on a 256 x 256 x 64 tile, wave tile 128 x 128 (256 accumulator registers =
+// the whole AGPR file; the 128 x 160 wave tile of MODE 4 needs 320, which the compiler can only serve by shuffling accumulators between AGPRs and
+// VGPRs -- 1257 v_accvgpr moves in that loop, so MODE 4's numbers measure the shuffling, not the structure), WITH an explicit software pipeline:
+// the fragments of MFMA group g+1 (32 MFMAs: one k32 half x 4 column tiles x 8 row tiles) are read from LDS while group g issues, two register
+// sets, the per-step barrier between groups 2 and 3, the 16 DMA pieces interleaved into group 3.  LDS fragment reads per k-step: 128 KB
+// (8 waves x 64 x 128: 192 KB).  A single wave per SIMD has nobody to hide its LDS latency behind: it must never wait on a read it just issued.
+__global__ __launch_bounds__(256, 1) void probe_4wave_swp(const f16* __restrict__ src, const f16* __restrict__ stream, long stream_rows, int iters,
+                                                          unsigned long long* stamps, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x 64 KB
+    constexpr int STG = 65536;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    for (int i = tid; i < 2 * 512 * 8; i += 256) *reinterpret_cast<f16x8*>(smem + i * 16) = *reinterpret_cast<const f16x8*>(src + (size_t)(i % (512 * 8)) * 8);
+    __syncthreads();
+    f32x4 acc[8][8];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + ((lane >> 4) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    long row = ((long)blockIdx.x * 577 + w * 128 + (lane >> 3)) % stream_rows;
+    f16x8 faA[8], faB[8], fwA[4], fwB[4];
+    auto ldfa = [&](f16x8 (&fa)[8], const char* ta, int fo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
+    };
+    auto ldfw = [&](f16x8 (&fw)[4], const char* tb, int half, int fo) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * 4 + i) * 2048 + fo);
+    };
+    auto mm = [&](int ks_half, const f16x8 (&fw)[4], const f16x8 (&fa)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[ks_half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[ks_half * 4 + i][j], 0, 0, 0);
+    };
+    ldfa(faA, smem + (wm * 128) * 128, fo0); ldfw(fwA, smem + 256 * 128 + (wn * 128) * 128, 0, fo0);
+    for (int it = 0; it < iters; ++it) {
+        const int buf = it & 1;
+        const char* ta = smem + buf * STG + (wm * 128) * 128; const char* tb = smem + buf * STG + 256 * 128 + (wn * 128) * 128;
+        const char* tan = smem + (buf ^ 1) * STG + (wm * 128) * 128; const char* tbn = smem + (buf ^ 1) * STG + 256 * 128 + (wn * 128) * 128;
+        char* dst = smem + buf * STG + w * 16 * 1024;
+        // group 0
+        ldfw(fwB, tb, 1, fo0); mm(0, fwA, faA);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); }
+        // group 1
+        ldfa(faB, ta, fo1); ldfw(fwA, tb, 0, fo1); mm(1, fwB, faA);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+        // group 2
+        ldfw(fwB, tb, 1, fo1); mm(0, fwA, faB);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 8, 0); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // group 3: refill this stage's buffer, prefetch group 0 of the next k-step from the other one
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(stream + (row * 64 + (lane & 7) * 8)), (lptr_t)(dst + j * 1024), 16, 0, 0);
+            row += 8; if (row >= stream_rows) row -= stream_rows;
+        }
+        ldfa(faA, tan, fo0); ldfw(fwA, tbn, 0, fo0); mm(1, fwB, faB);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+    }
+    if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+    float s = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+static void run_4wave_swp(const f16* d, const f16* stream, long rows, unsigned long long* st, float* sink) {
+    const int blocks = 256, iters = 4000;
+    hipFuncSetAttribute((const void*)probe_4wave_swp, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        for (int k = 0; k < 12; ++k) hipLaunchKernelGGL(probe_4wave_swp, dim3(blocks), dim3(256), 2 * 65536, 0, d, stream, rows, iters, st, sink);
+        hipEventRecord(b); hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b); ms /= 12;
+    }
+    std::vector<unsigned long long> s(blocks * 2);
+    hipMemcpy(s.data(), st, s.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int i = 0; i < blocks; ++i) ghz.push_back((double)s[2 * i] / (double)s[2 * i + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double flops = (double)blocks * iters * 4 * 128 * 16384.0;
+    printf("  4 waves x (128 x 128) on 256 x 256 x 64, software-pipelined: %.1f TFLOP/s, clock %.3f GHz, cycles per k-step %.0f (2048 = MFMA-bound)\n",
+           flops / (ms * 1e-3) / 1e12, ghz[blocks / 2], (double)s[0] / iters);
+}
+
 // Does a store stream on the same CUs slow the staged k loop down?  store_stream writes 16 B per lane to a large buffer (HBM bound);
 // it is launched on a second stream next to probe_dma<1> (144 KB of LDS per workgroup leaves room for LDS-free workgroups on every CU).
 __global__ __launch_bounds__(256) void store_stream(uint4* __restrict__ dst, long n16, int reps) {
@@ -450,6 +544,7 @@ int main() {
             run_direct(d, stream, rows, st, sink);
             run_4wave<0>(d, stream, rows, st, sink);
             run_4wave<1>(d, stream, rows, st, sink);
+            run_4wave_swp(d, stream, rows, st, sink);
         }
         hipFree(stream);
     }
