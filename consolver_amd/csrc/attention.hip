@@ -126,18 +126,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const f16* vbase = p.v + ((size_t)b * p.Nk + key0) * p.v_stride + h * DH;
 
     u32x4 kreg[NCH], vreg[NCH];
-    // per-thread staging slots (loop invariant): chunk id -> (row, 16-byte chunk) of the 64-key tile
-    int st_row[NCH], st_koff[NCH], st_voff[NCH], st_lk[NCH], st_lv[NCH];
+    // per-thread staging slots (loop invariant): chunk id -> (row, 16-byte chunk) of the 64-key tile.  When the 256 threads cover whole rows
+    // (dh 64 / 128) slot c is slot 0 moved down by c * RPC rows, so only slot 0's offsets are kept in registers.
+    constexpr bool REG = (256 % CPR == 0) && (NCH * 256 == 64 * CPR);
+    constexpr int RPC = 256 / CPR;
+    int st_row_[NCH], st_koff_[NCH], st_voff_[NCH], st_lk_[NCH], st_lv_[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int id = tid + c * 256;
         const int row = id / CPR, ch = id - row * CPR;
-        st_row[c] = (id < 64 * CPR) ? row : (1 << 20);            // slots past the tile never pass a bounds test
-        st_koff[c] = (id < 64 * CPR) ? row * p.k_stride + ch * 8 : 0;   // idle slots re-read key 0 (never stored)
-        st_voff[c] = (id < 64 * CPR) ? row * p.v_stride + ch * 8 : 0;
-        st_lk[c] = row * KS + (KSWZ ? (ch ^ (row & 7)) : ch) * 16;
-        st_lv[c] = row * VS + ch * 16;
+        st_row_[c] = (id < 64 * CPR) ? row : (1 << 20);            // slots past the tile never pass a bounds test
+        st_koff_[c] = (id < 64 * CPR) ? row * p.k_stride + ch * 8 : 0;   // idle slots re-read key 0 (never stored)
+        st_voff_[c] = (id < 64 * CPR) ? row * p.v_stride + ch * 8 : 0;
+        st_lk_[c] = row * KS + (KSWZ ? (ch ^ (row & 7)) : ch) * 16;
+        st_lv_[c] = row * VS + ch * 16;
     }
+    auto st_row = [&](int c) { return REG ? st_row_[0] + c * RPC : st_row_[c]; };
+    auto st_koff = [&](int c) { return REG ? st_koff_[0] + c * RPC * p.k_stride : st_koff_[c]; };
+    auto st_voff = [&](int c) { return REG ? st_voff_[0] + c * RPC * p.v_stride : st_voff_[c]; };
+    auto st_lk = [&](int c) { return REG ? st_lk_[0] + c * RPC * KS : st_lk_[c]; };
+    auto st_lv = [&](int c) { return REG ? st_lv_[0] + c * RPC * VS : st_lv_[c]; };
     auto load_tile = [&](int tile) {
         const f16* kt_base = kbase + (size_t)tile * 64 * p.k_stride;
         const f16* vt_base = vbase + (size_t)tile * 64 * p.v_stride;
@@ -145,16 +153,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         if (rows_left >= 64) {                                    // wave-uniform fast path: no per-lane guards
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                kreg[c] = *reinterpret_cast<const u32x4*>(kt_base + st_koff[c]);
-                vreg[c] = *reinterpret_cast<const u32x4*>(vt_base + st_voff[c]);
+                kreg[c] = *reinterpret_cast<const u32x4*>(kt_base + st_koff(c));
+                vreg[c] = *reinterpret_cast<const u32x4*>(vt_base + st_voff(c));
             }
         } else {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-                if (st_row[c] < rows_left) {
-                    kv = *reinterpret_cast<const u32x4*>(kt_base + st_koff[c]);
-                    vv = *reinterpret_cast<const u32x4*>(vt_base + st_voff[c]);
+                if (st_row(c) < rows_left) {
+                    kv = *reinterpret_cast<const u32x4*>(kt_base + st_koff(c));
+                    vv = *reinterpret_cast<const u32x4*>(vt_base + st_voff(c));
                 }
                 kreg[c] = kv; vreg[c] = vv;
             }
@@ -163,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            if (st_row[c] < 64) {
-                *reinterpret_cast<u32x4*>(lK + buf * KBUF + st_lk[c]) = kreg[c];
-                *reinterpret_cast<u32x4*>(lV + buf * VBUF + st_lv[c]) = vreg[c];
+            if (st_row(c) < 64) {
+                *reinterpret_cast<u32x4*>(lK + buf * KBUF + st_lk(c)) = kreg[c];
+                *reinterpret_cast<u32x4*>(lV + buf * VBUF + st_lv(c)) = vreg[c];
             }
         }
     };
@@ -199,15 +207,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         f32x4 negm[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) { const float v = FIRST ? 0.f : -m_run[t]; negm[t] = f32x4{v, v, v, v}; }
+        // K fragments run RING reads ahead of the MFMAs that consume them (the compiler's own order is read -> wait -> MFMA: every group of
+        // QT MFMAs then waits out a full LDS latency)
+        {
+            constexpr int NF = 4 * KSTEPS, RING = NF < 4 ? NF : 4;
+            auto kaddr = [&](int f) {
+                const int kt = f / KSTEPS, ks = f - kt * KSTEPS;
+                return tk + (kt * 16 + i16) * KS + (KSWZ ? ((ks * 4 + g) ^ (i16 & 7)) * 16 : (ks * 32 + 8 * g) * 2);
+            };
+            frag kf[RING];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+            for (int f = 0; f < RING; ++f) kf[f] = *reinterpret_cast<const frag*>(kaddr(f));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                const frag kf = *reinterpret_cast<const frag*>(
-                    tk + (kt * 16 + i16) * KS + (KSWZ ? ((ks * 4 + g) ^ (i16 & 7)) * 16 : (ks * 32 + 8 * g) * 2));
+            for (int f = 0; f < NF; ++f) {
+                const int kt = f / KSTEPS, ks = f - kt * KSTEPS;
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
-                    s[kt][t] = El<T>::mfma(kf, qf[t][ks], ks == 0 ? negm[t] : s[kt][t]);
+                    s[kt][t] = El<T>::mfma(kf[f % RING], qf[t][ks], ks == 0 ? negm[t] : s[kt][t]);
+                if (f + RING < NF) kf[f % RING] = *reinterpret_cast<const frag*>(kaddr(f + RING));
+                __builtin_amdgcn_sched_barrier(0);          // pin the program order: the scheduler would sink the read next to its use
             }
         }
         if (BIAS) {     // T5 relative-position bias: four consecutive keys of one query per load
