@@ -18,7 +18,17 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sum[k] = 0.f; sq[k] = 0.f; }
     const f16* base = x + ((size_t)b * HW + r0) * C + cv * 8;
-    for (int r = rr; r < rows; r += R) {
+    int r = rr;
+    for (; r + 3 * R < rows; r += 4 * R) {            // four independent 16-byte loads in flight per lane
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(r + u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float f = (float)v[u][k]; sum[k] += f; sq[k] += f * f; }
+    }
+    for (; r < rows; r += R) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)r * C);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; sum[k] += f; sq[k] += f * f; }
@@ -78,65 +88,90 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     const int rows_per_blk = (HW + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_blk;
     const int r1 = min(HW, r0 + rows_per_blk);
-    const long nvec = (long)(r1 - r0) * CV;
-    for (long i = threadIdx.x; i < nvec; i += blockDim.x) {
-        const int r = r0 + (int)(i / CV), cv = (int)(i % CV);
-        const int c = cv * 8;
-        const f16* src = (c < c0) ? x0 + ((size_t)b * HW + r) * c0 + c : x1 + ((size_t)b * HW + r) * c1 + (c - c0);
-        const f16x8 v = *reinterpret_cast<const f16x8*>(src);
-        f16x8 o;
+    const int nvec = (r1 - r0) * CV;
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * (int)blockDim.x) {      // four independent 16-byte loads in flight per lane
+        f16x8 v[4]; int cc[4]; size_t oo[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float y = (float)v[k] * ss[2 * (c + k)] + ss[2 * (c + k) + 1];
-            if (SILU) y = y / (1.0f + __expf(-y));
-            o[k] = (f16)y;
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            const int ic = i < nvec ? i : i0;                             // tail lanes re-read a valid vector (not stored)
+            const int rl = ic / CV, c = (ic - rl * CV) * 8, r = r0 + rl;
+            const f16* src = (c < c0) ? x0 + ((size_t)b * HW + r) * c0 + c : x1 + ((size_t)b * HW + r) * c1 + (c - c0);
+            v[u] = *reinterpret_cast<const f16x8*>(src);
+            cc[u] = c; oo[u] = ((size_t)b * HW + r) * Ctot + c;
         }
-        *reinterpret_cast<f16x8*>(out + ((size_t)b * HW + r) * Ctot + c) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * (int)blockDim.x >= nvec) break;
+            f16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float y = (float)v[u][k] * ss[2 * (cc[u] + k)] + ss[2 * (cc[u] + k) + 1];
+                if (SILU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+                o[k] = (f16)y;
+            }
+            *reinterpret_cast<f16x8*>(out + oo[u]) = o;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------- LayerNorm
-// one wave per token row, row kept in registers (C <= 8 * 64 * MAXV), two-pass variance
-template <int MAXV>
+// one wave per ROWS token rows, rows kept in registers (C <= 8 * 64 * MAXV), two-pass variance; the ROWS independent row loads keep
+// ROWS x 16 bytes in flight per lane (at C = 320 only 40 of the 64 lanes carry data: one row per wave left the kernel latency-bound)
+template <int MAXV, int ROWS>
 __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
                                                  f16* __restrict__ out, int M, int C, float eps) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + w;
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + w) * ROWS;
+    if (row0 >= M) return;
     const int CV = C >> 3;
-    float v[MAXV][8];
-    float sum = 0.f;
+    float v[ROWS][MAXV][8];
+    float sum[ROWS];
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int cv = lane + 64 * j;
-        if (cv < CV) {
-            const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + cv * 8);
+    for (int q = 0; q < ROWS; ++q) {
+        const int row = min(row0 + q, M - 1);                 // rows past the end re-read the last row (never stored)
+        sum[q] = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { v[j][k] = (float)t[k]; sum += v[j][k]; }
-        } else {
+        for (int j = 0; j < MAXV; ++j) {
+            const int cv = lane + 64 * j;
+            if (cv < CV) {
+                const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + cv * 8);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
+                for (int k = 0; k < 8; ++k) { v[q][j][k] = (float)t[k]; sum[q] += v[q][j][k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[q][j][k] = 0.f;
+            }
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+    f16x8 gv[MAXV], bv[MAXV];
 #pragma unroll
     for (int j = 0; j < MAXV; ++j)
         if (lane + 64 * j < CV) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += d * d; }
+            gv[j] = *reinterpret_cast<const f16x8*>(gamma + (lane + 64 * j) * 8);
+            bv[j] = *reinterpret_cast<const f16x8*>(beta + (lane + 64 * j) * 8);
         }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int cv = lane + 64 * j;
-        if (cv < CV) {
-            const f16x8 gv = *reinterpret_cast<const f16x8*>(gamma + cv * 8);
-            const f16x8 bv = *reinterpret_cast<const f16x8*>(beta + cv * 8);
-            f16x8 o;
+    for (int q = 0; q < ROWS; ++q) {
+        const float mean = wave_sum(sum[q]) / (float)C;
+        float sq = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = (f16)((v[j][k] - mean) * rstd * (float)gv[k] + (float)bv[k]);
-            *reinterpret_cast<f16x8*>(out + (size_t)row * C + cv * 8) = o;
+        for (int j = 0; j < MAXV; ++j)
+            if (lane + 64 * j < CV) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[q][j][k] - mean; sq += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        if (row0 + q >= M) break;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int cv = lane + 64 * j;
+            if (cv < CV) {
+                f16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (f16)((v[q][j][k] - mean) * rstd * (float)gv[j][k] + (float)bv[j][k]);
+                *reinterpret_cast<f16x8*>(out + (size_t)(row0 + q) * C + cv * 8) = o;
+            }
         }
     }
 }
@@ -178,12 +213,12 @@ int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out,
     if (!x || !gamma || !beta || !out) CS_FAIL(CS_E_ARG, "layer_norm: null pointer");
     if (C % 8 || C > 8 * 64 * 4) CS_FAIL(CS_E_SHAPE, "layer_norm: C=%d unsupported", C);
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
-    const dim3 grid((M + 3) / 4), block(256);
     const int nv = (C / 8 + 63) / 64;
-    if (nv <= 1) hipLaunchKernelGGL(ln_kernel<1>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
-    else if (nv == 2) hipLaunchKernelGGL(ln_kernel<2>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
-    else if (nv == 3) hipLaunchKernelGGL(ln_kernel<3>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
-    else hipLaunchKernelGGL(ln_kernel<4>, grid, block, 0, s, x, gamma, beta, out, M, C, eps);
+    const dim3 block(256);
+    if (nv <= 1) hipLaunchKernelGGL((ln_kernel<1, 4>), dim3((M + 15) / 16), block, 0, s, x, gamma, beta, out, M, C, eps);
+    else if (nv == 2) hipLaunchKernelGGL((ln_kernel<2, 2>), dim3((M + 7) / 8), block, 0, s, x, gamma, beta, out, M, C, eps);
+    else if (nv == 3) hipLaunchKernelGGL((ln_kernel<3, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps);
+    else hipLaunchKernelGGL((ln_kernel<4, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
