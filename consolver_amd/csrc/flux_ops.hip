@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict_
     }
 }
 
-// one wave per (token row, head): lanes 0..dh/8-1 hold 8 dims each of q (and k); RMS over the head, * weight,
+// one wave per (token row, group of 64 / (2 dh/8) heads): every lane holds 8 dims of q or k of one head (dh = 128: lanes 0-15 q(h), 16-31 k(h),
+// 32-47 q(h+1), 48-63 k(h+1)), two token rows per wave so that two independent 16-byte loads are in flight per lane; RMS over the head, * weight,
 // then rotate the (2i, 2i+1) pairs with cos/sin[pos][i]
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16* __restrict__ qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col,
@@ -67,50 +68,57 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16* __restrict__ qkv
                                                            const u16* __restrict__ wk_ctx, int ctx_rows, const float* __restrict__ cosv,
                                                            const float* __restrict__ sinv, float eps) {
     const int lane = threadIdx.x & 63;
+    const int nv = dh >> 3;                      // lanes per tensor per head (dh = 128 -> 16)
+    const int hpw = 64 / (2 * nv);               // heads per wave
+    const int hgroups = (heads + hpw - 1) / hpw;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (long)rows * heads) return;
-    const int row = (int)(item / heads), h = (int)(item - (long)row * heads);
-    const int pos = row % seq;
-    const bool is_ctx = pos < ctx_rows;
-    const int nv = dh >> 3;                      // lanes in use per tensor (dh = 128 -> 16)
-    const int which = lane / nv;                 // 0 = q, 1 = k ; lanes >= 2 nv idle
-    const int li = lane - which * nv;
-    const bool active = which < 2;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u16* ptr = qkv + (size_t)row * ld + (which == 0 ? q_col : k_col) + h * dh + li * 8;
-    if (active) {
-        const u32x4 t = *reinterpret_cast<const u32x4*>(ptr);
+    const int half_rows = (rows + 1) >> 1;
+    if (item >= (long)half_rows * hgroups) return;
+    const int row0 = (int)(item / hgroups), hg = (int)(item - (long)row0 * hgroups);
+    const int sub = lane / (2 * nv), which = (lane / nv) & 1, li = lane % nv;     // head in the group, 0 = q / 1 = k, 8-dim slot
+    const int h = hg * hpw + sub;
+    const bool head_ok = h < heads;
+    u32x4 t[2]; u16* ptr[2]; bool ok[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[2 * k] = El<T>::tof((u16)(t[k] & 0xffff)); v[2 * k + 1] = El<T>::tof((u16)(t[k] >> 16)); }
+    for (int u = 0; u < 2; ++u) {
+        const int row = row0 + u * half_rows;
+        ok[u] = head_ok && row < rows;
+        ptr[u] = qkv + (size_t)(ok[u] ? row : 0) * ld + (which == 0 ? q_col : k_col) + (head_ok ? h : 0) * dh + li * 8;
+        t[u] = *reinterpret_cast<const u32x4*>(ptr[u]);
     }
-    float sq = 0.f;
+    const u16* wsel_img = which == 0 ? wq : wk;
+    const u16* wsel_ctx = which == 0 ? (wq_ctx ? wq_ctx : wq) : (wk_ctx ? wk_ctx : wk);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sq += v[k] * v[k];
-    // reduce within the nv-lane group (nv is a power of two <= 32)
-    for (int o = nv >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    if (!active) return;
-    const float r = rsqrtf(sq / (float)dh + eps);
-    const u16* wsel = (which == 0) ? (is_ctx && wq_ctx ? wq_ctx : wq) : (is_ctx && wk_ctx ? wk_ctx : wk);
-    const u32x4 wv = *reinterpret_cast<const u32x4*>(wsel + li * 8);
-    float nrm[8];
+    for (int u = 0; u < 2; ++u) {
+        const int row = row0 + u * half_rows;
+        const int pos = (ok[u] ? row : 0) % seq;
+        float v[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // torch RMSNorm: (x * rsqrt(var + eps)) cast to the weight dtype, then * weight
-        nrm[2 * k] = El<T>::tof(El<T>::fromf(v[2 * k] * r)) * El<T>::tof((u16)(wv[k] & 0xffff));
-        nrm[2 * k + 1] = El<T>::tof(El<T>::fromf(v[2 * k + 1] * r)) * El<T>::tof((u16)(wv[k] >> 16));
+        for (int k = 0; k < 4; ++k) { v[2 * k] = El<T>::tof((u16)(t[u][k] & 0xffff)); v[2 * k + 1] = El<T>::tof((u16)(t[u][k] >> 16)); }
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sq += v[k] * v[k];
+        for (int o = nv >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);      // within the nv-lane group (nv is a power of two <= 32)
+        const float r = rsqrtf(sq / (float)dh + eps);
+        const u32x4 wv = *reinterpret_cast<const u32x4*>((pos < ctx_rows ? wsel_ctx : wsel_img) + li * 8);
+        float nrm[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // torch RMSNorm: (x * rsqrt(var + eps)) cast to the weight dtype, then * weight
+            nrm[2 * k] = El<T>::tof(El<T>::fromf(v[2 * k] * r)) * El<T>::tof((u16)(wv[k] & 0xffff));
+            nrm[2 * k + 1] = El<T>::tof(El<T>::fromf(v[2 * k + 1] * r)) * El<T>::tof((u16)(wv[k] >> 16));
+        }
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(cosv + (size_t)pos * (dh >> 1) + li * 4);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(sinv + (size_t)pos * (dh >> 1) + li * 4);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = El<T>::tof(El<T>::fromf(nrm[2 * k])), b = El<T>::tof(El<T>::fromf(nrm[2 * k + 1]));
+            o[2 * k] = a * c4[k] - b * s4[k];
+            o[2 * k + 1] = b * c4[k] + a * s4[k];
+        }
+        if (ok[u]) *reinterpret_cast<u32x4*>(ptr[u]) = u32x4{pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
     }
-    const float* cp = cosv + (size_t)pos * (dh >> 1) + li * 4;
-    const float* sp = sinv + (size_t)pos * (dh >> 1) + li * 4;
-    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp), s4 = *reinterpret_cast<const f32x4*>(sp);
-    float o[8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float a = El<T>::tof(El<T>::fromf(nrm[2 * k])), b = El<T>::tof(El<T>::fromf(nrm[2 * k + 1]));
-        o[2 * k] = a * c4[k] - b * s4[k];
-        o[2 * k + 1] = b * c4[k] + a * s4[k];
-    }
-    const u32x4 pk = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
-    *reinterpret_cast<u32x4*>(ptr) = pk;
 }
 
 __global__ void sinusoid_f32_kernel(const float* __restrict__ t, float mult, int R, int C, float* __restrict__ out) {
@@ -217,7 +225,8 @@ int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh
     if (!qkv || !wq || !wk || !cosv || !sinv) CS_FAIL(CS_E_ARG, "qk_norm_rope: null pointer");
     if (dh % 8 || (dh / 8) > 32 || ((dh / 8) & (dh / 8 - 1))) CS_FAIL(CS_E_SHAPE, "qk_norm_rope: head dim %d unsupported", dh);
     if (rows <= 0) return CS_OK;
-    const long items = (long)rows * heads;
+    const int nvl = dh >> 3, hpw = 64 / (2 * nvl);
+    const long items = (long)((rows + 1) / 2) * ((heads + hpw - 1) / hpw);
     const dim3 grid((unsigned)((items + 3) / 4)), block(256);
     if (dtype == CS_BF16) hipLaunchKernelGGL(qk_norm_rope_kernel<bf16_el>, grid, block, 0, s, (u16*)qkv, ld, rows, seq, heads, dh, q_col, k_col, (const u16*)wq, (const u16*)wk, (const u16*)wq_ctx, (const u16*)wk_ctx, ctx_rows, cosv, sinv, eps);
     else if (dtype == CS_F16) hipLaunchKernelGGL(qk_norm_rope_kernel<f16>, grid, block, 0, s, (u16*)qkv, ld, rows, seq, heads, dh, q_col, k_col, (const u16*)wq, (const u16*)wk, (const u16*)wq_ctx, (const u16*)wk_ctx, ctx_rows, cosv, sinv, eps);
