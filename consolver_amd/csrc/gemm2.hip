@@ -51,7 +51,7 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // the fp32 partial tiles go to `partial` ([tile - id0][split][256][256]) and g2_tail_reduce_kernel applies the epilogue.
 struct G2Pair { G2Params p[2]; int nblk0, nblk; int id0, splits; float* partial; };
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
     constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -117,11 +117,21 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         for (int j = 0; j < 4; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
     };
 
+    // Accumulators start from the bias (this lane's output channels n_blk + wn*128 + i*16 + 4*(lane>>4) .. +3), so the epilogue has no bias
+    // loads: there each sat in its own `if (p.bias)` block followed by s_waitcnt vmcnt(0), which on gfx9 also drains the stores in flight.
+    // (split-K partial tiles start from zero: the reduce kernel adds the bias once.)
     f32x4 acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        const int n = n_blk + wn * 128 + i * 16 + (lane >> 4) * 4;
+        if (p.bias && pp.splits == 1 && n < p.N) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(p.bias + n);
+            b = f32x4{El<T>::tof((u16)(t[0] & 0xffff)), El<T>::tof((u16)(t[0] >> 16)), El<T>::tof((u16)(t[1] & 0xffff)), El<T>::tof((u16)(t[1] >> 16))};
+        }
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = b;
+    }
 
     const int swz = (lane >> 1) & 7;
     const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
@@ -197,62 +207,79 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     char* patch = smem + w * (64 * ROWB);
     const int g4 = (lane >> 4) * 4, i16 = lane & 15;
     const int m_base = m_blk + wm * 64, n_base = n_blk + wn * 128;
+    // phase 2 geometry: lane -> (row (lane >> 3) + 8 k, 16-byte chunk lane & 7): the chunk, hence the gate vector, is the same for every k
+    const int prow = lane >> 3;                 // (pch = lane & 7 from the staging setup above)
+    bool one_sample = true;
+    int sample0 = 0;
+    if (p.gate) {
+        sample0 = m_base / p.rows_per_sample;
+        one_sample = (min(m_base + 63, p.M - 1) / p.rows_per_sample) == sample0;
+    }
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
+        // ---- phase 1: registers -> LDS patch [64 rows][64 cols] (bias is already in the accumulators) ----
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = grp * 4 + ii;
-            const int n = n_base + i * 16 + g4;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.N) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(p.bias + n);
-                bv[0] = El<T>::tof((u16)(t[0] & 0xffff)); bv[1] = El<T>::tof((u16)(t[0] >> 16));
-                bv[2] = El<T>::tof((u16)(t[1] & 0xffff)); bv[3] = El<T>::tof((u16)(t[1] >> 16));
-            }
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 u16 o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bv[r];
-                    if (p.act == 1) v = gelu_tanh(v);
-                    o[r] = El<T>::fromf(v);
-                }
+                for (int r = 0; r < 4; ++r) o[r] = El<T>::fromf(ACT == 1 ? gelu_tanh(acc[i][j][r]) : acc[i][j][r]);
                 u32x2 pk = {(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
                 *reinterpret_cast<u32x2*>(patch + (j * 16 + i16) * ROWB + (ii * 16 + g4) * 2) = pk;
             }
         }
-        const int n0 = n_base + grp * 64;
+        // ---- phase 2: LDS patch -> global.  Every residual / gate load of the pass is issued BEFORE its first store: a load waited on
+        // after a store (in-order vmcnt) also waits for that store's acknowledgement, one memory round trip per 16-byte store.
+        const int n = n_base + grp * 64 + pch * 8;
+        const bool n_ok = n < p.N;
+        size_t off[CH]; bool ok[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const int idx = lane + 64 * k;
-            const int row = idx / CH, ch = idx - row * CH;
-            const int m = m_base + row, n = n0 + ch * 8;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * ROWB + ch * 16);
-            if (m < p.M && n < p.N) {
-                const size_t off = (size_t)rowmap(m, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + n;
-                if (p.res || p.gate) {
-                    float f[8];
+            const int m = m_base + prow + 8 * k;
+            ok[k] = n_ok && m < p.M;
+            off[k] = (size_t)rowmap(ok[k] ? m : 0, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + (n_ok ? n : 0);
+        }
+        if (p.res || p.gate) {
+            u32x4 rv[CH];
+            if (p.res) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { f[2 * r] = El<T>::tof((u16)(v[r] & 0xffff)); f[2 * r + 1] = El<T>::tof((u16)(v[r] >> 16)); }
-                    if (p.gate) {
-                        const float* gp = p.gate + (size_t)(m / p.rows_per_sample) * p.gate_stride + n;
-                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                for (int k = 0; k < CH; ++k) rv[k] = *reinterpret_cast<const u32x4*>(p.res + off[k]);
+            }
+            f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
+            if (p.gate && one_sample && n_ok) {
+                const float* gp = p.gate + (size_t)sample0 * p.gate_stride + n;
+                g0 = *reinterpret_cast<const f32x4*>(gp); g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+            }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { f[r] *= g0[r]; f[4 + r] *= g1[r]; }
-                    }
-                    if (p.res) {
-                        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + off);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rv[r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rv[r] >> 16)); }
-                    }
-                    u32x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (unsigned)El<T>::fromf(f[2 * r]) | ((unsigned)El<T>::fromf(f[2 * r + 1]) << 16);
-                    *reinterpret_cast<u32x4*>(p.out + off) = o;
-                } else {
-                    *reinterpret_cast<u32x4*>(p.out + off) = v;
+            for (int k = 0; k < CH; ++k) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(patch + (prow + 8 * k) * ROWB + pch * 16);
+                if (p.gate && !one_sample && ok[k]) {       // tile straddles two samples (batch > 1): per-row gate
+                    const float* gp = p.gate + (size_t)((m_base + prow + 8 * k) / p.rows_per_sample) * p.gate_stride + n;
+                    g0 = *reinterpret_cast<const f32x4*>(gp); g1 = *reinterpret_cast<const f32x4*>(gp + 4);
                 }
+                float f[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f[2 * r] = El<T>::tof((u16)(v[r] & 0xffff)); f[2 * r + 1] = El<T>::tof((u16)(v[r] >> 16)); }
+                if (p.gate) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f[r] *= g0[r]; f[4 + r] *= g1[r]; }
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rv[k][r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rv[k][r] >> 16)); }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (unsigned)El<T>::fromf(f[2 * r]) | ((unsigned)El<T>::fromf(f[2 * r + 1]) << 16);
+                if (ok[k]) *reinterpret_cast<u32x4*>(p.out + off[k]) = o;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(patch + (prow + 8 * k) * ROWB + pch * 16);
+                if (ok[k]) *reinterpret_cast<u32x4*>(p.out + off[k]) = v;
             }
         }
     }
@@ -356,19 +383,26 @@ static int g2_fill(const Gemm2Args& a, G2Params& p) {
 
 constexpr int G2_CUS = 256;
 
-static int g2_launch(G2Pair pp, int dtype, hipStream_t s, dim3 grid) {
+template <typename T, int ACT>
+static int g2_launch_t(const G2Pair& pp, hipStream_t s, dim3 grid) {
     constexpr size_t lds = 2 * (256 * BK * 2 + 256 * BK * 2);
     static bool configured = false;
     if (!configured) {
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<bf16_el>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    if (dtype == CS_F16) hipLaunchKernelGGL(gemm2_kernel<f16>, grid, dim3(512), lds, s, pp);
-    else if (dtype == CS_BF16) hipLaunchKernelGGL(gemm2_kernel<bf16_el>, grid, dim3(512), lds, s, pp);
-    else CS_FAIL(CS_E_DTYPE, "gemm2: dtype must be f16 or bf16");
+    hipLaunchKernelGGL((gemm2_kernel<T, ACT>), grid, dim3(512), lds, s, pp);
     CS_CHECK_LAUNCH();
     return CS_OK;
+}
+
+// both problems of a launch share dtype and activation (launch_gemm2_pair falls back to two launches otherwise)
+static int g2_launch(const G2Pair& pp, int dtype, hipStream_t s, dim3 grid) {
+    const int act = pp.p[0].act;
+    if (act != 0 && act != 1) CS_FAIL(CS_E_ARG, "gemm2: act must be 0 (none) or 1 (GELU tanh)");
+    if (dtype == CS_F16) return act ? g2_launch_t<f16, 1>(pp, s, grid) : g2_launch_t<f16, 0>(pp, s, grid);
+    if (dtype == CS_BF16) return act ? g2_launch_t<bf16_el, 1>(pp, s, grid) : g2_launch_t<bf16_el, 0>(pp, s, grid);
+    CS_FAIL(CS_E_DTYPE, "gemm2: dtype must be f16 or bf16");
 }
 
 // Tail split: one tile per CU per round; when the last round is partly empty and K is long, its tiles are computed as `splits` k ranges side by
@@ -424,6 +458,7 @@ int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) {
     if (a.dtype != b.dtype) CS_FAIL(CS_E_DTYPE, "gemm2 pair: both problems must have the same dtype");
     if (a.M <= 0 || a.N <= 0) return launch_gemm2(b, s);
     if (b.M <= 0 || b.N <= 0) return launch_gemm2(a, s);
+    if (a.act != b.act) { const int r = launch_gemm2(a, s); return r != CS_OK ? r : launch_gemm2(b, s); }
     G2Pair pp{};
     int rc = g2_fill(a, pp.p[0]);
     if (rc == CS_OK) rc = g2_fill(b, pp.p[1]);
