@@ -351,13 +351,28 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     // the maxima: every tile is exponentiated against the FIRST tile's column maximum.  That is exact as long as no later score
     // exceeds it by 2^16 (the fp16 range of P); if one does, P holds an inf, the ones-column denominator comes out non-finite,
     // and the whole workgroup redoes its rows with the maxima-tracking loop (block-uniform decision, never seen on real inputs).
-    if constexpr (ONES) {
+    // Head dim 128 (FLUX) does the same (VALU work per tile exceeds the MFMA time there too); without a spare V column the overflow shows up
+    // as a non-finite output accumulator (inf P times V) or denominator, so all of them are checked once at the end.
+    constexpr bool FASTABLE = ONES || (DH == 128 && !CAUSAL && !BIAS);
+    if constexpr (FASTABLE) {
         run_tiles(std::true_type{});
         bool bad = false;
+        if constexpr (ONES) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const float l = __shfl(o_acc[DH / 16][t][(DH % 16) % 4], ((DH % 16) / 4) * 16 + i16, 64);
-            bad |= !(l < INFINITY);                      // inf or NaN
+            for (int t = 0; t < QT; ++t) {
+                const float l = __shfl(o_acc[DH / 16][t][(DH % 16) % 4], ((DH % 16) / 4) * 16 + i16, 64);
+                bad |= !(l < INFINITY);                      // inf or NaN
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float chk = l_run[t];
+#pragma unroll
+                for (int a = 0; a < DVT; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) chk += fabsf(o_acc[a][t][r]);
+                bad |= !(chk < INFINITY);                    // any inf or NaN among the accumulators or the denominator
+            }
         }
         if (__syncthreads_or(bad ? 1 : 0)) {
 #pragma unroll

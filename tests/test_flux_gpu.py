@@ -284,3 +284,21 @@ def test_flux_kontext_pipeline_call_surface():
     assert pt.shape == (1, 3, 128, 128) and torch.isfinite(pt).all() and float(pt.std()) > 0.01
     with pytest.raises(RuntimeError):
         pipe(image=ref, prompt="make it red")
+
+
+@pytest.mark.parametrize("dt,code,mult,tol", [(torch.float16, 1, 3.0, 3e-3), (torch.bfloat16, 2, 3.0, 2e-2)])
+def test_attention_dh128_outlier_key_takes_the_safe_path(dt, code, mult, tol):
+    """head dim 128 exponentiates later key tiles against the first tile's column maximum; a key whose score exceeds it by more than the
+    range of P (2^16 for f16) must trigger the maxima-tracking redo, not produce inf/NaN (bf16 P does not overflow: same result, no redo)"""
+    g = torch.Generator().manual_seed(11)
+    B, H, S = 1, 2, 640
+    q, k, v = (torch.randn(B, S, H * 128, generator=g).to(dt).to(DEV) for _ in range(3))
+    k = k.clone()
+    k[:, 500] = mult * q[:, 7]                      # score ~ 3 |q|^2 / sqrt(128) * log2e ~ 49 >> 16 above the first tile for query 7
+    o = torch.empty_like(q)
+    L.check(L.lib().cs_op_attention_ex(q.data_ptr(), H * 128, k.data_ptr(), H * 128, v.data_ptr(), H * 128, o.data_ptr(), H * 128,
+                                       B, H, S, S, 128, 128 ** -0.5, code, L.stream_ptr(q.device)))
+    qf, kf, vf = (t.float().view(B, S, H, 128).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 128 ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, S, H * 128)
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.float(), ref) < tol
