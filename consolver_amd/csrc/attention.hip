@@ -11,8 +11,8 @@
 //     exponentiated tile is already laid out as the B operand of the second product
 //     O^T = V^T P^T  -- P never touches LDS;
 //   * V^T fragments come from the row-major V tile with the gfx950 transposing LDS read
-//     (ds_read_b64_tr_b16); row strides are chosen so that both the ds_read_b128 K reads
-//     (stride = 16 B mod 32 B) and the transposed V reads (odd multiple of 32 B) are conflict free;
+//     (ds_read_b64_tr_b16); row strides (odd multiples of 32 B, or XOR-swizzled 128-B rows) keep both the ds_read_b128 K reads
+//     and the transposed V reads bank-conflict free under gfx950's lane grouping;
 //   * the MFMA k-index <-> key permutation induced by reusing the accumulator layout as an operand
 //     (keys 4g..4g+3 and 16+4g..16+4g+3 per lane group g) is applied identically to the V reads;
 //   * head dims are zero-padded in registers/LDS only (40 -> 64 for Q K^T, 40 -> 48 for P V);
@@ -67,7 +67,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr int DVT = (DH + 15) / 16;
     constexpr int DVP = DVT * 16;
     constexpr bool KSWZ = (DK == 64);                                 // 128-B rows: XOR-swizzled chunks, conflict-free b128 reads
-    constexpr int KS = KSWZ ? 128 : DK * 2 + 16;                      // bytes per K row in LDS
+    // bytes per K row in LDS.  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32), so
+    // with the lane -> (row i16, 16-byte chunk g) map of the K fragments a row stride of 16 B mod 32 B puts two lanes of every group on one bank
+    // (measured: SQ_LDS_BANK_CONFLICT = 25 % of the LDS cycles at dh 128); an odd multiple of 32 B is conflict free (simulated per group and
+    // confirmed with the counter), the same rule as for the transposed V reads.
+    constexpr int KS = KSWZ ? 128 : ((DK * 2) % 64 == 32 ? DK * 2 : DK * 2 + 32);
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;  // odd multiple of 32 B
     // spare padded V column (dh = 40 -> 48): a column of ones makes the P V MFMA also produce the softmax
     // denominator (row DH of O^T), replacing 16*QT v_add_f32 per tile per lane and the separate l rescale
@@ -460,7 +464,7 @@ constexpr int ATTN_SLOTS = 512;      // 256 CUs x 2 resident workgroups (launch_
 template <typename T, int DH, int QT, bool CAUSAL = false, bool BIAS = false>
 int launch_attn(AttnParams p, int B, hipStream_t s, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     constexpr int DK = (DH + 31) / 32 * 32, DVP = (DH + 15) / 16 * 16;
-    constexpr int KS = (DK == 64) ? 128 : DK * 2 + 16;
+    constexpr int KS = (DK == 64) ? 128 : ((DK * 2) % 64 == 32 ? DK * 2 : DK * 2 + 32);
     constexpr int VS = ((DVP * 2) % 64 == 32) ? DVP * 2 : DVP * 2 + 32;
     constexpr size_t lds = 2 * 64 * (size_t)(KS + VS);
     auto kfn = attn_kernel<T, DH, QT, CAUSAL, BIAS>;
