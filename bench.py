@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="capture the whole generation in one hipGraph")
     ap.add_argument("--decode", type=int, default=1, help="1: also time K generations WITH the VAE decode (pixel_images_per_s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ceilings", type=int, default=1, help="1: also measure the vendor 8192^3 fp16 GEMM and a 1 GiB device copy on this box")
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
     args = ap.parse_args()
 
@@ -228,6 +229,28 @@ def main():
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
                        "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None} for k, v in prof.items()}
 
+    # ---- same-run measured ceilings (makes the fraction of the spec-sheet peak auditable): what the vendor GEMM library and a
+    # plain device copy reach on THIS box, on random data.  Reference points only - nothing on the product path uses hipBLASLt or torch math.
+    ceilings = None
+    if rank == 0 and world == 1 and args.ceilings:
+        def _ev(fn, it):
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(it): fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / it
+        ga = (torch.randn(8192, 8192, device=dev) * 0.05).half(); gb = (torch.randn(8192, 8192, device=dev) * 0.05).half()
+        gc = torch.empty(8192, 8192, device=dev, dtype=torch.float16)
+        gms = _ev(lambda: torch.matmul(ga, gb, out=gc), 20)
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).random_(0, 255); dst = torch.empty_like(src)
+        cms = _ev(lambda: dst.copy_(src), 20)
+        ceilings = {"vendor_gemm_f16_8192_tflops": 2.0 * 8192 ** 3 / (gms * 1e-3) / 1e12,
+                    "dtod_copy_1gib_tbps": 2.0 * (1 << 30) / (cms * 1e-3) / 1e12,
+                    "note": "torch.matmul (hipBLASLt/rocBLAS) 8192^3 fp16 and a 1 GiB device copy (read + write bytes) on this box, random data"}
+        del ga, gb, gc, src, dst
+
     if rank == 0:
         images = B * world * args.steps
         rec = {
@@ -246,6 +269,9 @@ def main():
                                  "frac_of_mfma_peak": vae.flops(B) / (decode_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS}
         if kernels:
             rec["roofline_kernels"] = kernels
+        if ceilings:
+            rec["ceilings"] = ceilings
+            rec["roofline"]["frac_of_vendor_gemm"] = achieved / ceilings["vendor_gemm_f16_8192_tflops"]
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance, vae_sd=vae_sd)
         elif world == 1:
