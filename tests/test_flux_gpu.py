@@ -116,12 +116,12 @@ def test_gemm2_split_k_tail_matches_unsplit():
     assert rel_l2(o3.float(), keep[0][5].float()) < 2e-3
 
 
-@pytest.mark.parametrize("dt,code,tol", [(torch.bfloat16, 2, 2e-2), (torch.float16, 1, 3e-3)])
-def test_attention_split_kv_tail_matches_unsplit(dt, code, tol):
+@pytest.mark.parametrize("dt,code,tol,B", [(torch.bfloat16, 2, 2e-2, 1), (torch.float16, 1, 3e-3, 1), (torch.float16, 1, 3e-3, 2)])
+def test_attention_split_kv_tail_matches_unsplit(dt, code, tol, B):
     """head dim 128 with a workgroup count that leaves a small last round: the split-KV tail (partial softmaxes over key ranges + merge)
     must agree with the unsplit kernel and with an fp32 softmax; ragged Nq and Nk on purpose"""
     g = torch.Generator().manual_seed(3)
-    B, H, S = 1, 9, 7717            # 61 query blocks x 9 heads = 549 workgroups = 512 + 37 -> the last 37 are split over key ranges
+    H, S = 9, 7717                  # 61 query blocks x 9 heads (x B) = 549 (1098) workgroups = 512 (1024) + 37 (74): the last ones are split over key ranges
     q, k, v = ((torch.randn(B, S, H * 128, generator=g) * (1.5 if i == 0 else 1.0)).to(dt).to(DEV) for i in range(3))
     o0, o1 = torch.empty_like(q), torch.empty_like(q)
     st = L.stream_ptr(q.device)
@@ -136,9 +136,9 @@ def test_attention_split_kv_tail_matches_unsplit(dt, code, tol):
     assert rel_l2(o1.float(), o0.float()) < 2e-3
     # the rows of the split workgroups against fp32 math: last head, last query blocks
     hsel = H - 1
-    qf, kf, vf = (t[0, :, hsel * 128:(hsel + 1) * 128].float() for t in (q, k, v))
+    qf, kf, vf = (t[B - 1, :, hsel * 128:(hsel + 1) * 128].float() for t in (q, k, v))
     ref = torch.softmax(qf[-1500:] @ kf.T * 128 ** -0.5, -1) @ vf
-    assert rel_l2(o1[0, -1500:, hsel * 128:(hsel + 1) * 128].float(), ref) < tol
+    assert rel_l2(o1[B - 1, -1500:, hsel * 128:(hsel + 1) * 128].float(), ref) < tol
     assert L.lib().cs_op_attention_workspace(B, 8, 4096, 4096, 128) == 0      # 32 x 8 = 256 workgroups: no tail to split
 
 
