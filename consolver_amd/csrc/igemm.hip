@@ -226,10 +226,18 @@ struct PatchRows {          // tile-local pixel -> output row
     }
 };
 
-template <bool UP, int BN>
+// KH = 2 (BN = 320): the inner step is HALF a tap (k = 32): wave tile 64 x 160 like the big GEMM (22 % fewer LDS fragment bytes per MFMA than
+// 64 x 80, half the per-tile prologue / epilogue and half the halo traffic per FLOP); the weight tile of a step is [320 rows][32 k] = 64-byte
+// rows (chunk index XOR (row >> 1) & 3: conflict-free ds_read_b128 under gfx950's lane grouping), the same 20 KB and 20 DMA instructions as
+// the [160][64] tile of KH = 1, so buffers, rotation and the stagger are unchanged - a chunk is 18 steps instead of 9.
+template <bool UP, int BN, int KH = 1>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
-    constexpr int NT = BN / 32, MT = 4, NBQ = BN / 8;      // NBQ: weight-tile DMA instructions (8 rows each)
-    constexpr int A_BYTES = HALO_ROWS_MAX * 128, B_BYTES = BN * 128;
+    static_assert(KH == 1 || KH == 2, "k halves per tap");
+    constexpr int NT = BN / 32, MT = 4;
+    constexpr int WROW = 128 / KH;                          // bytes per weight row in LDS
+    constexpr int NBQ = BN * WROW / 1024;                   // weight-tile DMA instructions (1 KiB each)
+    constexpr int STEPS = 9 * KH;                           // inner steps per 64-channel chunk
+    constexpr int A_BYTES = HALO_ROWS_MAX * 128, B_BYTES = BN * WROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lA = smem;                    // [2][A_BYTES]
     char* const lB = smem + 2 * A_BYTES;      // [3][B_BYTES]
@@ -286,8 +294,13 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = w + 8 * j;
-        const int r = 8 * q + (lane >> 3);
-        b_src[j] = p.w + (size_t)(n_blk + (q < NBQ ? r : 0)) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+        if (KH == 1) {
+            const int r = 8 * q + (lane >> 3);
+            b_src[j] = p.w + (size_t)(n_blk + (q < NBQ ? r : 0)) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+        } else {                                            // 16 rows x 64 B per DMA instruction
+            const int r = 16 * q + (lane >> 2);
+            b_src[j] = p.w + (size_t)(n_blk + (q < NBQ ? r : 0)) * (9 * p.Cin) + ((lane & 3) ^ ((r >> 1) & 3)) * 8;
+        }
     }
 
     auto stage_a = [&](int c, int sl, int buf) {         // one eighth of chunk c's halo
@@ -298,8 +311,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
             glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), lA + buf * A_BYTES + (sl + 8 * w) * 1024);
         }
     };
-    auto stage_w = [&](int c, int t, int buf) {
-        const size_t koff = (size_t)t * p.Cin + c * BK;
+    auto stage_w = [&](int c, int st, int buf) {           // st: step inside the chunk (tap, or tap * 2 + k half)
+        const size_t koff = (size_t)(st / KH) * p.Cin + c * BK + (st % KH) * 32;
         char* lb = lB + buf * B_BYTES;
         glds16(b_src[0] + koff, lb + w * 1024);
         glds16(b_src[1] + koff, lb + (w + 8) * 1024);
@@ -307,16 +320,18 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     };
 
     // ---- fragment addressing: output pixel -> (image offset, row in patch, column in patch) ---------------
-    int fi[MT], fy[MT], fx[MT];
+    int fi[MT], fy[MT], fx[MT];          // (without the fused upsample only fi is kept: the halo row of tap (0, 0))
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int o = wm * 64 + j * 16 + (lane & 15);
         const int img = o >> p.trw_shift, rem = o & ((1 << p.trw_shift) - 1);
         fy[j] = rem >> p.tw_shift; fx[j] = rem & ((1 << p.tw_shift) - 1); fi[j] = img * p.HALO_IMG;
+        if (!UP) fi[j] += fy[j] * p.HALO_W + fx[j];
     }
     const int g = lane >> 4;
     const int swz = (lane >> 1) & 7;
-    const int wfrag0 = (lane & 15) * 128 + ((g) ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + g) ^ swz) * 16;
+    const int wfrag0 = KH == 1 ? (lane & 15) * 128 + ((g) ^ swz) * 16 : (lane & 15) * 64 + (g ^ (swz & 3)) * 16;
+    const int wfrag1 = (lane & 15) * 128 + ((4 + g) ^ swz) * 16;      // (KH = 1 only)
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -339,27 +354,36 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     // buffer is re-staged no earlier than iteration it+2: weights rotate through three buffers, and the next chunk's
     // halo (into the buffer last read at tap 8 of the previous chunk) starts at tap 1, not tap 0.
     const bool groupB = w >= 4;
-    f16x8 fa[2][MT], fw[2][NT];
-    auto read_frags = [&](const char* ha, const char* tb, int t) {
+    f16x8 fa[2 / KH][MT], fw[2 / KH][NT];
+    auto read_frags = [&](const char* ha, const char* tb, int st) {
+        const int t = st / KH, kh = st % KH;       // tap, k half (KH = 2)
         const int dy = t / 3, dx = t - 3 * dy;
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-            const int hyv = UP ? ((fy[j] + dy - 1) >> 1) + 1 : fy[j] + dy;
-            const int hxv = UP ? ((fx[j] + dx - 1) >> 1) + 1 : fx[j] + dx;
-            const int hr = fi[j] + hyv * p.HALO_W + hxv;
+            int hr;
+            if (UP) {
+                const int hyv = ((fy[j] + dy - 1) >> 1) + 1, hxv = ((fx[j] + dx - 1) >> 1) + 1;
+                hr = fi[j] + hyv * p.HALO_W + hxv;
+            } else {
+                hr = fi[j] + dy * p.HALO_W + dx;
+            }
             const int sw = (g ^ (hr & 7)) * 16;
-            fa[0][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + sw);
-            fa[1][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + (sw ^ 64));
+            if (KH == 1) {
+                fa[0][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + sw);
+                fa[2 / KH - 1][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + (sw ^ 64));
+            } else {
+                fa[0][j] = *reinterpret_cast<const f16x8*>(ha + hr * 128 + (sw ^ (kh * 64)));
+            }
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            fw[0][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag0);
-            fw[1][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag1);
+            fw[0][i] = *reinterpret_cast<const f16x8*>(tb + i * (16 * WROW) + wfrag0);
+            if (KH == 1) fw[2 / KH - 1][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag1);
         }
     };
     auto multiply = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2 / KH; ++ks)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -372,15 +396,15 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
         const char* ha = lA + ab * A_BYTES;
         hi = hi0; hy = hy0; hx = hx0;
 #pragma unroll 1
-        for (int t = 0; t < 9; ++t, ++it) {
+        for (int t = 0; t < STEPS; ++t, ++it) {       // t: step inside the chunk (a tap, or half a tap when KH = 2)
             const int wnext = wb == (CS_HALO_NWB - 1) ? 0 : wb + 1;
-            if (t < 8) stage_w(c, t + 1, wnext);
+            if (t < STEPS - 1) stage_w(c, t + 1, wnext);
             else if (c + 1 < c_end) stage_w(c + 1, 0, wnext);
-            if (t > 0 && c + 1 < c_end) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
-            const char* tb = lB + wb * B_BYTES + (wn * (BN / 2)) * 128;
-            if (groupB && it > 0) multiply();      // group B: tap it-1, fragments read before the previous barrier
+            if (t > 0 && t <= 8 && c + 1 < c_end) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
+            const char* tb = lB + wb * B_BYTES + (wn * (BN / 2)) * WROW;
+            if (groupB && it > 0) multiply();      // group B: step it-1, fragments read before the previous barrier
             read_frags(ha, tb, t);
-            if (!groupB) multiply();               // group A: this tap
+            if (!groupB) multiply();               // group A: this step
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             wb = wnext;
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
         __syncthreads();                           // group B's last reads are consumed; the stage buffers become the epilogue patches
-        igemm_epilogue<false, NT, MT, NT>(p.e, acc, rows, n_blk + wn * (BN / 2), lane, smem + w * 11264);
+        igemm_epilogue<false, NT, MT, NT, PatchRows, KH>(p.e, acc, rows, n_blk + wn * (BN / 2), lane, smem + w * 11264);
     } else {
         // split-K: raw fp32 partial sums, 16-byte stores (4 consecutive channels per lane)
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
@@ -741,7 +765,10 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     const bool conv3 = a.taps == 9;
     const int use_halo = g_tune_halo;   // 0 = never, 1 = when it pays, 2 = whenever the shape allows (tests)
     const int Wo = a.upsample ? 2 * a.Wi : a.Wi, Ho = a.upsample ? 2 * a.Hi : a.Hi;
-    const int hbn = a.N % 160 == 0 ? 160 : (a.N % 128 == 0 ? 128 : 0);
+    int hbn = a.N % 160 == 0 ? 160 : (a.N % 128 == 0 ? 128 : 0);
+    // 256 x 320 tiles (k32 inner step) when they still fill the chip: SD1.5's 320- and 640-wide layers at 64 x 64 / 32 x 32 (g_tune_halo 3 forces,
+    // 4 forbids: tests / A-B)
+    bool wide = false;
     // patch geometry: TW = min(Wo, 16) in {8, 16}; TH = min(Ho, 256 / TW); both powers of two dividing the image
     const int TW = Wo >= 16 ? 16 : Wo, THmax = TW ? 256 / TW : 0, TH = Ho < THmax ? Ho : THmax;
     const bool pow2 = TW == 8 || TW == 16;
@@ -750,7 +777,9 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (use_halo && conv3 && a.stride == 1 && a.c1 == 0 && hbn && !a.geglu && geom_ok) {
         const int TRW = TH * TW, IPT = 256 / TRW;                       // output pixels per image in a tile; images per tile
         const int PX = Wo / TW, PY = Ho / TH, PP = PX * PY;
-        const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP, tiles_n = a.N / hbn;
+        const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP;
+        if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
+        const int tiles_n = a.N / hbn;
         const int NC = cin / BK;
         int splits = 1;
         if (tiles_m * tiles_n < 160 && a.splitk_ws) {          // small images: split the channel chunks to fill the chip
@@ -761,7 +790,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         const int tin_w = a.upsample ? TW / 2 : TW, tin_h = a.upsample ? TH / 2 : TH;
         HaloParams h;
         h.HALO_W = tin_w + 2; h.HALO_IMG = (tin_h + 2) * (tin_w + 2); h.NHALO = IPT * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
-        if ((pays || use_halo == 2) && h.NHALO <= HALO_ROWS_MAX && h.NQ <= 64 && (PP == 1 || IPT == 1)) {
+        if ((pays || use_halo == 2 || use_halo == 3) && h.NHALO <= HALO_ROWS_MAX && h.NQ <= 64 && (PP == 1 || IPT == 1)) {
             h.e = p; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n;
             h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Ho = Ho; h.Wo = Wo;
             h.tw_shift = TW == 16 ? 4 : 3; h.trw_shift = 0; while ((1 << h.trw_shift) < TRW) ++h.trw_shift;
@@ -774,11 +803,16 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * 128);
+            const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * (wide ? 64 : 128));
             const dim3 grid(h.e.nblk, splits);
-            if (hbn == 160) {
+            if (wide) {
+                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 320, 2>), grid, dim3(512), l, s, h);
+                else hipLaunchKernelGGL((conv3_halo_kernel<false, 320, 2>), grid, dim3(512), l, s, h);
+            } else if (hbn == 160) {
                 if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 160>), grid, dim3(512), l, s, h);
                 else hipLaunchKernelGGL((conv3_halo_kernel<false, 160>), grid, dim3(512), l, s, h);
             } else {
