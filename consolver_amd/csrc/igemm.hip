@@ -779,6 +779,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         const int PX = Wo / TW, PY = Ho / TH, PP = PX * PY;
         const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP;
         if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
+        else if (a.N % 256 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 256) >= 192 || g_tune_halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
         const int tiles_n = a.N / hbn;
         const int NC = cin / BK;
         int splits = 1;
@@ -805,13 +806,18 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
             const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * (wide ? 64 : 128));
             const dim3 grid(h.e.nblk, splits);
-            if (wide) {
+            if (wide && hbn == 320) {
                 if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 320, 2>), grid, dim3(512), l, s, h);
                 else hipLaunchKernelGGL((conv3_halo_kernel<false, 320, 2>), grid, dim3(512), l, s, h);
+            } else if (wide) {
+                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 256, 2>), grid, dim3(512), l, s, h);
+                else hipLaunchKernelGGL((conv3_halo_kernel<false, 256, 2>), grid, dim3(512), l, s, h);
             } else if (hbn == 160) {
                 if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 160>), grid, dim3(512), l, s, h);
                 else hipLaunchKernelGGL((conv3_halo_kernel<false, 160>), grid, dim3(512), l, s, h);
