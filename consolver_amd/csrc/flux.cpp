@@ -201,7 +201,12 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
         const int tD = (D + 255) / 256;
         const size_t t1 = gemm2_tail_workspace_bytes(((B * I + 255) / 256 + (B * T + 255) / 256) * tD, 4 * D);
         const size_t t2 = gemm2_tail_workspace_bytes(((B * S + 255) / 256) * tD, 5 * D);
-        Rn.tail_ws_bytes = t1 > t2 ? t1 : t2;
+        const size_t t3 = gemm2_tail_workspace_bytes(((B * I + 255) / 256 + (B * T + 255) / 256) * 4 * tD, D);      // FF1 pair (K = D)
+        const size_t t4 = gemm2_tail_workspace_bytes(((B * S + 255) / 256) * 4 * tD, D);                              // single-stream MLP
+        const size_t t5 = gemm2_tail_workspace_bytes(((B * S + 255) / 256) * 3 * tD, D);                              // single-stream QKV
+        const size_t t6 = gemm2_tail_workspace_bytes(((B * I + 255) / 256 + (B * T + 255) / 256) * 3 * tD, D);      // QKV pair
+        const size_t t7 = gemm2_tail_workspace_bytes(((B * I + 255) / 256 + (B * T + 255) / 256) * tD, D);          // attention out pair
+        Rn.tail_ws_bytes = std::max({t1, t2, t3, t4, t5, t6, t7});
         if (Rn.tail_ws_bytes) Rn.tail_ws = Rn.alloc(Rn.tail_ws_bytes);
     }
     Rn.attn_ws_bytes = attention_split_workspace_bytes(B, H, S, S, dh);

@@ -51,6 +51,17 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // the fp32 partial tiles go to `partial` ([tile - id0][split][256][256]) and g2_tail_reduce_kernel applies the epilogue.
 struct G2Pair { G2Params p[2]; int nblk0, nblk; int id0, splits; float* partial; };
 
+// Tile order: bands of GM row-tiles, row-tile fastest inside a band.  The ~32 tiles an XCD runs at once (consecutive ids) then cover
+// GM x (32 / GM) tiles: GM activation panels + 32/GM weight panels per k-step through that XCD's L2 instead of 1 + 32 in plain row-major
+// order (FLUX: 36-84 column tiles per row).  Measured: -4.5 % on the 36 / 48-column-tile shapes; nothing to gain at 12 column tiles, where plain
+// order is already 2.7 x 12.
+__device__ __forceinline__ void g2_tile_coords(const G2Params& p, int id, int& tm, int& tn) {
+    const int GM = p.tiles_n >= 24 ? 4 : 1;
+    const int band = id / (GM * p.tiles_n), rem = id - band * (GM * p.tiles_n);
+    const int gsz = min(GM, p.tiles_m - band * GM);
+    tn = rem / gsz; tm = band * GM + (rem - tn * gsz);
+}
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
@@ -77,14 +88,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         const int per = (p.KT + pp.splits - 1) / pp.splits;
         kt0 = blockIdx.y * per; KT = min(per, p.KT - kt0);
     }
-    // Tile order: bands of GM row-tiles, row-tile fastest inside a band.  The ~32 tiles an XCD runs at once (consecutive ids) then
-    // cover GM x (32 / GM) tiles: GM activation panels + 32/GM weight panels per k-step through that XCD's L2 instead of 1 + 32 in plain
-    // row-major order (FLUX: 36-84 column tiles per row), which is what the fabric can feed at the k-step rate.
-    // (measured: -4.5 % on the 36 / 48-column-tile shapes; nothing to gain at 12 column tiles, where plain order is already 2.7 x 12.)
-    const int GM = p.tiles_n >= 24 ? 4 : 1;
-    const int band = id / (GM * p.tiles_n), rem = id - band * (GM * p.tiles_n);
-    const int gsz = min(GM, p.tiles_m - band * GM);
-    const int tn = rem / gsz, tm = band * GM + (rem - tn * gsz);
+    int tm, tn;
+    g2_tile_coords(p, id, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BNX;
 
     const int pch = lane & 7;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     }
 }
 
-// split-K tail: out tile = epilogue(sum of the fp32 partial tiles); one thread per 8 output columns (no activation: the long-K layers have none)
+// split-K tail: out tile = epilogue(sum of the fp32 partial tiles); one thread per 8 output columns
 template <typename T>
 __global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
     const int second = id >= pp.nblk0;
     const G2Params& p = pp.p[second];
     if (second) id -= pp.nblk0;
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;      // plain row-major order (tiles_n < 24)
+    int tm, tn;
+    g2_tile_coords(p, id, tm, tn);
     const int m = tm * 256 + r, n = tn * 256 + c;
     if (m >= p.M || n >= p.N) return;
     float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -313,9 +319,9 @@ __global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(t[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(t[k] >> 16)); }
     }
-    // same rounding points as the in-kernel epilogue: the biased value is rounded to T before gate / residual
+    // same rounding points as the in-kernel epilogue: the biased (and activated) value is rounded to T before gate / residual
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = El<T>::tof(El<T>::fromf(f[k]));
+    for (int k = 0; k < 8; ++k) f[k] = El<T>::tof(El<T>::fromf(p.act == 1 ? gelu_tanh(f[k]) : f[k]));
     const size_t off = (size_t)rowmap(m, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + n;
     if (p.gate) {
         const float* gp = p.gate + (size_t)(m / p.rows_per_sample) * p.gate_stride + n;
@@ -407,21 +413,23 @@ static int g2_launch(const G2Pair& pp, int dtype, hipStream_t s, dim3 grid) {
 
 // Tail split: one tile per CU per round; when the last round is partly empty and K is long, its tiles are computed as `splits` k ranges side by
 // side (ceil(tail * splits / 256) rounds of 1/splits the length) and summed by the reduce kernel.  Returns 0 when it does not pay.
-static int g2_tail_splits(int nblk, int min_kt, bool plain, int* tail_out) {
+static int g2_tail_splits(int nblk, int min_kt, int* tail_out) {
     const int tail = nblk % G2_CUS;
     *tail_out = tail;
-    if (nblk <= G2_CUS || tail == 0 || min_kt < 96 || !plain) return 0;
-    int best = 0; double best_cost = 0.93;       // fraction of a full round; the partial write + reduce pass costs the rest
+    if (nblk <= G2_CUS || tail == 0 || min_kt < 96) return 0;      // K = 3072 tails were measured: +0.5 % (the partials cost more than the half round they save)
+    // cost of the tail in units of a full round: rounds of 1/sp length + the fp32 partial write and the reduce pass (about 10 us per split, i.e.
+    // 3.5 % of a K = 12288 round); it has to beat the partly empty round it replaces by a margin
+    int best = 0; double best_cost = 0.93;
     for (int sp = 2; sp <= 6; ++sp) {
-        const double cost = (double)((tail * sp + G2_CUS - 1) / G2_CUS) / sp + 0.035 * sp;
+        if (min_kt / sp < 16) break;
+        const double cost = (double)((tail * sp + G2_CUS - 1) / G2_CUS) / sp + 0.035 * sp * 200.0 / min_kt;
         if (cost < best_cost) { best_cost = cost; best = sp; }
     }
     return best;
 }
-static bool g2_plain(const G2Params& p) { return p.act == 0 && p.tiles_n < 24; }
 
 size_t gemm2_tail_workspace_bytes(int tiles, int K) {
-    int tail; const int sp = g2_tail_splits(tiles, K / BK, true, &tail);
+    int tail; const int sp = g2_tail_splits(tiles, K / BK, &tail);
     return sp ? (size_t)tail * sp * 256 * 256 * sizeof(float) : 0;
 }
 
@@ -429,7 +437,7 @@ static int g2_run(G2Pair pp, int dtype, void* tail_ws, size_t tail_ws_bytes, hip
     pp.id0 = 0; pp.splits = 1; pp.partial = nullptr;
     const bool two = pp.nblk > pp.nblk0;
     int tail = 0;
-    const int sp = tail_ws ? g2_tail_splits(pp.nblk, two ? std::min(pp.p[0].KT, pp.p[1].KT) : pp.p[0].KT, g2_plain(pp.p[0]) && (!two || g2_plain(pp.p[1])), &tail) : 0;
+    const int sp = tail_ws ? g2_tail_splits(pp.nblk, two ? std::min(pp.p[0].KT, pp.p[1].KT) : pp.p[0].KT, &tail) : 0;
     if (!sp || (size_t)tail * sp * 256 * 256 * sizeof(float) > tail_ws_bytes) return g2_launch(pp, dtype, s, dim3(pp.nblk));
     const int main_tiles = pp.nblk - tail;
     pp.nblk = main_tiles;

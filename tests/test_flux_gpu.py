@@ -95,7 +95,7 @@ def test_gemm2_split_k_tail_matches_unsplit():
         probs1.append(mk(o1)); probs2.append(mk(o2))
     tiles = 34 * 8 + 8
     nb = L.lib().cs_op_gemm2_workspace(tiles, K)
-    assert nb > 0 and L.lib().cs_op_gemm2_workspace(tiles, 3072) == 0 and L.lib().cs_op_gemm2_workspace(512, K) == 0
+    assert nb > 0 and L.lib().cs_op_gemm2_workspace(tiles, 1024) == 0 and L.lib().cs_op_gemm2_workspace(512, K) == 0
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
     st = L.stream_ptr(DEV)
     L.check(L.lib().cs_op_gemm2_pair(C.byref(probs1[0]), C.byref(probs1[1]), code, None, 0, st))
@@ -114,6 +114,28 @@ def test_gemm2_split_k_tail_matches_unsplit():
     L.check(L.lib().cs_op_gemm2_pair(C.byref(pr), None, code, ws.data_ptr(), nb, st))
     torch.cuda.synchronize()
     assert rel_l2(o3.float(), keep[0][5].float()) < 2e-3
+
+
+def test_gemm2_split_k_tail_gelu_banded_order():
+    """K = 6144 launch with the GELU epilogue and >= 24 column tiles (banded tile order): 11 x 24 = 264 tiles, the 8 of the last round are split in K"""
+    import ctypes as C
+    g = torch.Generator().manual_seed(5)
+    dt, code, M, K, N = torch.bfloat16, 2, 11 * 256 - 37, 6144, 6144
+    x = torch.randn(M, K, generator=g).to(dt).to(DEV); w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+    b = torch.randn(N, generator=g).to(dt).to(DEV)
+    o1, o2 = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
+    nb = L.lib().cs_op_gemm2_workspace(11 * 24, K)
+    assert nb > 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    st = L.stream_ptr(DEV)
+    mk = lambda o: L.CsGemm2Problem(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, None, None, 0, 0, 1, o.data_ptr(), N, 0)
+    p1, p2 = mk(o1), mk(o2)
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(p1), None, code, None, 0, st))
+    L.check(L.lib().cs_op_gemm2_pair(C.byref(p2), None, code, ws.data_ptr(), nb, st))
+    torch.cuda.synchronize()
+    assert rel_l2(o2.float(), o1.float()) < 2e-3
+    ref = torch.nn.functional.gelu(x.float() @ w.float().T + b.float(), approximate="tanh")
+    assert rel_l2(o2.float(), ref) < 8e-3
 
 
 @pytest.mark.parametrize("dt,code,tol,B", [(torch.bfloat16, 2, 2e-2, 1), (torch.float16, 1, 3e-3, 1), (torch.float16, 1, 3e-3, 2)])
