@@ -19,8 +19,9 @@
 //   * O^T leaves each lane with 4 consecutive channels of one query row -> 8-byte stores.
 #include "ops.h"
 #include "el.h"
-#include <stdlib.h>
 #include <type_traits>
+
+int g_tune_attn_qt40 = 4;
 
 namespace {
 
@@ -545,7 +546,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     }
     switch (a.dh) {
         case 40: {
-            static const int qt = getenv("CS_ATTN_QT40") ? atoi(getenv("CS_ATTN_QT40")) : 4;   // tuning knob
+            const int qt = g_tune_attn_qt40;      // cs_set_tuning("attn_qt40", 2 | 4): query tiles per wave at head dim 40
             if (a.dtype == CS_BF16) CS_FAIL(CS_E_UNSUPPORTED, "attention: bf16 is built for head dim 128 only");
             if (qt == 4) return launch_attn<f16, 40, 4>(p, a.B, s);
             return launch_attn<f16, 40, 2>(p, a.B, s);

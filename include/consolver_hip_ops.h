@@ -92,7 +92,11 @@ int cs_op_embed_rows(const int64_t* ids, const void* table, void* out, int64_t r
 int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                          int B, int H, int N, int dh, float scale, const float* bias_log2e, int dtype, void* stream);
 
-/* kernel-selection knobs (tests / tuning): "conv_halo" = 0 never, 1 auto (default), 2 whenever the shape allows */
+/* kernel-selection knobs (tests / tuning):
+ *   "conv_halo": 0 never, 1 auto (default), 2 whenever the shape allows, 3 also force the 256x320 / 256x256 k32 tiles, 4 never use those;
+ *   "gemm_big":  0 off, 1 auto (default), 2 force the 256x320 GEMM, 3 force the 256x160 GEMM;
+ *   "attn_qt40": query tiles per wave at head dim 40 (2 | 4, default 4);
+ *   "debug":     1 skip the GEMM epilogue, 2 skip its k loop (timing experiments only: results are wrong) */
 int cs_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
