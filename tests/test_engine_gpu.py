@@ -186,3 +186,24 @@ def test_pipeline_call_surface():
         pipe(prompt_embeds=pe, negative_prompt_embeds=ne, height=512, width=512)
     with pytest.raises(RuntimeError):
         pipe(prompt="a cat")
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    """bench.py (N = 1, short) prints ONE JSON line with the driver's keys plus roofline / ceilings / cpu_baseline objects"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--decode", "0",
+                        "--no-cpu-baseline", "--profile-kernels", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 1 and rec["steps"] == 1 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["dtype"] == "f16"
+    assert rec["unit"] == "images/s" and rec["value"] > 1.0 and "workload" in rec["config"] and "model" not in rec["config"]
+    rf = rec["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
+    assert rec["ceilings"]["vendor_gemm_f16_8192_tflops"] > 100 and rec["ceilings"]["dtod_copy_1gib_tbps"] > 1.0
+    assert rec["cpu_baseline"] is None          # --no-cpu-baseline
