@@ -114,6 +114,43 @@ def test_conv3x3_halo_kernel_fused_upsample(B, H, cin, N):
     assert rel_l2(nchw(out), ref) < 1e-3
 
 
+WIDE_CASES = [  # B, H, W, cin, N (multiples of 320 / 256): the 256x320 and 256x256 tiles with the k32 inner step, forced (conv_halo = 3) on every
+    # tile geometry: 16x16 patches, whole 8-wide images four per tile with a ragged last tile, non-square images, several column tiles
+    (2, 64, 64, 64, 320), (1, 32, 32, 128, 640), (2, 16, 16, 64, 1280), (5, 8, 8, 64, 320), (1, 64, 64, 64, 256), (1, 32, 32, 128, 512),
+    (3, 8, 8, 128, 256), (2, 16, 32, 64, 320), (1, 48, 80, 64, 256),
+    (8, 8, 8, 1280, 320), (2, 16, 16, 512, 256)]        # + split over the channel chunks (fp32 partials)
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv3x3_halo_kernel_wide_tiles(case):
+    B, H, W, cin, N = case
+    x, w, b = rnd(B, H, W, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, W, N, seed=5)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
+    outs = {}
+    for mode in (3, 4):                     # 3: force the wide tiles, 4: forbid them (k64 tiles of 160 / 128 columns)
+        ops.set_tuning("conv_halo", mode)
+        try:
+            outs[mode] = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
+        finally:
+            ops.set_tuning("conv_halo", 1)
+    assert rel_l2(nchw(outs[3]), ref) < 1e-3
+    assert float((nchw(outs[3]) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+    assert rel_l2(outs[3].float(), outs[4].float()) < 5e-4      # same math, different k order
+
+
+@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 640), (1, 64, 64, 256)])
+def test_conv3x3_halo_kernel_wide_tiles_fused_upsample(B, H, cin, N):
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    ops.set_tuning("conv_halo", 3)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, upsample=True)
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+
+
 @pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160)])
 def test_conv3x3_halo_kernel_split_k(B, H, cin, N):
     """small images: channel chunks split over workgroups, fp32 partials + fused reduce epilogue"""
