@@ -29,7 +29,7 @@ class CsStepArgs(C.Structure):
                 ("actions", C.c_void_p), ("actions_stride", C.c_int), ("B", C.c_int), ("elems", C.c_int64),
                 ("io_dtype", C.c_int), ("out_dtype", C.c_int), ("x_out", C.c_void_p), ("eps_out", C.c_void_p),
                 ("sqrt_at", C.c_float), ("sqrt_1mat", C.c_float), ("sqrt_ap", C.c_float), ("sqrt_1map", C.c_float),
-                ("v_prediction", C.c_int), ("dt", C.c_float)]
+                ("v_prediction", C.c_int), ("dt", C.c_float), ("x_is_f32", C.c_int)]
 
 
 class CsFluxConfig(C.Structure):
@@ -186,7 +186,7 @@ def lib():
             raise RuntimeError(f"libconsolver_hip.so does not export {name}") from e
         f.restype = res
         f.argtypes = args
-    if l.cs_abi_version() != 1:
+    if l.cs_abi_version() != 2:
         raise RuntimeError("libconsolver_hip.so ABI version mismatch")
     _lib = l
     return l

@@ -53,7 +53,8 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(PKG), "include", "consolver_hip.h"))
+    inc = os.path.join(os.path.dirname(PKG), "include")
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]   # every ABI header
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

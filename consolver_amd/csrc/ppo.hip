@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void policy_row_kernel(PolicyRowArgs a) {
         se = wave_sum(se);
         const float inv = 1.0f / se;
         float ent = 0.f;
-        for (int k = lane; k < K; k += 64) { const float p = lg[ad * K + k] * inv; lg[ad * K + k] = p; ent -= p * logf(fmaxf(p, 1.1920929e-07f)); }
+        for (int k = lane; k < K; k += 64) { const float p = lg[ad * K + k] * inv; lg[ad * K + k] = p; ent -= p * logf(fminf(fmaxf(p, 1.1920929e-07f), 1.f - 1.1920929e-07f)); }
         ent = wave_sum(ent);
         // nearest grid bin (first minimum), factor_net_ppo.py:174-178
         const float act = a.actions[(size_t)r * A + ad];

@@ -75,6 +75,7 @@ struct StepParams {
     int64_t elems;
     void* x_out; void* eps_out;
     float sat, s1mat, sap, s1map; int vpred; float dt;
+    int x_f32;   // x is fp32 although eps / history are TI (scheduler_fmppo.py:354 upcasts the sample, not the model output)
 };
 
 // coefficient fix-up, identical for every thread of a sample (b is block-uniform)
@@ -129,7 +130,12 @@ __global__ __launch_bounds__(256) void lms_step_kernel(StepParams p) {
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = base + v * V;
         float x[V], e[V], u[V], h[CS_MAX_ORDER - 1][V], o[V];
-        Io<TI>::load(p.x, i, x);
+        if (p.x_f32) {   // block-uniform
+#pragma unroll
+            for (int j = 0; j < V; ++j) x[j] = reinterpret_cast<const float*>(p.x)[i + j];
+        } else {
+            Io<TI>::load(p.x, i, x);
+        }
         Io<TI>::load(p.ec, i, e);
         if (p.eu) {
             Io<TI>::load(p.eu, i, u);
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void lms_step_kernel(StepParams p) {
     if (blockIdx.x == 0) {
         for (int64_t t = nvec * V + threadIdx.x; t < p.elems; t += blockDim.x) {
             const int64_t i = base + t;
-            float x = Io<TI>::load1(p.x, i), e = Io<TI>::load1(p.ec, i);
+            float x = p.x_f32 ? reinterpret_cast<const float*>(p.x)[i] : Io<TI>::load1(p.x, i), e = Io<TI>::load1(p.ec, i);
             if (p.eu) { float u = Io<TI>::load1(p.eu, i); e = Io<TI>::round(u + p.g * (e - u)); }
             float hh[CS_MAX_ORDER - 1];
 #pragma unroll
@@ -192,6 +198,7 @@ int launch_step(const CsStepArgs* a, void* stream) {
     p.x_out = a->x_out; p.eps_out = a->eps_out;
     p.sat = a->sqrt_at; p.s1mat = a->sqrt_1mat; p.sap = a->sqrt_ap; p.s1map = a->sqrt_1map;
     p.vpred = a->v_prediction; p.dt = a->dt;
+    p.x_f32 = (a->x_is_f32 != 0 && a->io_dtype != CS_F32);
     const int vec = (a->io_dtype == CS_F32) ? 4 : 8;
     int64_t nvec = a->elems / vec;
     int gx = (int)((nvec + 255) / 256);
@@ -214,13 +221,60 @@ int launch_step(const CsStepArgs* a, void* stream) {
 }
 
 // ---------------------------------------------------------------- policy MLP
-// one 256-thread workgroup per sample row; weights (<= ~1 MB) stay in L2.
-__global__ __launch_bounds__(256) void factor_probs_kernel(CsFactorNet n, const float* x, int xstride, const float* cosf, float* probs) {
+// one workgroup per DISTINCT conditioning row; weights (<= ~1 MB) stay in L2.  When one row is
+// broadcast to all B samples (x_row_stride == 0, no cosine features: every sampling step), a single
+// workgroup evaluates the MLP once and writes the B identical probability rows.  Each wave keeps
+// RW weight rows in flight (one 16-byte load per lane and row when hidden % 4 == 0) so the layer is
+// a few L2 round trips instead of hidden / waves dependent ones.
+template <int RW>
+__device__ __forceinline__ void dense_rows(const float* __restrict__ w, const float* __restrict__ bias, const float* in_lds,
+                                           float* out_lds, int rows, int K, int wave, int nw, int lane, bool relu, float post) {
+    const bool vec = (K & 3) == 0 && ((uintptr_t)w & 15) == 0;
+    for (int j0 = wave * RW; j0 < rows; j0 += nw * RW) {
+        float acc[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+        if (vec) {
+            for (int k = lane * 4; k < K; k += 256) {
+                f32x4 wv[RW];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const int j = j0 + r < rows ? j0 + r : rows - 1;
+                    wv[r] = *reinterpret_cast<const f32x4*>(w + (int64_t)j * K + k);
+                }
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(in_lds + k);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r] += xv[0] * wv[r][0] + xv[1] * wv[r][1] + xv[2] * wv[r][2] + xv[3] * wv[r][3];
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                const float xv = in_lds[k];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const int j = j0 + r < rows ? j0 + r : rows - 1;
+                    acc[r] += xv * w[(int64_t)j * K + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const float v = wave_sum(acc[r]);
+            if (lane == 0 && j0 + r < rows) {
+                const float o = (v + bias[j0 + r]) * post;
+                out_lds[j0 + r] = relu ? fmaxf(o, 0.f) : o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void factor_probs_kernel(CsFactorNet n, const float* x, int xstride, const float* cosf, float* probs,
+                                                            int rows_out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* in = sm;                    // [in_dim] (<= 16)
-    float* h0 = sm + 16;               // [H]
-    float* h1 = h0 + n.hidden;         // [H]
-    float* lg = h1 + n.hidden;         // [A*K]
+    float* in = sm;                               // [in_dim] (<= 16)
+    float* h0 = sm + 16;                          // [H] (padded to a multiple of 4)
+    const int Hp = (n.hidden + 3) & ~3;
+    float* h1 = h0 + Hp;                          // [H]
+    float* lg = h1 + Hp;                          // [A*K] logits, then probabilities
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     if (tid < n.in_dim) in[tid] = (tid < 2) ? x[(int64_t)b * xstride + tid] * n.input_scale
                                             : cosf[(int64_t)b * (n.in_dim - 2) + tid - 2];
@@ -231,32 +285,26 @@ __global__ __launch_bounds__(256) void factor_probs_kernel(CsFactorNet n, const 
         h0[j] = fmaxf(acc + n.b0[j], 0.f);
     }
     __syncthreads();
-    for (int j = wave; j < n.hidden; j += nw) {
-        float acc = 0.f;
-        for (int k = lane; k < n.hidden; k += 64) acc += h0[k] * n.w1[(int64_t)j * n.hidden + k];
-        acc = wave_sum(acc);
-        if (lane == 0) h1[j] = fmaxf(acc + n.b1[j], 0.f);
-    }
+    dense_rows<8>(n.w1, n.b1, h0, h1, n.hidden, n.hidden, wave, nw, lane, true, 1.f);
     __syncthreads();
     const int AK = n.action_dims * n.num_actions;
-    for (int j = wave; j < AK; j += nw) {
-        float acc = 0.f;
-        for (int k = lane; k < n.hidden; k += 64) acc += h1[k] * n.w2[(int64_t)j * n.hidden + k];
-        acc = wave_sum(acc);
-        if (lane == 0) lg[j] = (acc + n.b2[j]) * n.inv_temperature;
-    }
+    dense_rows<4>(n.w2, n.b2, h1, lg, AK, n.hidden, wave, nw, lane, false, n.inv_temperature);
     __syncthreads();
     for (int a = wave; a < n.action_dims; a += nw) {
-        const float* row = lg + a * n.num_actions;
+        float* row = lg + a * n.num_actions;
         float mx = -INFINITY;
         for (int k = lane; k < n.num_actions; k += 64) mx = fmaxf(mx, row[k]);
         mx = wave_max(mx);
         float s = 0.f;
         for (int k = lane; k < n.num_actions; k += 64) s += expf(row[k] - mx);
         s = wave_sum(s);
-        float* out = probs + ((int64_t)b * n.action_dims + a) * n.num_actions;
-        for (int k = lane; k < n.num_actions; k += 64) out[k] = expf(row[k] - mx) / s;
+        for (int k = lane; k < n.num_actions; k += 64) row[k] = expf(row[k] - mx) / s;
     }
+    __syncthreads();
+    // rows_out == 1: this workgroup's own row; > 1: the broadcast row written to every sample
+    float* out = probs + (int64_t)b * AK;
+    for (int r = wave; r < rows_out; r += nw)
+        for (int k = lane; k < AK; k += 64) out[(int64_t)r * AK + k] = lg[k];
 }
 
 struct HistPtrs { const void* p[CS_MAX_ORDER]; };
@@ -333,7 +381,9 @@ __global__ void action_probs_kernel(const float* probs, const float* actions, co
         s += p[j];
     }
     float h = 0.f;
-    for (int j = 0; j < K; ++j) { float q = p[j] / s; if (q > 0.f) h -= q * logf(q); }
+    // torch.distributions.Categorical(probs=p).entropy(): -sum q log(clamp(q, eps, 1 - eps)) with q = p / sum p
+    // (the same clamp the PPO gradient kernel differentiates, ppo.hip policy_row_kernel)
+    for (int j = 0; j < K; ++j) { float q = p[j] / s; h -= q * logf(fminf(fmaxf(q, 1.1920929e-07f), 1.f - 1.1920929e-07f)); }
     if (sel) sel[t] = p[best];
     if (ent) ent[t] = h / logf((float)K);
 }
@@ -384,9 +434,14 @@ int cs_factor_probs(const CsFactorNet* n, const float* x, int x_row_stride, cons
     if (n->action_dims < 1 || n->action_dims > CS_MAX_ACTION_DIMS) CS_FAIL(CS_E_SHAPE, "action_dims %d out of range", n->action_dims);
     if (n->num_actions < 1 || n->num_actions > 1024) CS_FAIL(CS_E_SHAPE, "num_actions %d out of range", n->num_actions);
     if (n->in_dim > 2 && !cos_feat) CS_FAIL(CS_E_ARG, "use_conv=True requires epsilon (factor_net_ppo.py:109-110)");
-    size_t lds = (16 + 2 * (size_t)n->hidden + (size_t)n->action_dims * n->num_actions) * sizeof(float);
+    const size_t Hp = ((size_t)n->hidden + 3) & ~(size_t)3;
+    size_t lds = (16 + 2 * Hp + (size_t)n->action_dims * n->num_actions) * sizeof(float);
     if (lds > 64 * 1024) CS_FAIL(CS_E_SHAPE, "policy net too large for one workgroup (%zu B LDS)", lds);
-    hipLaunchKernelGGL(factor_probs_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, *n, x, x_row_stride, cos_feat, probs);
+    // one broadcast conditioning row and no per-sample features: evaluate once, write B rows
+    const bool bcast = (x_row_stride == 0 && n->in_dim == 2 && B > 1);
+    const int threads = n->hidden >= 128 ? 1024 : 256;
+    hipLaunchKernelGGL(factor_probs_kernel, dim3(bcast ? 1 : B), dim3(bcast ? threads : 256), lds, (hipStream_t)stream, *n, x,
+                       x_row_stride, cos_feat, probs, bcast ? B : 1);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

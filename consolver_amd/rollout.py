@@ -46,8 +46,9 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
     try:
         for i, t in enumerate(scheduler.timesteps):
             if native:
+                # K/V of the prompt: computed at step 0 of THIS rollout, reused afterwards
                 noise_pred = unet(latents, t, encoder_hidden_states=prompt_embeds, return_dict=False,
-                                  dup=2 if do_cfg else 1)[0]
+                                  dup=2 if do_cfg else 1, reuse_kv=(i > 0))[0]
             else:
                 lat_in = torch.cat([latents] * 2) if do_cfg else latents
                 lat_in = scheduler.scale_model_input(lat_in, t)

@@ -157,7 +157,12 @@ class FMPPOScheduler(HistoryMixin):
         L.require_cuda(model_output, "model_output")
         L.require_cuda(sample, "sample")
         model_output = model_output.contiguous()
-        sample = sample.contiguous().to(model_output.dtype)
+        # the reference upcasts the SAMPLE to fp32 (scheduler_fmppo.py:354) and rounds only the result (:435-436):
+        # an fp32 sample is consumed as fp32 by the kernel; a sample already in the model dtype is exact either way
+        sample = sample.contiguous()
+        x_is_f32 = (sample.dtype == torch.float32 and model_output.dtype != torch.float32)
+        if not x_is_f32 and sample.dtype != model_output.dtype:
+            sample = sample.to(model_output.dtype)
         dev = model_output.device
         B = model_output.shape[0]
         self.ets.append(model_output)
@@ -181,6 +186,8 @@ class FMPPOScheduler(HistoryMixin):
         a = L.CsStepArgs()
         self._fill_step_args(a, sample, model_output, None, 1.0, actions, prev, None, model_output.dtype)
         a.dt = float(dt)
+        if x_is_f32:
+            a.io_dtype, a.x_is_f32 = L.dtype_code(model_output.dtype), 1
         L.check(L.lib().cs_lms_euler_step(C.byref(a), L.stream_ptr(dev)))
         self._step_index += 1
 

@@ -130,6 +130,9 @@ class PPOScheduler(HistoryMixin):
         self._timesteps = np.arange(0, num_train_timesteps)[::-1].copy()
         self.timesteps = torch.from_numpy(self._timesteps)
         self.ets = []
+        self._grid_index = {int(v): i for i, v in enumerate(self._timesteps)}
+        self._step_counter = None
+        self._t_mismatch = None
         kw = dict(factor_net_kwargs) if factor_net_kwargs is not None else {}
         kw["order_dim"], kw["scaler_dim"], kw["use_conv"] = order_dim, scaler_dim, use_conv
         kw.setdefault("embedding_dim", 32)
@@ -157,8 +160,12 @@ class PPOScheduler(HistoryMixin):
         if ts.min() < 0 or ts.max() >= T:
             # e.g. trailing with n=61 yields 62 entries ending in -1 in the reference (it would wrap around)
             raise ValueError(f"timestep grid for n={num_inference_steps} leaves [0, {T}): {ts.min()}..{ts.max()}")
+        if self._t_mismatch is not None and not torch.cuda.is_current_stream_capturing():
+            self.verify_timesteps()
         self.num_inference_steps = num_inference_steps
         self._timesteps = ts
+        self._grid_index = {int(v): i for i, v in enumerate(ts)}
+        self._step_counter = None
         same = (self._cond_table is not None and self._cond_table[3] == num_inference_steps and device is not None
                 and self.timesteps.device == torch.device(device))
         if not same:
@@ -173,17 +180,46 @@ class PPOScheduler(HistoryMixin):
         return self.config.num_train_timesteps
 
     def _resolve_timestep(self, timestep):
-        """integer value of ``timestep`` without a device sync when it is an element of self.timesteps."""
-        if isinstance(timestep, torch.Tensor):
-            if timestep.is_cuda:
-                ts = self.timesteps
-                if ts.is_cuda and ts.device == timestep.device and timestep.dtype == ts.dtype:
-                    off = timestep.data_ptr() - ts.data_ptr()
-                    if 0 <= off < ts.numel() * ts.element_size() and off % ts.element_size() == 0:
-                        return int(self._timesteps[off // ts.element_size()])
-                return int(timestep.item())
-            return int(timestep)
-        return int(timestep)
+        """integer value of ``timestep`` without a device->host sync per step.
+
+        Host ints / CPU tensors are read directly.  A CUDA element of ``self.timesteps`` (what
+        ``for t in scheduler.timesteps`` yields) is identified by its address.  Any other CUDA tensor
+        (``t.clone()``, ``t + 0``, a caller's own grid) costs ONE ``.item()`` for the first such step after
+        ``set_timesteps`` -- that anchors a host-side step counter on the grid -- and later steps take the
+        next grid entry from the counter, verified on the device without a sync (``verify_timesteps()`` /
+        the next ``set_timesteps`` raise if a step was driven with a different value).  The reference
+        itself syncs on every step (CPU table indexed by the CUDA timestep, scheduler_ppo.py:309-312)."""
+        grid = self._timesteps
+        if not isinstance(timestep, torch.Tensor):
+            v = int(timestep)
+        elif not timestep.is_cuda:
+            v = int(timestep)
+        else:
+            ts = self.timesteps
+            v = None
+            if ts.is_cuda and ts.device == timestep.device and timestep.dtype == ts.dtype:
+                off = timestep.data_ptr() - ts.data_ptr()
+                if 0 <= off < ts.numel() * ts.element_size() and off % ts.element_size() == 0:
+                    v = int(grid[off // ts.element_size()])
+            if v is None:
+                i = self._step_counter
+                if i is None or i >= len(grid):
+                    v = int(timestep.item())                     # anchor (first foreign tensor) or past the grid
+                else:
+                    v = int(grid[i])
+                    bad = (timestep.reshape(-1)[:1] != v).to(torch.int32)
+                    self._t_mismatch = bad if self._t_mismatch is None else self._t_mismatch + bad
+        i = self._grid_index.get(v)
+        self._step_counter = None if i is None else i + 1
+        return v
+
+    def verify_timesteps(self):
+        """raise if a step whose timestep was taken from the host-side counter was driven with another value
+        (one device->host read; called by ``set_timesteps`` outside stream capture, or by the user)."""
+        m, self._t_mismatch = self._t_mismatch, None
+        if m is not None and int(m.item()) != 0:
+            raise RuntimeError("PPOScheduler.step was called with CUDA timesteps that are not consecutive entries of "
+                               "scheduler.timesteps; pass elements of scheduler.timesteps or host integers")
 
     def _cond_row(self, t, prev_t, dtype, device):
         """[1,2] fp32 device row (t, prev_t) rounded through the model dtype like

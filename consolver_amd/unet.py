@@ -42,7 +42,9 @@ class HipUNet2DConditionModel:
         self._h = h
         self._ws = None
         self._ws_batch = 0
-        self._kv_ctx_key = None
+        self._kv_ctx_ref = None      # strong reference to the conditioning tensor the K/V cache was built from
+        self._kv_ctx_version = -1
+        self._kv_batch = -1
         self._finalized = False
         self._t_buf = None
 
@@ -92,8 +94,14 @@ class HipUNet2DConditionModel:
             n = int(L.lib().cs_unet_workspace_bytes(self._h, batch))
             self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
-            self._kv_ctx_key = None
+            self.invalidate_kv()
         return self._ws
+
+    def invalidate_kv(self):
+        """drop the cached cross-attention K/V (the next forward recomputes them from its conditioning)."""
+        self._kv_ctx_ref = None
+        self._kv_ctx_version = -1
+        self._kv_batch = -1
 
     def set_profiling(self, on):
         L.check(L.lib().cs_unet_set_profiling(self._h, int(on)))
@@ -127,14 +135,25 @@ class HipUNet2DConditionModel:
         if t.numel() not in (1, B):
             raise ValueError("timestep must be a scalar or one value per sample")
         ws = self._workspace(B)
-        key = (ctx.data_ptr(), ctx._version, B)
-        kv_valid = (self._kv_ctx_key == key) if reuse_kv is None else bool(reuse_kv)
+        # Cross-attention K/V of the prompt are cached across the steps of one generation.  reuse_kv=True/False
+        # is the caller's explicit statement (the sampling engine and the rollout pass ``i > 0``).  With
+        # reuse_kv=None the cache is reused only when the SAME tensor object, unmodified, is passed again: the
+        # cache holds a strong reference to it, so its storage cannot be recycled for another prompt batch
+        # (a (data_ptr, _version) key alone would match a fresh ``torch.cat`` that the caching allocator placed
+        # at the freed address of the previous one).
+        if reuse_kv is None:
+            kv_valid = (encoder_hidden_states is self._kv_ctx_ref and ctx is encoder_hidden_states
+                        and ctx._version == self._kv_ctx_version and self._kv_batch == B)
+        else:
+            kv_valid = bool(reuse_kv) and self._kv_batch == B
+            if reuse_kv and not kv_valid:
+                raise RuntimeError("reuse_kv=True but no K/V cache exists for this batch size")
         if out is None:
             out = torch.empty(B, self.config["out_channels"], sample.shape[2], sample.shape[3], dtype=torch.float16,
                               device=sample.device)
         L.check(L.lib().cs_unet_forward(self._h, L.ptr(sample), n_lat, dup, L.ptr(t), t.numel(), L.ptr(ctx), L.ptr(out),
                                         L.ptr(ws), ws.numel(), int(kv_valid), L.stream_ptr(sample.device)))
-        self._kv_ctx_key = key
+        self._kv_ctx_ref, self._kv_ctx_version, self._kv_batch = encoder_hidden_states, ctx._version, B
         if return_dict:
             return {"sample": out}
         return (out,)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2
 #define CS_MAX_ORDER 8        /* order_dim <= 8 */
 #define CS_MAX_ACTION_DIMS 16 /* order + scaler + mu - 1 */
 
@@ -127,6 +127,9 @@ typedef struct CsStepArgs {
     int v_prediction;
     /* Euler (flow matching): dt = sigma_next - sigma (scheduler_fmppo.py:376) */
     float dt;
+    /* nonzero: x is fp32 while eps_* / hist stay io_dtype (scheduler_fmppo.py:354 upcasts the sample
+       before the update and rounds only the result); ABI version 2 */
+    int x_is_f32;
 } CsStepArgs;
 
 int cs_lms_ddim_step(const CsStepArgs* args, void* stream);

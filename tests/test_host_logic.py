@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), name
     l = _lib.lib()
-    assert l.cs_abi_version() == 1 and l.cs_target_arch() == b"gfx950"
+    assert l.cs_abi_version() == 2 and l.cs_target_arch() == b"gfx950"
     assert l.cs_error_string(-6) == b"not implemented"
 
 

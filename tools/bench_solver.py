@@ -42,3 +42,28 @@ rows = [run(16, 16384, torch.float16, 4),            # configs[1]: batch 16, ste
         run(4096, 16384, torch.float16, 4),          # 1 GB working set: what the kernel sustains when HBM-bound
         run(2048, 262144, torch.bfloat16, 2, cfg=False, euler=True)]
 for r in rows: print(json.dumps(r))
+
+
+def policy_us(B, hidden=256, K=11, order=4, iters=200):
+    """policy MLP + softmax (cs_factor_probs) per sampling step: one conditioning row broadcast to B samples"""
+    import consolver_amd
+    net = consolver_amd.FactorNetPPO(hidden_dim=hidden, num_actions=K, order_dim=order, scaler_dim=0)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn(p.shape) * 0.5)
+    net.to(dev)
+    row = torch.tensor([[874.0, 749.0]], device=dev)
+    rows = row.repeat(B, 1).contiguous()
+    out = {}
+    for name, fn in (("broadcast_row", lambda: net.probs_from(row, batch=B)), ("per_row", lambda: net.probs_from(rows))):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        out[name + "_us"] = round(e0.elapsed_time(e1) / iters * 1e3, 2)     # includes the host-side launch path
+    return dict(kernel="factor_probs", B=B, hidden=hidden, **out)
+
+print(json.dumps(policy_us(16)))
+print(json.dumps(policy_us(80)))
