@@ -180,9 +180,15 @@ struct FRun {
     }
 };
 
+// hidden2 / I2: optional second block of image tokens per sample (the Kontext reference-image latents,
+// edit_ppo/pipeline.py:1080 `cat([latents, image_latents], dim=1)`): the joint image sequence [hidden | hidden2] is never
+// materialised -- the embedder reads both sources -- and only the I1 = I - I2 rows of `hidden` get an output row
+// (`noise_pred[:, :latents.size(1)]`, edit_ppo/denoise_diffusion.py:145).
 int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const void* enc, int T, const float* pooled, const float* timestep,
-                 const float* guidance, const float* rcos, const float* rsin, void* out, char* ws, size_t ws_bytes, hipStream_t s) {
+                 const float* guidance, const float* rcos, const float* rsin, void* out, char* ws, size_t ws_bytes, hipStream_t s,
+                 const void* hidden2 = nullptr, int I2 = 0) {
     const CsFluxConfig& c = f->cfg; const int D = f->D, S = T + I, H = c.num_heads, dh = c.head_dim;
+    const int I1 = I - I2;                    // rows of `hidden` per sample = output rows per sample
     f->arena.reset(dry ? (char*)256 : ws, ws_bytes, dry); f->dry_flops = 0;
     FRun Rn{f, s, dry}; Rn.dt = c.dtype;
     const size_t e = 2;
@@ -228,7 +234,11 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     const long MS = f->mod_total;
 
     // ---- embedders ---------------------------------------------------------------------------------------------
-    Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D);
+    if (I2 > 0)
+        Rn.gemm_pair(FRun::gargs(f->x_emb, hidden, c.in_channels, B * I1, img, D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I1, I, 0),
+                     FRun::gargs(f->x_emb, hidden2, c.in_channels, B * I2, img, D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I2, I, I1));
+    else
+        Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D);
     Rn.gemm(f->c_emb, enc, c.joint_attention_dim, B * T, ctx, D);
 
     // ---- double-stream blocks -----------------------------------------------------------------------------------
@@ -272,10 +282,10 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     // ---- output head on the image tokens ----------------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK)
         for (int b = 0; b < B; ++b)
-            hipMemcpyAsync(img + (size_t)b * I * D, hs + ((size_t)b * S + T) * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(img + (size_t)b * I1 * D, hs + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s);
     const float* mf = mod + f->mod_final;                                         // AdaLayerNormContinuous: [scale, shift]
-    Rn.lnmod(img, nimg, B * I, D, I, mf + D, mf, MS);
-    Rn.gemm(f->proj_out, nimg, D, B * I, out, c.in_channels);
+    Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS);
+    Rn.gemm(f->proj_out, nimg, D, B * I1, out, c.in_channels);
     return Rn.rc;
 }
 
@@ -413,6 +423,20 @@ int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len
     if (img_len <= 0 || txt_len <= 0) CS_FAIL(CS_E_SHAPE, "sequence lengths must be positive");
     return flux_forward(f, false, hidden_states, batch, img_len, encoder_hidden_states, txt_len, pooled_f32, timestep, guidance, rope_cos, rope_sin, out,
                         (char*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const void* image_latents, int image_len, int batch,
+                          const void* encoder_hidden_states, int txt_len, const float* pooled_f32, const float* timestep, const float* guidance,
+                          const float* rope_cos, const float* rope_sin, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!f) CS_FAIL(CS_E_ARG, "flux is NULL");
+    if (!f->finalized) CS_FAIL(CS_E_STATE, "cs_flux_finalize has not been called");
+    if (batch <= 0) return batch < 0 ? CS_E_SHAPE : CS_OK;
+    if (!latents || !encoder_hidden_states || !pooled_f32 || !timestep || !rope_cos || !rope_sin || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
+    if (f->cfg.guidance_embeds && !guidance) CS_FAIL(CS_E_ARG, "guidance is required (guidance_embeds)");
+    if (lat_len <= 0 || txt_len <= 0 || image_len < 0) CS_FAIL(CS_E_SHAPE, "sequence lengths must be positive");
+    if (image_len > 0 && !image_latents) CS_FAIL(CS_E_ARG, "image_latents is NULL but image_len > 0");
+    return flux_forward(f, false, latents, batch, lat_len + image_len, encoder_hidden_states, txt_len, pooled_f32, timestep, guidance, rope_cos,
+                        rope_sin, out, (char*)workspace, workspace_bytes, (hipStream_t)stream, image_len > 0 ? image_latents : nullptr, image_len);
 }
 
 }  // extern "C"

@@ -113,7 +113,14 @@ __device__ __forceinline__ float solve_one(const StepParams& p, float x, float e
     }
     if (p.scaler >= 1) eff = eff * sc0;
     if (p.scaler >= 2) x = x * sc1;
-    if (EULER) return x + p.dt * eff;
+    if (EULER) {
+        // scheduler_fmppo.py:429 `sample + dt * effective_model_output`: with ONE history entry and no scale the effective
+        // output is the bf16 / f16 model output itself and dt is a 0-d fp32 tensor, so torch runs the product as a 16-bit op
+        // (dt cast to the model dtype, product rounded to it) before the fp32 add; otherwise the [B,1,1] fp32 coefficients
+        // have promoted everything to fp32.
+        if (p.m == 1 && p.scaler == 0) return x + Io<TI>::round(Io<TI>::round(p.dt) * eff);
+        return x + p.dt * eff;
+    }
     if (p.vpred) eff = p.sat * eff + p.s1mat * x;
     float x0 = (x - p.s1mat * eff) / p.sat;
     return p.sap * x0 + p.s1map * eff;

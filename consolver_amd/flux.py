@@ -23,6 +23,16 @@ FLUX_KONTEXT_CONFIG = dict(in_channels=64, num_layers=19, num_single_layers=38, 
                            axes_dims_rope=(16, 56, 56), dtype=torch.bfloat16)
 
 
+class _Config(dict):
+    """dict with attribute access (``pipe.transformer.config.in_channels``, edit_ppo/denoise_diffusion.py:50,69)"""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
 # ---- layout helpers (pure index shuffles, edit_ppo/pipeline.py:574-611) ------------------------------------------
 def prepare_latent_image_ids(height, width, first=0.0):
     ids = np.zeros((height, width, 3), np.float32)
@@ -62,7 +72,7 @@ class HipFluxTransformer2DModel:
     is_consolver_hip = True
 
     def __init__(self, config=None, device="cuda:0"):
-        cfg = dict(FLUX_KONTEXT_CONFIG)
+        cfg = _Config(FLUX_KONTEXT_CONFIG)
         cfg.update(config or {})
         self.config = cfg
         self.dtype = cfg["dtype"]
@@ -127,8 +137,18 @@ class HipFluxTransformer2DModel:
         return float(L.lib().cs_flux_flops(self._h, batch, txt_len, img_len))
 
     def _rope_dev(self, txt_ids, img_ids):
-        ids = np.concatenate([np.asarray(txt_ids.detach().cpu() if torch.is_tensor(txt_ids) else txt_ids, np.float32),
-                              np.asarray(img_ids.detach().cpu() if torch.is_tensor(img_ids) else img_ids, np.float32)], 0)
+        # same id objects as the previous call (the edit loop passes them unchanged every step): no D2H copy, no sync
+        last = getattr(self, "_rope_last", None)
+        if last is not None and last[0] is txt_ids and last[1] is img_ids and not (
+                torch.is_tensor(img_ids) and img_ids._version != last[2]):
+            return last[3]
+        out = self._rope_from_values(txt_ids, img_ids)
+        self._rope_last = (txt_ids, img_ids, img_ids._version if torch.is_tensor(img_ids) else 0, out)
+        return out
+
+    def _rope_from_values(self, txt_ids, img_ids):
+        ids = np.concatenate([np.asarray(txt_ids.detach().float().cpu() if torch.is_tensor(txt_ids) else txt_ids, np.float32),
+                              np.asarray(img_ids.detach().float().cpu() if torch.is_tensor(img_ids) else img_ids, np.float32)], 0)
         key = ids.tobytes()
         if key not in self._rope:
             cos, sin = rope_tables(ids, self.config["axes_dims_rope"])
@@ -136,7 +156,15 @@ class HipFluxTransformer2DModel:
         return self._rope[key]
 
     def __call__(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
-                 txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False, out=None, **_ignored):
+                 txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False, out=None, image_latents=None,
+                 **_ignored):
+        """the reference's call (edit_ppo/pipeline.py:1087-1097): ``hidden_states`` [B, I, 64] (the caller's
+        ``cat([latents, image_latents], 1)``) -> [B, I, 64].
+
+        Extension used by the native edit loop: ``image_latents=`` [B, I2, 64] passes the Kontext reference-image
+        tokens as a second buffer -- the joint sequence [hidden_states | image_latents] is read in place (no per-step
+        ``torch.cat``) and the result holds the rows of ``hidden_states`` only ([B, I, 64], i.e. the reference's
+        ``noise_pred[:, :latents.size(1)]`` without the slice copy); ``img_ids`` cover I + I2 tokens."""
         if not self._finalized:
             raise RuntimeError("weights not loaded")
         L.require_cuda(hidden_states, "hidden_states")
@@ -144,6 +172,12 @@ class HipFluxTransformer2DModel:
         enc = L.require_cuda(encoder_hidden_states, "encoder_hidden_states").to(self.dtype).contiguous()
         B, I, _ = hs.shape
         T = enc.shape[1]
+        il, I2 = None, 0
+        if image_latents is not None:
+            il = L.require_cuda(image_latents, "image_latents").to(self.dtype).contiguous()
+            if il.shape[0] != B or il.shape[2] != hs.shape[2]:
+                raise ValueError("image_latents must be [B, I2, in_channels]")
+            I2 = il.shape[1]
         pooled = L.require_cuda(pooled_projections, "pooled_projections").to(torch.float32).contiguous()
         t = timestep.to(device=hs.device, dtype=torch.float32).reshape(-1) if torch.is_tensor(timestep) else \
             torch.full((B,), float(timestep), dtype=torch.float32, device=hs.device)
@@ -157,17 +191,22 @@ class HipFluxTransformer2DModel:
             if g.numel() == 1:
                 g = g.expand(B).contiguous()
         cos, sin = self._rope_dev(txt_ids, img_ids)
-        if cos.shape[0] != T + I:
-            raise ValueError(f"ids cover {cos.shape[0]} tokens, expected {T + I}")
-        key = (B, T, I)
+        if cos.shape[0] != T + I + I2:
+            raise ValueError(f"ids cover {cos.shape[0]} tokens, expected {T + I + I2}")
+        key = (B, T, I + I2)
         if self._ws_key != key:
-            n = int(L.lib().cs_flux_workspace_bytes(self._h, B, T, I))
+            n = int(L.lib().cs_flux_workspace_bytes(self._h, B, T, I + I2))
             self._ws = torch.empty(n, dtype=torch.uint8, device=hs.device)
             self._ws_key = key
         if out is None:
             out = torch.empty(B, I, self.config["in_channels"], dtype=self.dtype, device=hs.device)
-        L.check(L.lib().cs_flux_forward(self._h, L.ptr(hs), B, I, L.ptr(enc), T, L.ptr(pooled), L.ptr(t), L.ptr(g), L.ptr(cos),
-                                        L.ptr(sin), L.ptr(out), L.ptr(self._ws), self._ws.numel(), L.stream_ptr(hs.device)))
+        if il is None:
+            L.check(L.lib().cs_flux_forward(self._h, L.ptr(hs), B, I, L.ptr(enc), T, L.ptr(pooled), L.ptr(t), L.ptr(g), L.ptr(cos),
+                                            L.ptr(sin), L.ptr(out), L.ptr(self._ws), self._ws.numel(), L.stream_ptr(hs.device)))
+        else:
+            L.check(L.lib().cs_flux_forward_joint(self._h, L.ptr(hs), I, L.ptr(il), I2, B, L.ptr(enc), T, L.ptr(pooled), L.ptr(t),
+                                                  L.ptr(g), L.ptr(cos), L.ptr(sin), L.ptr(out), L.ptr(self._ws), self._ws.numel(),
+                                                  L.stream_ptr(hs.device)))
         if return_dict:
             return {"sample": out}
         return (out,)
@@ -199,16 +238,18 @@ class FluxKontextSamplingEngine:
             ids = np.concatenate([ids, prepare_latent_image_ids(*(image_hw or latent_hw), first=1.0)], 0)
         txt_ids = np.zeros((prompt_embeds.shape[1], 3), np.float32)
         guidance = torch.full([B], self.guidance_scale, device=dev, dtype=torch.float32)
+        # timestep / 1000 in the model dtype like the reference (`t.expand(B).to(dtype)` then `/ 1000`, pipeline.py:1084-1089)
+        sig = (sch.timesteps.to(latents.dtype) / 1000).to(torch.float32)
         x = latents
         rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
         prev_record = sch.record_conds
         sch.record_conds = bool(record)
         try:
             for i, t in enumerate(sch.timesteps):
-                x_in = torch.cat([x, image_latents], dim=1) if image_latents is not None else x
-                v = self.transformer(x_in, (t / 1000).expand(B), guidance=guidance, pooled_projections=pooled_prompt_embeds,
-                                     encoder_hidden_states=prompt_embeds, txt_ids=txt_ids, img_ids=ids)[0][:, :Lq]
-                x, actions, probs, conds, masks = sch.step(v.contiguous(), t, x, return_dict=False)
+                # [latents | image_latents] is read in place by the embedder; v holds the latent rows only
+                v = self.transformer(x, sig[i:i + 1].expand(B), guidance=guidance, pooled_projections=pooled_prompt_embeds,
+                                     encoder_hidden_states=prompt_embeds, txt_ids=txt_ids, img_ids=ids, image_latents=image_latents)[0]
+                x, actions, probs, conds, masks = sch.step(v, t, x, return_dict=False)
                 if record and i > 0:
                     rec["x"].append(conds["x"].unsqueeze(1)); rec["epsilon"].append(conds["epsilon"].unsqueeze(1))
                     rec["probs"].append(probs.unsqueeze(1)); rec["actions"].append(actions.unsqueeze(1)); rec["masks"].append(masks.unsqueeze(1))

@@ -93,8 +93,13 @@ class FluxKontextEditPipeline:
         self.text_encoder, self.text_encoder_2, self.tokenizer, self.tokenizer_2 = text_encoder, text_encoder_2, tokenizer, tokenizer_2
         self._engine = FluxKontextSamplingEngine(transformer, scheduler, guidance_scale=guidance_scale)
 
-    def encode_prompt(self, prompt=None, input_ids_t5=None, input_ids_clip=None, max_sequence_length=512):
-        """edit_ppo/pipeline.py:279-345: T5 last_hidden_state (512 tokens) + CLIP pooler_output"""
+    vae_scale_factor = 8
+
+    def encode_prompt(self, prompt=None, prompt_2=None, device=None, num_images_per_prompt=1, max_sequence_length=512,
+                      input_ids_t5=None, input_ids_clip=None, **_ignored):
+        """edit_ppo/pipeline.py:279-345 -> (prompt_embeds = T5 last_hidden_state [B, 512, 4096], pooled_prompt_embeds = CLIP
+        pooler_output [B, 768], text_ids zeros [512, 3]), the 3-tuple edit_ppo/denoise_diffusion.py:36-42 unpacks.  Token ids
+        (``input_ids_t5`` / ``input_ids_clip``) replace ``prompt`` when the tokenizers' asset files are not at hand."""
         dev = self.vae.device
         if input_ids_t5 is None or input_ids_clip is None:
             if prompt is None or self.tokenizer is None or self.tokenizer_2 is None:
@@ -108,7 +113,67 @@ class FluxKontextEditPipeline:
             raise RuntimeError("text encoders are not attached to this pipeline")
         pooled = self.text_encoder(input_ids_clip.to(dev)).pooler_output
         embeds = self.text_encoder_2(input_ids_t5.to(dev))[0]
-        return embeds, pooled
+        text_ids = torch.zeros(embeds.shape[1], 3, device=dev, dtype=embeds.dtype)
+        return embeds, pooled, text_ids
+
+    # ---- the FluxKontextPipeline members edit_ppo/denoise_diffusion.py drives (:45-66, :163-166) --------------------------------
+    @property
+    def image_processor(self):
+        pipe = self
+
+        class _Proc:
+            def preprocess(self, image):
+                """PIL image(s) -> [B, 3, 8S, 8S] in [-1, 1] (resized to the VAE's configured size); tensors pass through"""
+                if isinstance(image, torch.Tensor):
+                    return image
+                import numpy as np
+                from PIL import Image
+                S = pipe.vae.config.sample_size
+                ims = image if isinstance(image, (list, tuple)) else [image]
+                arr = [np.asarray(im.convert("RGB").resize((8 * S, 8 * S), Image.LANCZOS), dtype=np.uint8) for im in ims]
+                return torch.stack([torch.from_numpy(a.copy()).permute(2, 0, 1).float() / 255.0 * 2 - 1 for a in arr])
+
+            def postprocess(self, images, output_type="pil"):
+                """decoder output in [-1, 1] -> (x / 2 + 0.5).clamp(0, 1) -> PIL images ("pil") or the tensor ("pt")"""
+                x = (images.float() / 2 + 0.5).clamp(0, 1)
+                if output_type == "pt":
+                    return x
+                from PIL import Image
+                from .evaluation import tensor_to_uint8_hwc
+                return [Image.fromarray(tensor_to_uint8_hwc(img)) for img in x]
+        return _Proc()
+
+    @staticmethod
+    def _pack_latents(latents, batch_size=None, num_channels_latents=None, height=None, width=None):
+        from .flux import pack_latents
+        return pack_latents(latents)
+
+    @staticmethod
+    def _unpack_latents(latents, height, width, vae_scale_factor=8):
+        from .flux import unpack_latents
+        return unpack_latents(latents, height, width, vae_scale_factor)
+
+    def prepare_latents(self, image=None, batch_size=1, num_channels_latents=16, height=None, width=None, dtype=None, device=None,
+                        generator=None, latents=None):
+        """edit_ppo/pipeline.py:625-712: (latents, image_latents = packed VAE-encoded reference image, latent_ids, image_ids);
+        ``latents`` (packed noise) is taken as given, like the rollout passes it (edit_ppo/denoise_diffusion.py:52-62)."""
+        from .flux import pack_latents, prepare_latent_image_ids
+        from .vae import encode_image_latents
+        dev = device or self.vae.device
+        S = self.vae.config.sample_size
+        image_latents = image_ids = None
+        if image is not None:
+            img = image.to(dev, torch.float16)
+            if img.shape[0] == 1 and batch_size > 1:
+                img = img.expand(batch_size, -1, -1, -1)
+            image_latents = pack_latents(encode_image_latents(self.vae, img.contiguous())).to(dtype or torch.bfloat16)
+            image_ids = torch.from_numpy(prepare_latent_image_ids(S // 2, S // 2, first=1.0)).to(dev)
+        if latents is None:
+            noise = torch.randn(batch_size, self.vae.config.latent_channels, S, S, generator=generator,
+                                device=generator.device if generator is not None else dev).to(dev)
+            latents = pack_latents(noise).to(dtype or torch.bfloat16)
+        latent_ids = torch.from_numpy(prepare_latent_image_ids(S // 2, S // 2)).to(dev)
+        return latents, image_latents, latent_ids, image_ids
 
     @torch.no_grad()
     def __call__(self, image=None, prompt=None, num_inference_steps=28, guidance_scale=None, generator=None, prompt_embeds=None,
@@ -119,7 +184,7 @@ class FluxKontextEditPipeline:
         if guidance_scale is not None:
             self._engine.guidance_scale = float(guidance_scale)
         if prompt_embeds is None or pooled_prompt_embeds is None:
-            prompt_embeds, pooled_prompt_embeds = self.encode_prompt(prompt, input_ids_t5, input_ids_clip)
+            prompt_embeds, pooled_prompt_embeds, _ = self.encode_prompt(prompt, input_ids_t5=input_ids_t5, input_ids_clip=input_ids_clip)
         B = prompt_embeds.shape[0]
         image_latents = None
         if image is not None:

@@ -221,6 +221,15 @@ double cs_flux_flops(const CsFlux* f, int batch, int txt_len, int img_len);
 int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len, const void* encoder_hidden_states, int txt_len,
                     const float* pooled_f32, const float* timestep, const float* guidance, const float* rope_cos, const float* rope_sin,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
+/* The Kontext edit step (edit_ppo/pipeline.py:1080-1098, edit_ppo/denoise_diffusion.py:102,135-145) without the per-step
+ * `torch.cat([latents, image_latents], dim=1)` and without the `[:, :latents.size(1)]` slice copy: the image sequence is
+ * [latents [B, lat_len, C] | image_latents [B, image_len, C]] read from the two buffers in place, rope tables cover
+ * txt_len + lat_len + image_len tokens, workspace = cs_flux_workspace_bytes(f, batch, txt_len, lat_len + image_len),
+ * out [B, lat_len, C] = the prediction for the latent rows only.  image_len = 0: same as cs_flux_forward. */
+int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const void* image_latents, int image_len, int batch,
+                          const void* encoder_hidden_states, int txt_len, const float* pooled_f32, const float* timestep,
+                          const float* guidance, const float* rope_cos, const float* rope_sin, void* out, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * AutoencoderKL decoder (SD1.5 VAE): latents -> images.  Replaces

@@ -416,11 +416,86 @@ def gen_flux():
     print("flux fixtures written")
 
 
+def _ref_functions(path, names):
+    """exec the named top-level function definitions of a reference file that cannot be imported as a whole (it pulls in
+    the un-vendored diffusers package), from where the file lies -- nothing is copied into the repo."""
+    import ast, inspect, typing
+    import torch
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = dict(inspect=inspect, torch=torch, Optional=typing.Optional, Union=typing.Union, List=typing.List)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def gen_flux_rollout():
+    """edit_ppo/denoise_diffusion.denoise_diffusion (the FLUX PPO rollout, a18) driven with the closed-form stub pipe
+    (oracle/flux_stub_pipe.py): inputs, the forced action indices and the returned 6-tuple."""
+    sys.path.insert(0, HERE)
+    import types
+    import ref_stubs
+    ref_stubs.install("flux")
+    import torch
+    torch.set_num_threads(1)
+    # the module imports two helpers from diffusers' Kontext pipeline and the pipeline class (:6-7); the reference ships its
+    # own copies of both helpers in edit_ppo/pipeline.py:119-183 -- use those, executed from where they lie
+    calc, retr = _ref_functions(os.path.join(ref_stubs.REF_ROOT, "edit_ppo", "pipeline.py"), ["calculate_shift", "retrieve_timesteps"])
+    pk = types.ModuleType("diffusers.pipelines.flux.pipeline_flux_kontext")
+    pk.calculate_shift, pk.retrieve_timesteps = calc, retr
+    for name in ("diffusers.pipelines", "diffusers.pipelines.flux"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["diffusers.pipelines.flux.pipeline_flux_kontext"] = pk
+    sys.modules["diffusers"].FluxKontextPipeline = object
+    with ref_stubs.quiet():
+        from scheduler_fmppo import FMPPOScheduler
+        import denoise_diffusion as ref_dd
+    from flux_stub_pipe import StubKontextPipe
+
+    fr = {}
+    cases = [(2, 0, 0, 4, 1, 2.5), (3, 1, 0, 5, 2, 3.5)]          # order, scaler, mu_dim, n, B, guidance
+    fr["cases"] = np.asarray([[o, sc, mu, n, B] for o, sc, mu, n, B, _ in cases], np.int64)
+    for ci, (o, sc, mu, n, B, gs) in enumerate(cases):
+        with ref_stubs.quiet():
+            s = FMPPOScheduler(shift=3.0, use_dynamic_shifting=True, order_dim=o, scaler_dim=sc, mu_dim=mu,
+                               factor_net_kwargs=dict(hidden_dim=32, num_actions=11))
+        g = torch.Generator().manual_seed(4500 + ci)
+        with torch.no_grad():
+            for p in s.factor_net.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        for k, v in s.factor_net.state_dict().items():
+            fr[f"c{ci}_w_{k}"] = v.numpy().copy()
+        rng = np.random.default_rng(4600 + ci)
+        noise = torch.from_numpy(rng.standard_normal((B, 16, 8, 8)).astype(np.float32)).to(torch.bfloat16)
+        image = torch.from_numpy(np.tanh(rng.standard_normal((B, 3, 64, 64))).astype(np.float32))
+        text = ["make it red", "mi355x"][:B]
+        pipe = StubKontextPipe()
+        with ForcedMultinomial(torch, np.random.default_rng(4700 + ci)) as fm, ref_stubs.quiet():
+            lat, imgs, conds, probs, actions, masks = ref_dd.denoise_diffusion(
+                s, pipe, noise, text, image, cfg=gs, num_inference_steps=n)
+        fr[f"c{ci}_guidance"] = np.float32(gs)
+        fr[f"c{ci}_noise"] = noise.float().numpy()
+        fr[f"c{ci}_image"] = image.numpy()
+        fr[f"c{ci}_idx"] = np.stack([l.reshape(B, -1) for l in fm.log])
+        fr[f"c{ci}_sigmas"] = s.sigmas.numpy()
+        fr[f"c{ci}_timestep_seen"] = np.stack([t for _, t in pipe.transformer.calls])       # what the DiT was called with (t / 1000 in bf16)
+        fr[f"c{ci}_latents"] = lat.float().numpy()
+        fr[f"c{ci}_pred_images"] = imgs.float().numpy()
+        fr[f"c{ci}_conds_x"] = conds["x"].float().numpy()
+        fr[f"c{ci}_conds_eps"] = conds["epsilon"].float().numpy()
+        fr[f"c{ci}_probs"] = probs.float().numpy()
+        fr[f"c{ci}_actions"] = actions.float().numpy()
+        fr[f"c{ci}_masks"] = masks.float().numpy()
+    np.savez_compressed(os.path.join(OUT, "flux_rollout.npz"), **fr)
+    print("flux rollout fixtures written")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
-        {"sd": gen_sd, "flux": gen_flux}[sys.argv[1]]()
+        {"sd": gen_sd, "flux": gen_flux, "flux_rollout": gen_flux_rollout}[sys.argv[1]]()
     else:
-        for fl in ("sd", "flux"):
+        for fl in ("sd", "flux", "flux_rollout"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), fl])
         os.system(f"ls -la {OUT}")

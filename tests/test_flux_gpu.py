@@ -324,3 +324,117 @@ def test_attention_dh128_outlier_key_takes_the_safe_path(dt, code, mult, tol):
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 128 ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, S, H * 128)
     assert torch.isfinite(o).all()
     assert rel_l2(o.float(), ref) < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a18: the FLUX PPO rollout function (edit_ppo/denoise_diffusion.py:11-176)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _close_bf16(got, want, what):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    err = float(np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want.astype(np.float64)), 1e-30))
+    assert got.shape == want.shape and err < 2e-3 and np.mean(got != want) < 0.02, (what, err, float(np.mean(got != want)))
+
+
+def test_flux_rollout_function_vs_reference_golden(golden):
+    """rollout_flux.denoise_diffusion driven with the SAME closed-form stub pipe the imported reference function was driven with
+    (oracle/make_golden.py flux_rollout): the 6-tuple (latents, pred_images, conds{x, epsilon}, probs, actions, masks)."""
+    from consolver_amd.rollout_flux import denoise_diffusion
+    from oracle.flux_stub_pipe import StubKontextPipe
+    g = golden["flux_rollout"]
+    for ci, (o, sc, mu, n, B) in enumerate(g["cases"]):
+        o, sc, mu, n, B = int(o), int(sc), int(mu), int(n), int(B)
+        s = consolver_amd.FMPPOScheduler(shift=3.0, use_dynamic_shifting=True, order_dim=o, scaler_dim=sc, mu_dim=mu,
+                                         factor_net_kwargs=dict(hidden_dim=32, num_actions=11))
+        s.factor_net.load_state_dict({k[len(f"c{ci}_w_"):]: torch.from_numpy(np.asarray(g[k])) for k in g.files if k.startswith(f"c{ci}_w_")})
+        s.factor_net.to(DEV)
+        s.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in g[f"c{ci}_idx"]]
+        pipe = StubKontextPipe()
+        noise = torch.from_numpy(g[f"c{ci}_noise"]).to(torch.bfloat16).to(DEV)
+        image = torch.from_numpy(g[f"c{ci}_image"]).to(DEV)
+        out = denoise_diffusion(s, pipe, noise, ["make it red", "mi355x"][:B], image, cfg=float(g[f"c{ci}_guidance"]), num_inference_steps=n)
+        lat, imgs, conds, probs, actions, masks = out
+        assert lat.dtype == torch.bfloat16 and lat.shape == (B, 16, 64)
+        np.testing.assert_allclose(s.sigmas.cpu().numpy(), g[f"c{ci}_sigmas"], rtol=2e-7)
+        np.testing.assert_array_equal(np.stack([t for _, t in pipe.transformer.calls]), g[f"c{ci}_timestep_seen"])
+        assert all(S == 32 for S, _ in pipe.transformer.calls)                 # [latents | image_latents] every step
+        np.testing.assert_array_equal(conds["x"].float().cpu().numpy(), g[f"c{ci}_conds_x"])
+        np.testing.assert_array_equal(actions.cpu().numpy(), g[f"c{ci}_actions"])
+        np.testing.assert_array_equal(masks.cpu().numpy(), g[f"c{ci}_masks"])
+        np.testing.assert_allclose(probs.cpu().numpy(), g[f"c{ci}_probs"], rtol=5e-3, atol=2e-5)
+        _close_bf16(conds["epsilon"].float().cpu().numpy(), g[f"c{ci}_conds_eps"], "conds.epsilon")
+        _close_bf16(lat.float().cpu().numpy(), g[f"c{ci}_latents"], "latents")
+        _close_bf16(imgs.float().cpu().numpy(), g[f"c{ci}_pred_images"], "pred_images")
+        # use_naive_scheduler returns the 2-tuple (:175-176)
+        s.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in g[f"c{ci}_idx"]]
+        two = denoise_diffusion(s, pipe, noise, ["make it red", "mi355x"][:B], image, cfg=float(g[f"c{ci}_guidance"]), num_inference_steps=n,
+                                use_naive_scheduler=True)
+        assert len(two) == 2 and torch.equal(two[0], lat)
+
+
+@pytest.mark.timeout(900)
+def test_flux_rollout_on_hip_components_vs_oracle():
+    """the same function on the HIP pipeline (reduced DiT, reduced FLUX VAE with its encoder): latents + records against
+    FluxOracle (fp32 CPU) inside the oracle's rollout loop with the same replayed action indices; and the in-place joint input
+    (image_latents=) equals the reference's cat([latents, image_latents], 1) ... [:, :L] bit for bit."""
+    from consolver_amd.pipeline import FluxKontextEditPipeline
+    from consolver_amd.rollout_flux import denoise_diffusion
+    from consolver_amd.vae import HipAutoencoderKL, FLUX_VAE_CONFIG
+    from consolver_amd.synth import synthetic_vae_state_dict
+    from oracle import solver_oracle as so
+    cfg = dict(SMALL, dtype=torch.bfloat16)
+    m = HipFluxTransformer2DModel(cfg, device=DEV)
+    sd = synthetic_flux_state_dict(m.manifest(), seed=4)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    o, n, B, gs = 2, 4, 2, 2.5
+    sch = consolver_amd.FMPPOScheduler.from_pretrained("x", subfolder="scheduler", order_dim=o, scaler_dim=0, mu_dim=0,
+                                                       factor_net_kwargs=dict(hidden_dim=64, num_actions=11))
+    w = {k: v.numpy().copy() for k, v in sch.factor_net.state_dict().items()}
+    sch.factor_net.to(DEV)
+    vcfg = dict(FLUX_VAE_CONFIG); vcfg.update(layers_per_block=1, sample_size=16, with_encoder=True)
+    vae = HipAutoencoderKL(vcfg, device=DEV)
+    vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=9))
+    pipe = FluxKontextEditPipeline(m, sch, vae)
+    g = torch.Generator().manual_seed(7)
+    noise = torch.randn(B, 16, 16, 16, generator=g).to(torch.bfloat16).to(DEV)
+    image = torch.tanh(torch.randn(B, 3, 128, 128, generator=g)).to(DEV)
+    pe = torch.randn(B, 64, 256, generator=g).to(torch.bfloat16).to(DEV)
+    pooled = torch.randn(B, 768, generator=g).to(torch.bfloat16).to(DEV)
+    idx = np.random.default_rng(3).integers(0, 11, size=(n, B, 1))
+    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+    text = {"prompt_embeds": pe, "pooled_prompt_embeds": pooled}
+    lat, imgs, conds, probs, actions, masks = denoise_diffusion(sch, pipe, noise, text, image, cfg=gs, num_inference_steps=n)
+    assert lat.shape == (B, 64, 64) and lat.dtype == torch.bfloat16 and len(imgs) == B and imgs[0].size == (128, 128)
+    assert conds["x"].shape == (B, n - 1, 2) and conds["epsilon"].shape == (B, n - 1, o, 64, 64)
+    assert probs.shape == actions.shape == masks.shape == (B, n - 1, 1)
+
+    # ---- oracle: FluxOracle as the velocity model of the restated loop
+    packed, il, lat_ids, img_ids = pipe.prepare_latents(image=image, batch_size=B, dtype=torch.bfloat16, device=torch.device(DEV),
+                                                        latents=pipe._pack_latents(noise))
+    ids = torch.cat([lat_ids, img_ids]).float().cpu().numpy()
+    txt_ids = np.zeros((pe.shape[1], 3), np.float32)
+    orc = FluxOracle(sd, m.config)
+    torch.set_num_threads(16)
+    guidance = torch.full((B,), gs)
+
+    def v_model(h, ts):
+        return orc(torch.from_numpy(h), torch.from_numpy(ts), guidance, pooled.float().cpu(), pe.float().cpu(), txt_ids, ids).numpy()
+
+    s_or = so.FMPPOSchedulerOracle(shift=3.0, use_dynamic_shifting=True, order_dim=o, scaler_dim=0, mu_dim=0, num_actions=11, weights=w)
+    lat_o, conds_o, probs_o, actions_o, masks_o, _ = so.flux_rollout(s_or, v_model, packed.float().cpu().numpy(), il.float().cpu().numpy(),
+                                                                    n, idx, io_dtype="bf16")
+    np.testing.assert_array_equal(conds["x"].float().cpu().numpy(), conds_o["x"])
+    np.testing.assert_array_equal(actions.cpu().numpy(), actions_o)
+    np.testing.assert_array_equal(masks.cpu().numpy(), masks_o)
+    np.testing.assert_allclose(probs.cpu().numpy(), probs_o, rtol=5e-3, atol=2e-5)
+    e_lat = rel_l2(lat.float(), torch.from_numpy(lat_o))
+    e_eps = rel_l2(conds["epsilon"].float(), torch.from_numpy(conds_o["epsilon"]))
+    print("flux rollout (reduced DiT, bf16) vs oracle: latents", e_lat, "conds.epsilon", e_eps)
+    assert e_lat < 2e-2 and e_eps < 3e-2, (e_lat, e_eps)          # the bf16 DiT's own tolerance (test_reduced_flux_dit_matches_oracle: 3e-2)
+
+    # ---- in-place joint input == materialised cat + slice
+    t = torch.full((B,), 0.9567, device=DEV)
+    kw = dict(guidance=guidance.to(DEV), pooled_projections=pooled, encoder_hidden_states=pe, txt_ids=txt_ids, img_ids=ids)
+    a = m(packed, t, image_latents=il, **kw)[0]
+    b = m(torch.cat([packed, il], 1), t, **kw)[0][:, :packed.shape[1]]
+    assert a.shape == packed.shape and torch.equal(a, b)

@@ -283,3 +283,41 @@ def test_t5_encoder_oracle_vs_transformers(golden):
     for name in ("short", "long"):
         out = orc(torch.from_numpy(np.asarray(g[f"{name}_ids"])))[0].numpy()
         assert rel_l2(out, g[f"{name}_out"]) < 3e-6
+
+
+def test_flux_rollout_records(golden):
+    """a18: the oracle's restatement of the FLUX rollout loop against the 6-tuple the IMPORTED reference function
+    (edit_ppo/denoise_diffusion.py:11-176) returned for the closed-form stub pipe (oracle/flux_stub_pipe.py)."""
+    import torch
+    from oracle.flux_stub_pipe import StubKontextPipe, velocity_np
+    g = golden["flux_rollout"]
+    for ci, (o, sc, mu, n, B) in enumerate(g["cases"]):
+        o, sc, mu, n, B = int(o), int(sc), int(mu), int(n), int(B)
+        gs = float(g[f"c{ci}_guidance"])
+        pipe = StubKontextPipe()
+        text = ["make it red", "mi355x"][:B]
+        pe, pooled, _ = pipe.encode_prompt(prompt=text, device="cpu")
+        noise = torch.from_numpy(g[f"c{ci}_noise"]).to(torch.bfloat16)
+        packed = pipe._pack_latents(noise, B, 16, 0, 0)
+        _, il, lat_ids, img_ids = pipe.prepare_latents(image=torch.from_numpy(g[f"c{ci}_image"]), batch_size=B, dtype=torch.bfloat16,
+                                                       device="cpu", latents=packed)
+        ids = torch.cat([lat_ids, img_ids]).float().numpy()
+        sch = so.FMPPOSchedulerOracle(shift=3.0, use_dynamic_shifting=True, order_dim=o, scaler_dim=sc, mu_dim=mu,
+                                      num_actions=11, weights=weights(g, f"c{ci}_w_"))
+        guidance = np.full((B,), gs, np.float32)
+
+        def v_model(h, ts):
+            return velocity_np(h, ts, guidance, pooled.float().numpy(), pe.float().numpy(), ids)
+
+        lat, conds, probs, actions, masks, seen = so.flux_rollout(sch, v_model, packed.float().numpy(), il.float().numpy(), n,
+                                                                  g[f"c{ci}_idx"], io_dtype="bf16")
+        np.testing.assert_allclose(sch.sigmas, g[f"c{ci}_sigmas"], rtol=2e-7)
+        np.testing.assert_array_equal(seen, g[f"c{ci}_timestep_seen"])            # t.to(bf16) / 1000 in bf16
+        np.testing.assert_array_equal(conds["x"], g[f"c{ci}_conds_x"])
+        np.testing.assert_array_equal(actions, g[f"c{ci}_actions"])
+        np.testing.assert_array_equal(masks, g[f"c{ci}_masks"])
+        np.testing.assert_allclose(probs, g[f"c{ci}_probs"], rtol=5e-3, atol=2e-5)
+        assert conds["epsilon"].shape == g[f"c{ci}_conds_eps"].shape == (B, n - 1, o, 16, 64)
+        # bf16 trajectories: equal up to 1 bf16 ulp on a small fraction of elements (tanh / reduction order of the stub DiT)
+        for got, want in ((conds["epsilon"], g[f"c{ci}_conds_eps"]), (lat, g[f"c{ci}_latents"])):
+            assert rel_l2(got, want) < 2e-3 and np.mean(got != want) < 0.02, (ci, rel_l2(got, want), np.mean(got != want))

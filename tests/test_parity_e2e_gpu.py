@@ -340,7 +340,9 @@ def test_fmppo_fp32_sample_is_consumed_as_fp32():
     out = s.step(v.to(DEV), s.timesteps[0], x.to(DEV), return_dict=False)[0]
     assert out.dtype == torch.bfloat16
     dt = np.float32(s._sigmas[1] - s._sigmas[0])
-    want = (x + float(dt) * v.float()).bfloat16()                   # m = 1: v_eff = v
-    rounded_in = (x.bfloat16().float() + float(dt) * v.float()).bfloat16()
+    step = torch.tensor(dt) * v                                     # m = 1: v_eff = v (bf16) and 0-d fp32 dt -> a bf16 product (:429)
+    assert step.dtype == torch.bfloat16
+    want = (x + step).bfloat16()
+    rounded_in = (x.bfloat16().float() + step.float()).bfloat16()
     assert torch.equal(out.cpu(), want)
     assert not torch.equal(want, rounded_in)                        # the case distinguishes the two behaviours
