@@ -87,6 +87,173 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
     return out
 
 
+PEAK_HBM_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured float4 copy)
+
+
+def _timed_ms(fn, iters, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        out = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters, out
+
+
+def extra_four_step(eng, unet, pe, ne, noise, guidance, iters):
+    """configs[2]'s per-GPU shape: 4-step generation, batch 16, CFG 3 (gen_ppo.py path; 128 prompts over 8 GPUs)."""
+    B = noise.shape[0]
+    ms, out = _timed_ms(lambda: eng.generate(pe, ne, latents=noise, num_inference_steps=4), iters)
+    tf = unet.flops(2 * B) * 4 / (ms * 1e-3) / 1e12
+    return {"workload": "configs[2] per-GPU shape: SD1.5 + PPOScheduler 4-step CFG 3, batch 16", "ms_per_generation": ms,
+            "images_per_s": B / (ms * 1e-3), "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS, "finite": bool(torch.isfinite(out).all())}
+
+
+def extra_solver(dev, sch):
+    """the fused solver-update kernel K1 (CFG combine + coefficient fix-up + LMS combine + DDIM, one pass) and the policy MLP (K2).
+    K1 bytes per step: [x] + [eps_u, eps_c] + [m-1 history] + [x'] + [eps store] passes of B x 32 KiB."""
+    import ctypes as C
+    from consolver_amd import _lib as L
+    lib = L.lib()
+
+    def k1(B, iters):
+        t = lambda: torch.randn(B, 16384, device=dev).half()
+        x, eu, ec, out, eo, h1, h2, h3 = (t() for _ in range(8))
+        actions = torch.rand(B, 3, device=dev)
+        a = L.CsStepArgs()
+        a.x, a.eps_text, a.eps_uncond, a.guidance = x.data_ptr(), ec.data_ptr(), eu.data_ptr(), 3.0
+        for k, h in enumerate((h1, h2, h3)):
+            a.hist[k] = h.data_ptr()
+        a.m, a.order_dim, a.scaler_dim = 4, 4, 0
+        a.actions, a.actions_stride, a.B, a.elems = actions.data_ptr(), 3, B, 16384
+        a.io_dtype = a.out_dtype = L.dtype_code(torch.float16)
+        a.x_out, a.eps_out = out.data_ptr(), eo.data_ptr()
+        a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = 0.3, 0.95, 0.5, 0.86
+        st = L.stream_ptr(dev)
+        ms, _ = _timed_ms(lambda: L.check(lib.cs_lms_ddim_step(C.byref(a), st)), iters, warm=3)
+        nbytes = 8 * B * 16384 * 2
+        return ms * 1e3, nbytes / (ms * 1e-3) / 1e9
+    us16, gb16 = k1(16, 200)
+    us4k, gb4k = k1(4096, 20)
+    row = torch.tensor([[874.0, 749.0]], device=dev)
+    net = sch.factor_net
+    pol_ms, _ = _timed_ms(lambda: net.probs_from(row, batch=16), 200, warm=5)
+    return {"k1_us_at_batch16": us16, "k1_gbps_at_batch16": gb16, "k1_us_at_1GB": us4k, "k1_gbps_at_1GB": gb4k,
+            "k1_frac_of_hbm_peak_at_1GB": gb4k / PEAK_HBM_GBPS, "k1_note": "fp16, order 4 steady state, CFG: 8 tensor passes per step; "
+            "batch 16 (4.2 MB) is launch-latency bound, the 1 GB working set is what the kernel sustains when HBM-bound",
+            "policy_mlp_us_at_batch16": pol_ms * 1e3, "policy_note": "cs_factor_probs, hidden 256, one conditioning row broadcast to 16 samples; "
+            "wall per call incl. the host launch path (back-to-back launches)"}
+
+
+def extra_rollout(unet, vae, dev, B=80, n=8, epochs=4, iters=2):
+    """configs[4] on one GPU: one PPO trainer iteration (train_ppo.py:322-437) = B trajectories x n steps (CFG 3 -> UNet batch 2B),
+    decode of the B predictions + B teacher latents, image-PSNR reward, advantages, `epochs` policy updates."""
+    import consolver_amd
+    from consolver_amd import ppo
+    from consolver_amd.synth import synthetic_prompt_embeds
+    sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
+                                     order_dim=4, scaler_dim=0, factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=11))
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in sch.factor_net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sch.factor_net.to(dev)
+    tr = ppo.PolicyTrainer(sch.factor_net, lr=1e-4)
+    pe = synthetic_prompt_embeds(1, seed=1001).half().to(dev).repeat(B, 1, 1)
+    ne = synthetic_prompt_embeds(1, seed=1002).half().to(dev).repeat(B, 1, 1)
+    batch = (["p"] * B, torch.randn(1, 4, 64, 64, generator=g).half().to(dev).repeat(B, 1, 1, 1),
+             (torch.randn(1, 4, 64, 64, generator=g) * 0.18).half().to(dev).repeat(B, 1, 1, 1))
+    ms, out = _timed_ms(lambda: ppo.train_iteration(tr, None, sch, unet, vae, batch, None, cfg=3.0, num_inference_steps=n, ppo_epochs=epochs,
+                                                    prompt_embeds=pe, negative_prompt_embeds=ne), iters)
+    fl = unet.flops(2 * B) * n + vae.flops(8) * (2 * B / 8)
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"workload": f"configs[4] on 1 GPU: PPO rollout B={B}, {n} steps, CFG 3, 2x{B} VAE decodes, image_psnr reward, {epochs} PPO epochs",
+            "ms_per_iteration": ms, "trajectories_per_s": B / (ms * 1e-3), "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS,
+            "loss_finite": bool(torch.isfinite(torch.as_tensor(float(out["loss"]))))}
+
+
+def extra_flux(dev, n=8):
+    """configs[3]: full FLUX.1-Kontext DiT (19 + 38 blocks, 11.9 B synthetic bf16 parameters generated on the GPU) + FMPPOScheduler,
+    8-step 1024x1024 edit, batch 1; finiteness + run-to-run determinism of the full-size edit (fixed action indices)."""
+    import consolver_amd
+    from consolver_amd.flux import HipFluxTransformer2DModel, FluxKontextSamplingEngine, pack_latents
+    m = HipFluxTransformer2DModel(device=dev)
+    g = torch.Generator(device=dev).manual_seed(20251226)
+    nparams = 0
+    for name, shape in m.manifest():
+        if name.endswith(("norm_q.weight", "norm_k.weight", "norm_added_q.weight", "norm_added_k.weight")):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g, device=dev)
+        elif name.endswith(".weight"):
+            w = torch.randn(shape, generator=g, device=dev) * (1.0 / shape[1]) ** 0.5
+            if ".norm" in name and name.endswith("linear.weight"):
+                w = w * 0.5
+        else:
+            w = 0.05 * torch.randn(shape, generator=g, device=dev)
+            if ".norm" in name and name.endswith("linear.bias"):
+                w = w + 0.3
+        nparams += w.numel()
+        m.set_weight(name, w)
+        del w
+    m.finalize()
+    B, T, Lq = 1, 512, 4096
+    sch = consolver_amd.FMPPOScheduler.from_pretrained("black-forest-labs/FLUX.1-Kontext-dev", subfolder="scheduler", order_dim=2, scaler_dim=0,
+                                                       mu_dim=0, factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=11))
+    sch.factor_net.to(dev)
+    sch.factor_net.forced_action_idx = torch.full((B, 1), 3, dtype=torch.long, device=dev)      # fixed policy draw: determinism check
+    gc = torch.Generator().manual_seed(43)
+    lat = pack_latents(torch.randn(B, 16, 128, 128, generator=gc)).to(torch.bfloat16).to(dev)
+    img = pack_latents(torch.randn(B, 16, 128, 128, generator=gc)).to(torch.bfloat16).to(dev)
+    enc = torch.nn.functional.layer_norm(torch.randn(B, T, 4096, generator=gc), (4096,)).to(torch.bfloat16).to(dev)
+    pooled = torch.randn(B, 768, generator=gc).to(torch.bfloat16).to(dev)
+    eng = FluxKontextSamplingEngine(m, sch, guidance_scale=2.5)
+    first = eng.generate(lat, img, enc, pooled, latent_hw=(64, 64), num_inference_steps=n).clone()       # warm-up, sizes the workspace
+    ms, out = _timed_ms(lambda: eng.generate(lat, img, enc, pooled, latent_hw=(64, 64), num_inference_steps=n), 2, warm=0)
+    fl = m.flops(B, T, 2 * Lq)
+    tf = fl * n / (ms * 1e-3) / 1e12
+    rec = {"workload": "configs[3]: FLUX-Kontext + scheduler_fmppo 8-step bf16, 1024x1024 edit on 1 MI355X", "params_B": nparams / 1e9,
+           "ms_per_edit": ms, "edits_per_s": 1e3 / ms, "tflop_per_forward": fl / 1e12, "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS,
+           "dtype": "bf16", "finite": bool(torch.isfinite(out.float()).all()), "deterministic": bool(torch.equal(out, first))}
+    del m, eng, lat, img, enc, pooled, first, out
+    torch.cuda.empty_cache()
+    return rec
+
+
+def dry_run(args):
+    """`--dry-run`: everything bench.py does around the GPU work and nothing on a GPU -- the rendezvous (gloo instead of RCCL), the shard
+    bounds, the start barrier, the max-over-ranks reduction and the one JSON line -- so that the N > 1 launch path can be exercised in the
+    CPU-only build container (tests/test_launch_cpu.py).  No CUDA call is made."""
+    from consolver_amd.launch import shard_bounds
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    lo, hi = shard_bounds(B * world, world, rank)
+    if dist is not None:
+        dist.barrier()
+    elapsed = 0.001 * (rank + 1)                      # stand-in for this rank's timed region
+    bounds = [[lo, hi]]
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        all_b = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(all_b, torch.tensor([lo, hi], dtype=torch.int64))
+        bounds = [b.tolist() for b in all_b]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "images": B * world * args.steps, "max_elapsed_s": elapsed, "shards": bounds,
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "cuda_initialised": torch.cuda.is_initialized()}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +267,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ceilings", type=int, default=1, help="1: also measure the vendor 8192^3 fp16 GEMM and a 1 GiB device copy on this box")
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
+    ap.add_argument("--extras", type=int, default=1, help="1 (N = 1 only): also measure configs[2] per-GPU shape, configs[3] (full FLUX edit), "
+                    "configs[4] (PPO rollout iteration) and the solver kernels, reported as sub-records of the same JSON line")
+    ap.add_argument("--dry-run", action="store_true", help="exercise the launch / rendezvous / sharding / reduction path without touching a GPU")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -110,6 +280,8 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
+    if args.dry_run:
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world and rank == 0:
@@ -261,6 +433,19 @@ def main():
                     "note": "torch.matmul (hipBLASLt/rocBLAS) 8192^3 fp16 and a 1 GiB device copy (read + write bytes) on this box, random data"}
         del ga, gb, gc, src, dst
 
+    # ---- the other configurations of BASELINE.json, measured in the same driver-run process (sub-records; N = 1 only) -------------
+    extras = None
+    if rank == 0 and world == 1 and args.extras:
+        extras = {}
+        for name, fn in (("four_step", lambda: extra_four_step(eng, unet, pe, ne, noise, args.guidance, max(2, args.steps))),
+                         ("solver_k1", lambda: extra_solver(dev, sch)),
+                         ("rollout_iteration", lambda: extra_rollout(unet, vae, dev) if vae is not None else None),
+                         ("flux_edit", lambda: extra_flux(dev))):
+            try:
+                extras[name] = fn()
+            except Exception as e:                      # a failing extra must not take the headline line down with it
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         images = B * world * args.steps
         rec = {
@@ -279,6 +464,8 @@ def main():
                                  "frac_of_mfma_peak": vae.flops(B) / (decode_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS}
         if kernels:
             rec["roofline_kernels"] = kernels
+        if extras:
+            rec.update({k: v for k, v in extras.items() if v is not None})
         if ceilings:
             rec["ceilings"] = ceilings
             rec["roofline"]["frac_of_vendor_gemm"] = achieved / ceilings["vendor_gemm_f16_8192_tflops"]

@@ -193,7 +193,7 @@ def test_bench_prints_one_contract_line():
     """bench.py (N = 1, short) prints ONE JSON line with the driver's keys plus roofline / ceilings / cpu_baseline objects"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--decode", "0",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--decode", "0", "--extras", "0",
                         "--no-cpu-baseline", "--profile-kernels", "0"], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

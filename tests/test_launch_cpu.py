@@ -68,3 +68,84 @@ def test_two_process_gloo_launch(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").read_text() == "ok" and (tmp_path / "rank1.ok").read_text() == "ok"
+
+
+def test_bench_launcher_branch_dry_run():
+    """`python bench.py --gpus 2 --dry-run`: bench.py's own child-launch branch (torch.distributed.run, one process per rank, 127.0.0.1
+    rendezvous) + sharding + start barrier + max-over-ranks reduction + the single JSON line from rank 0, with gloo in place of RCCL and no
+    CUDA call (the scaling curve itself has never been measured: the driver owns the 8-GPU node)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # exactly ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] and rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["shards"] == [[0, 16], [16, 32]] and rec["images"] == 16 * 2 * 3
+    assert rec["max_elapsed_s"] == 0.002                  # MAX over ranks (rank 1 reported the larger time)
+    assert rec["cuda_initialised"] is False
+    # N = 1 takes the in-process path (no launcher)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    rec1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert rec1["n_gpus"] == 1 and rec1["shards"] == [[0, 16]]
+
+
+GEN_WORKER = r'''
+import os, sys, types, torch
+sys.path.insert(0, %r)
+from consolver_amd import generate as gen, launch
+rank, world, local, dist = launch.init_distributed("gloo")
+out = sys.argv[1]
+N, bs, seed = 11, 3, 43
+prompts = [f"prompt {i}" for i in range(N)]
+pe = torch.arange(N, dtype=torch.float32).view(N, 1, 1).repeat(1, 2, 4)          # prompt i is recognisable from its embedding
+ne = torch.zeros_like(pe)
+
+class Engine:                                   # stands in for SDSamplingEngine: image = f(prompt embedding, noise), no GPU
+    unet = types.SimpleNamespace(config=dict(in_channels=4, sample_size=8))
+    def generate(self, pe, ne, latents=None, num_inference_steps=8, use_graph=False, output_type="pt"):
+        B = pe.shape[0]
+        img = torch.zeros(B, 3, 16, 16)
+        img[:, 0] = pe[:, 0, 0].view(B, 1, 1) / 16.0                                # red channel = global prompt index / 16
+        img[:, 1] = torch.sigmoid(latents.float().mean(dim=(1, 2, 3))).view(B, 1, 1)  # green = a function of the batch's noise
+        return img
+
+dist.barrier()
+n = gen.generate_imgs(out, prompts, pe, ne, Engine(), 8, rank, world, seed, batch_size=bs, device=torch.device("cpu"))
+rep = launch.gather_report(dist, n, 0.0)
+assert [c for c, _ in rep] == [5, 6], rep
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_generate_writes_rank_indexed_files(tmp_path):
+    """consolver_amd.generate's rank logic (gen_ppo.py:333-379) in two real processes (gloo): shard rule, ragged last batch, per-batch seed
+    `seed + batch_idx` identical on both ranks, `{rank}_{idx:08d}.png/.txt` naming, and that each file holds ITS prompt's image."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from consolver_amd import generate as gen
+    script = tmp_path / "gen_worker.py"
+    script.write_text(GEN_WORKER % ROOT)
+    out = tmp_path / "generation"
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, str(script), str(out)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    names = sorted(f for f in os.listdir(out) if f.endswith(".png"))
+    assert names == [f"0_{i:08d}.png" for i in range(5)] + [f"1_{i:08d}.png" for i in range(6)]
+    for rank, lo, cnt in ((0, 0, 5), (1, 5, 6)):
+        for i in range(cnt):
+            assert open(out / f"{rank}_{i:08d}.txt").read() == f"prompt {lo + i}"
+            px = np.asarray(Image.open(out / f"{rank}_{i:08d}.png").convert("RGB"))
+            assert px[0, 0, 0] == round((lo + i) / 16.0 * 255)                 # the image generated FOR that prompt
+            # green encodes the batch noise: seed + batch_idx with batch_idx LOCAL to the rank, so both ranks share seeds 43, 44
+            noise = gen.prepare_latents(min(3, cnt - (i // 3) * 3), (4, 8, 8), 43 + i // 3, torch.device("cpu"))
+            want = torch.sigmoid(noise.float().mean(dim=(1, 2, 3)))[i % 3]
+            assert abs(int(px[0, 0, 1]) - round(float(want) * 255)) <= 1
