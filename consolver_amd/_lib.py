@@ -119,6 +119,7 @@ SYMBOLS = {
     "cs_unet_finalize": (C.c_int, [C.c_void_p]),
     "cs_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "cs_unet_flops": (C.c_double, [C.c_void_p, C.c_int]),
+    "cs_unet_flops_executed": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
     "cs_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cs_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

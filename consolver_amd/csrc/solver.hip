@@ -447,7 +447,7 @@ int cs_factor_probs(const CsFactorNet* n, const float* x, int x_row_stride, cons
     // one broadcast conditioning row and no per-sample features: evaluate once, write B rows
     const bool bcast = (x_row_stride == 0 && n->in_dim == 2 && B > 1);
     const int threads = n->hidden >= 128 ? 1024 : 256;
-    hipLaunchKernelGGL(factor_probs_kernel, dim3(bcast ? 1 : B), dim3(bcast ? threads : 256), lds, (hipStream_t)stream, *n, x,
+    hipLaunchKernelGGL(factor_probs_kernel, dim3(bcast ? 1 : B), dim3(threads), lds, (hipStream_t)stream, *n, x,
                        x_row_stride, cos_feat, probs, bcast ? B : 1);
     CS_CHECK_LAUNCH();
     return CS_OK;

@@ -24,6 +24,8 @@
 #include <cstring>
 #include <cmath>
 
+int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
+
 namespace {
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<f16> data; };
@@ -380,11 +382,68 @@ struct Run {
     }
 };
 
+// ---- CFG dual batch, shared prefix --------------------------------------------------------------------------------------
+// With classifier-free guidance the two halves of the batch (unconditional | text, gen_pretrain/pipeline.py:1054) carry the SAME
+// latents and the same timestep; they differ only in the text context, which first enters at the cross-attention of the first
+// transformer block.  Everything before that point -- conv_in, the first resnet, and GroupNorm / proj_in / LayerNorm / QKV /
+// self-attention / to_out / LayerNorm2 / to_q of the first transformer block -- is the same function of the same inputs for sample
+// b and sample b + n_lat, so it is computed once at batch n_lat and the residual stream is duplicated right before the two halves
+// diverge.  Bit-identical to running the full batch (the kernels are batch-independent per sample); ~1/32 of the forward's FLOPs are
+// not executed.  `xformer_cfg_shared` is `xformer` with that split.
+f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, int W, int n_lat);
+
 size_t kv_cache_bytes(const CsUNet* u, int B) { return ((u->kv_halfs_per_token * (size_t)B * u->cfg.ctx_len * sizeof(f16)) + 255) & ~(size_t)255; }
 size_t sk_ws_bytes(const CsUNet*, int B) { return ((size_t)B * (8u << 20)) + (16u << 20); }
 size_t gn_ws_bytes(const CsUNet* u, int B) {
     const int cmax = 2 * u->cfg.block_out_channels[3];
     return (((size_t)B * (GN_SPLITS + 1) * cmax * 2 * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, int W, int n_lat) {
+    CsUNet* u = R.u;
+    const int C = X.c, HW = H * W, L = u->cfg.ctx_len;
+    const int Bfull = R.B, M1 = n_lat * HW, M = Bfull * HW;
+    // ---- shared part at batch n_lat ----
+    R.B = n_lat;
+    f16* g1 = R.alloc((size_t)M1 * C);
+    R.group_norm(X.gn, x_half, C, nullptr, 0, HW, false, g1);
+    f16* h1 = R.alloc((size_t)M1 * C);
+    R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, nullptr, h1);
+    R.layer_norm(X.ln1, h1, M1, g1);
+    f16* qkv = R.alloc((size_t)M1 * 3 * C);
+    R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, nullptr, qkv, 0);
+    R.attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g1, C, HW, HW, C);
+    R.release(qkv);
+    R.linear(g1, M1, C, X.wo1, X.bo1, C, h1, h1, 0);
+    R.layer_norm(X.ln2, h1, M1, g1);
+    f16* q = R.alloc((size_t)M1 * C);
+    R.linear(g1, M1, C, X.wq2, nullptr, C, nullptr, q, 0);
+    R.release(g1);
+    // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
+    f16* h = R.alloc((size_t)M * C);
+    f16* g = R.alloc((size_t)M * C);
+    const f16* kvl = R.kv + X.kv_off * (size_t)Bfull * L;
+    for (int half = 0; half < 2; ++half) {
+        if (!R.dry && R.rc == CS_OK)
+            hipMemcpyAsync(h + (size_t)half * M1 * C, h1, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+        const f16* kvh = kvl + (size_t)half * n_lat * L * 2 * C;
+        R.attention(true, q, C, kvh, 2 * C, kvh + C, 2 * C, g + (size_t)half * M1 * C, C, HW, L, C);
+    }
+    R.release(q); R.release(h1);
+    R.B = Bfull;
+    R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
+    R.layer_norm(X.ln3, h, M, g);
+    f16* ff = R.alloc((size_t)M * 4 * C);
+    R.linear(g, M, C, X.wff1, X.bff1, 8 * C, nullptr, ff, 1);
+    R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, h, 0);
+    R.release(ff);
+    // proj_out + residual with the block input, which exists once: one launch per half
+    R.B = n_lat;
+    for (int half = 0; half < 2; ++half)
+        R.conv(X.proj_out, h + (size_t)half * M1 * C, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x_half, g + (size_t)half * M1 * C);
+    R.B = Bfull;
+    R.release(h);
+    return g;
 }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
@@ -425,11 +484,23 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     R.launch(P_MISC, 2.0 * B * H * W * 9.0 * c.in_channels * c0, 2.0 * B * H * W * c0, [&] { return launch_conv_in(latents, n_lat, B, c.in_channels, H, W, u->conv_in.w, u->conv_in.b, c0, h, s); });
     int ch = c0;
     skips.push_back({h, ch});
+    // CFG dual batch with one timestep: the first resnet and the first transformer block up to its cross attention are shared
+    const bool share = (dup == 2 && nt == 1 && c.down_has_attn[0] && g_tune_cfg_share != 0 && !u->down_res[0].empty());
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->down_res[i].size(); ++j) {
-            f16* r = R.resnet(u->down_res[i][j], h, ch, nullptr, 0, H, W);
-            ch = u->down_res[i][j].cout;
-            if (c.down_has_attn[i]) { f16* a = R.xformer(u->down_att[i][j], r, H, W); R.release(r); r = a; }
+            f16* r;
+            if (share && i == 0 && j == 0) {
+                R.B = n_lat;                                          // h holds [uncond | text] copies of the same tensor: use the first
+                f16* r1 = R.resnet(u->down_res[0][0], h, ch, nullptr, 0, H, W);
+                R.B = B;
+                ch = u->down_res[0][0].cout;
+                r = Run_xformer_cfg_shared(R, u->down_att[0][0], r1, H, W, n_lat);
+                R.release(r1);
+            } else {
+                r = R.resnet(u->down_res[i][j], h, ch, nullptr, 0, H, W);
+                ch = u->down_res[i][j].cout;
+                if (c.down_has_attn[i]) { f16* a = R.xformer(u->down_att[i][j], r, H, W); R.release(r); r = a; }
+            }
             h = r; skips.push_back({h, ch});
         }
         if (u->has_down[i]) {
@@ -571,7 +642,19 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || batch <= 0) return 0;
     run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
-    return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + u->arena.peak + 4096;
+    size_t peak = u->arena.peak;
+    if (batch % 2 == 0) {       // the CFG shared-prefix path allocates differently: take the larger peak
+        run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+        if (u->arena.peak > peak) peak = u->arena.peak;
+    }
+    return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;
+}
+
+double cs_unet_flops_executed(const CsUNet* cu, int n_lat, int dup) {
+    CsUNet* u = const_cast<CsUNet*>(cu);
+    if (!u || !u->finalized || n_lat <= 0 || (dup != 1 && dup != 2)) return 0;
+    run_forward(u, true, nullptr, n_lat, dup, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+    return u->dry_flops;
 }
 
 double cs_unet_flops(const CsUNet* cu, int batch) {

@@ -89,6 +89,10 @@ class HipUNet2DConditionModel:
     def flops(self, batch):
         return float(L.lib().cs_unet_flops(self._h, batch))
 
+    def flops_executed(self, n_lat, dup=1):
+        """FLOPs the library actually executes for ``dup`` copies of ``n_lat`` latents (CFG shared prefix, see consolver_hip.h)."""
+        return float(L.lib().cs_unet_flops_executed(self._h, n_lat, dup))
+
     def _workspace(self, batch):
         if self._ws is None or batch > self._ws_batch:
             n = int(L.lib().cs_unet_workspace_bytes(self._h, batch))

@@ -168,6 +168,10 @@ int cs_unet_finalize(CsUNet* u);
 size_t cs_unet_workspace_bytes(const CsUNet* u, int batch);
 /* FLOPs of one forward at `batch` samples (algorithmic, 2*MAC) */
 double cs_unet_flops(const CsUNet* u, int batch);
+/* FLOPs actually executed by cs_unet_forward(n_lat, dup): with dup = 2 and one timestep the layers in front of the first
+ * cross attention are evaluated once for both CFG halves (same latents, same timestep; bit-identical results), so this is
+ * slightly below cs_unet_flops(n_lat * dup), which stays the algorithmic count of the reference graph. */
+double cs_unet_flops_executed(const CsUNet* u, int n_lat, int dup);
 
 /* latents: [n_lat, C, H, W] (NCHW, fp16).  The effective batch is
  * n_lat * dup (dup = 2 for the CFG dual batch, sample b reads latent b % n_lat;

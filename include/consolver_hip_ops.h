@@ -96,6 +96,7 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "conv_halo": 0 never, 1 auto (default), 2 whenever the shape allows, 3 also force the 256x320 / 256x256 k32 tiles, 4 never use those;
  *   "gemm_big":  0 off, 1 auto (default), 2 force the 256x320 GEMM, 3 force the 256x160 GEMM;
  *   "attn_qt40": query tiles per wave at head dim 40 (2 | 4, default 4);
+ *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "debug":     1 skip the GEMM epilogue, 2 skip its k loop (timing experiments only: results are wrong) */
 int cs_set_tuning(const char* key, int value);
 

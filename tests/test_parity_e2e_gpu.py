@@ -53,13 +53,15 @@ class HipHooks:
         self._packed = {}
 
     def _w(self, w, kind):
-        key = (w.data_ptr(), kind)
+        # keyed on the tensor OBJECT, which the cache keeps alive: a (data_ptr) key would match another layer's weight that the
+        # allocator later placed at a freed address
+        key = (id(w), kind)
         if key not in self._packed:
             if kind == "conv":
-                self._packed[key] = ops.pack_conv_weight(w).to(DEV)
+                self._packed[key] = (w, ops.pack_conv_weight(w).to(DEV))
             else:
-                self._packed[key] = w.to(DEV, torch.float16).contiguous()
-        return self._packed[key]
+                self._packed[key] = (w, w.to(DEV, torch.float16).contiguous())
+        return self._packed[key][1]
 
     def conv3(self, x, w, b, stride):
         return _nchw(ops.conv2d(_nhwc(x), self._w(w, "conv"), b, taps=9, stride=stride))
@@ -73,11 +75,11 @@ class HipHooks:
         return ops.linear(x.reshape(B * N, K).contiguous(), self._w(w, "lin"), b).reshape(B, N, -1)
 
     def geglu(self, x, w, b):
-        key = (w.data_ptr(), "geglu")
+        key = (id(w), "geglu")
         if key not in self._packed:
             wp, bp = ops.geglu_pack(w, b)
-            self._packed[key] = (wp.to(DEV), bp.to(DEV))
-        wp, bp = self._packed[key]
+            self._packed[key] = (w, wp.to(DEV), bp.to(DEV))
+        _, wp, bp = self._packed[key]
         B, N, K = x.shape
         return ops.linear(x.reshape(B * N, K).contiguous(), wp, bp, geglu=True).reshape(B, N, -1)
 

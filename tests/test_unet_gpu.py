@@ -106,3 +106,40 @@ def test_full_sd15_unet_matches_oracle_cfg_batch():
     # determinism
     again = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
     assert torch.equal(got, again)
+
+
+@pytest.mark.timeout(900)
+def test_cfg_shared_prefix_matches_full_dual_batch():
+    """CFG dual batch (dup = 2, one timestep): the layers in front of the first cross attention are evaluated once for both
+    halves (unet.cpp `Run_xformer_cfg_shared`).  Same function of the same inputs -> the result must equal the full dual
+    batch: bit for bit at the benchmark's shape (the per-sample kernels and their tile / split choices are the same at batch 16
+    and 32), and to fp16 rounding on a reduced model where the smaller prefix batch may pick another split-K factor."""
+    from consolver_amd import ops
+    try:
+        for cfg_over, n_lat, exact in ((dict(layers_per_block=1, sample_size=16), 3, False), ({}, 16, True)):
+            u, _ = build(cfg_over)
+            S = u.config["sample_size"]
+            g = torch.Generator().manual_seed(9)
+            lat = torch.randn(n_lat, 4, S, S, generator=g).half().to(DEV)
+            ctx = synthetic_prompt_embeds(2 * n_lat, seed=21).half().to(DEV)
+            ops.set_tuning("cfg_share", 0)
+            full = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+            ops.set_tuning("cfg_share", 1)
+            shared = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+            again = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=True)[0]
+            assert torch.equal(shared, again)
+            err = rel_l2(shared, full)
+            print("cfg shared prefix vs full dual batch: rel l2", err, "bit-identical" if torch.equal(shared, full) else "")
+            assert torch.isfinite(shared).all()
+            if exact:
+                assert torch.equal(shared, full)
+            else:
+                assert err < 1e-3, err
+            assert not torch.equal(shared[:n_lat], shared[n_lat:])          # the halves do diverge after the shared prefix
+            # per-sample timesteps (the halves could differ): the shared path is not taken, results equal the full batch
+            tt = torch.full((2 * n_lat,), 499.0, device=DEV)
+            assert torch.equal(u(lat, tt, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0], full)
+            assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat) and u.flops_executed(2 * n_lat, 1) == u.flops(2 * n_lat)
+            del u
+    finally:
+        ops.set_tuning("cfg_share", 1)
