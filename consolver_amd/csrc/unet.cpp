@@ -275,7 +275,11 @@ struct Run {
 
     f16* alloc(size_t halfs) {
         void* p = u->arena.alloc(halfs * sizeof(f16));
-        if (!p && rc == CS_OK) { cs_set_error("unet: workspace too small"); rc = CS_E_ARG; }
+        if (!p && rc == CS_OK) {
+            cs_set_error("unet: workspace too small (request %zu B, arena %zu B, peak so far %zu B, batch %d)", halfs * sizeof(f16), u->arena.cap,
+                         u->arena.peak, B);
+            rc = CS_E_ARG;
+        }
         return (f16*)p;
     }
     void release(const void* p) { u->arena.free(const_cast<void*>(p)); }
@@ -643,8 +647,11 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     if (!u || !u->finalized || batch <= 0) return 0;
     run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
     size_t peak = u->arena.peak;
-    if (batch % 2 == 0) {       // the CFG shared-prefix path allocates differently: take the larger peak
+    if (batch % 2 == 0) {       // the CFG shared-prefix path allocates differently: take the larger peak (whatever the knob says now)
+        const int knob = g_tune_cfg_share;
+        g_tune_cfg_share = 1;
         run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+        g_tune_cfg_share = knob;
         if (u->arena.peak > peak) peak = u->arena.peak;
     }
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;

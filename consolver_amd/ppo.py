@@ -93,15 +93,20 @@ def ppo_loss(curr_probs, old_probs, entropy, advantages, clip_range=0.2, entropy
 
 def collect_rollout(text_encoder, noise_scheduler, unet, vae, noise, text, tokenizer, target_latents, cfg=3.0, num_inference_steps=8,
                     reward_type="image_psnr", reward_model=None, reward_model_processor=None, decode_batch_size=8,
-                    prompt_embeds=None, negative_prompt_embeds=None):
+                    prompt_embeds=None, negative_prompt_embeds=None, identical_inputs=False):
     """train_ppo.py:352-403 for one batch: rollout, decode pred and teacher latents, reward, advantages, and the
-    records flattened to [B (n-1), ...].  Returns a dict(conds, actions, probs, masks, advantages, rewards, model_pred)."""
+    records flattened to [B (n-1), ...].  Returns a dict(conds, actions, probs, masks, advantages, rewards, model_pred).
+    ``identical_inputs=True``: the B rows are copies of one (prompt, noise, teacher latent) sample (``repeat_random_sample``):
+    the rollout shares the denoiser calls whose inputs cannot differ yet, and the teacher image is decoded once."""
     n = num_inference_steps
     model_pred, conds, probs, actions, masks, _ = denoise_diffusion(
         text_encoder, noise_scheduler, unet, noise, text, tokenizer, cfg=float(cfg), num_inference_steps=n,
-        prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, identical_inputs=identical_inputs)
     model_pred_decoded = decode_latents(vae, model_pred, batch_size=decode_batch_size)
-    target_decoded = decode_latents(vae, target_latents, batch_size=decode_batch_size)
+    if identical_inputs and target_latents.shape[0] > 1:
+        target_decoded = decode_latents(vae, target_latents[:1], batch_size=1).expand(target_latents.shape[0], -1, -1, -1).contiguous()
+    else:
+        target_decoded = decode_latents(vae, target_latents, batch_size=decode_batch_size)
     rewards = calculate_reward(reward_type, reward_model, reward_model_processor, model_pred_decoded, target_decoded, noise.device)
     B = model_pred.shape[0]
     flat = lambda v: v.reshape(v.shape[0] * (n - 1), *v.shape[2:])
@@ -209,7 +214,7 @@ class PolicyTrainer:
 
 
 def train_iteration(trainer, text_encoder, noise_scheduler, unet, vae, batch, tokenizer, cfg=3.0, num_inference_steps=None, ppo_epochs=4,
-                    reward_type="image_psnr", dist=None, prompt_embeds=None, negative_prompt_embeds=None, rng=None):
+                    reward_type="image_psnr", dist=None, prompt_embeds=None, negative_prompt_embeds=None, rng=None, share_identical=True):
     """One iteration of the training loop body (train_ppo.py:322-437): ``repeat_random_sample`` -> random step count in [2, 15]
     (:345) -> rollout, decode, reward, advantages (``collect_rollout``) -> ``ppo_epochs`` optimisation steps on the collected
     batch.  ``batch`` = (text list, noise [B,4,64,64], teacher latents [B,4,64,64]) already on the GPU.
@@ -218,9 +223,17 @@ def train_iteration(trainer, text_encoder, noise_scheduler, unet, vae, batch, to
     from .ppo_data import repeat_random_sample
     rng = rng or random
     text, noise, tch = repeat_random_sample(batch)
+    B = noise.shape[0]
+    if prompt_embeds is not None and prompt_embeds.shape[0] == B:       # cached embeddings follow the item that was picked
+        i = repeat_random_sample.last_index
+        prompt_embeds = prompt_embeds[i:i + 1].expand(B, -1, -1).contiguous()
+        if negative_prompt_embeds is not None:
+            negative_prompt_embeds = negative_prompt_embeds[i:i + 1].expand(B, -1, -1).contiguous()
     n = num_inference_steps or rng.choice(list(range(2, 16)))
+    # the B rows are copies of one sample by construction (data_processing.py:65-83): share what cannot differ
     roll = collect_rollout(text_encoder, noise_scheduler, unet, vae, noise, text, tokenizer, tch, cfg=cfg, num_inference_steps=n,
-                           reward_type=reward_type, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+                           reward_type=reward_type, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
+                           identical_inputs=share_identical)
     loss = norm = None
     for _ in range(ppo_epochs):
         loss, norm = trainer.step(roll["conds"], roll["actions"], roll["probs"], roll["advantages"], dist=dist)

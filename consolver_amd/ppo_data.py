@@ -72,4 +72,5 @@ def repeat_random_sample(batch):
     text, noise, tch = batch
     B = noise.shape[0]
     i = random.randint(0, B - 1)
+    repeat_random_sample.last_index = i          # callers holding per-item side data (cached prompt embeddings) pick the same item
     return [text[i]] * B, noise[i:i + 1].repeat(B, *[1] * (noise.dim() - 1)), tch[i:i + 1].repeat(B, *[1] * (tch.dim() - 1))

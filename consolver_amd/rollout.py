@@ -6,6 +6,14 @@
 Differences in mechanism, not in results: the CFG dual batch is not materialised by
 ``torch.cat`` when the denoiser is the HIP UNet (it reads latent ``b % B``), and the CFG
 combine ``u + g (c - u)`` (:96-100) is fused into the solver-update kernel.
+
+``identical_inputs=True`` (extension): the caller states that all B rows of ``noise`` / ``text`` /
+prompt embeddings are copies of ONE sample -- what the trainer feeds this function
+(``repeat_random_sample``, data_processing.py:65-83, train_ppo.py:336).  The B trajectories then only
+diverge through their sampled solver coefficients, which first enter the update at step 1 (one history
+entry at step 0: eps_eff = eps, scheduler_ppo.py:263-265; scale actions, if any, act from step 0).  The
+denoiser inputs of step 0 (and of step 1 when ``scaler_dim == 0``) are therefore the same for every row:
+they are evaluated for one row and broadcast.  Every returned tensor keeps its full-batch shape.
 """
 import torch
 
@@ -13,7 +21,7 @@ from . import _lib as L
 
 
 def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg=3, num_inference_steps=50,
-                      gradient_checkpointing=False, prompt_embeds=None, negative_prompt_embeds=None):
+                      gradient_checkpointing=False, prompt_embeds=None, negative_prompt_embeds=None, identical_inputs=False):
     if gradient_checkpointing:
         raise NotImplementedError("inference-only rollout: the denoiser is frozen (train_ppo.py:148-154)")
     if isinstance(text, str):
@@ -44,11 +52,20 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
     native = getattr(unet, "is_consolver_hip", False)
     rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
     try:
+        shared_steps = 0
+        if identical_inputs and native and batch_size > 1:
+            shared_steps = 2 if scheduler.config.scaler_dim == 0 else 1
+            pe1 = (torch.cat([prompt_embeds[:1], prompt_embeds[batch_size:batch_size + 1]]) if do_cfg else prompt_embeds[:1]).contiguous()
         for i, t in enumerate(scheduler.timesteps):
-            if native:
-                # K/V of the prompt: computed at step 0 of THIS rollout, reused afterwards
+            if native and i < shared_steps:
+                # every row carries the same latents: one row through the denoiser, broadcast to the batch
+                e1 = unet(latents[:1], t, encoder_hidden_states=pe1, return_dict=False, dup=2 if do_cfg else 1, reuse_kv=(i > 0))[0]
+                noise_pred = (torch.cat([e1[:1].expand(batch_size, -1, -1, -1), e1[1:].expand(batch_size, -1, -1, -1)]) if do_cfg
+                              else e1.expand(batch_size, -1, -1, -1)).contiguous()
+            elif native:
+                # K/V of the prompt: computed at the first full-batch step of THIS rollout, reused afterwards
                 noise_pred = unet(latents, t, encoder_hidden_states=prompt_embeds, return_dict=False,
-                                  dup=2 if do_cfg else 1, reuse_kv=(i > 0))[0]
+                                  dup=2 if do_cfg else 1, reuse_kv=(i > shared_steps))[0]
             else:
                 lat_in = torch.cat([latents] * 2) if do_cfg else latents
                 lat_in = scheduler.scale_model_input(lat_in, t)

@@ -348,3 +348,32 @@ def test_fmppo_fp32_sample_is_consumed_as_fp32():
     rounded_in = (x.bfloat16().float() + step.float()).bfloat16()
     assert torch.equal(out.cpu(), want)
     assert not torch.equal(want, rounded_in)                        # the case distinguishes the two behaviours
+
+
+def test_rollout_shares_denoiser_calls_for_identical_inputs():
+    """the trainer's batch is B copies of one sample (repeat_random_sample, data_processing.py:65-83): with identical_inputs=True the
+    rollout evaluates steps 0 and 1 (scaler_dim = 0) for one row and broadcasts; records and latents equal the full-batch rollout to
+    fp16 rounding (the one-row denoiser call may pick other tile / split-K shapes than the batch-B call)."""
+    from consolver_amd.rollout import denoise_diffusion
+    u = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
+    u.load_state_dict(synthetic_unet_state_dict(u.manifest(), seed=3))
+    sch, _ = _scheduler()
+    B, n = 4, 5
+    noise = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half().to(DEV).repeat(B, 1, 1, 1)
+    pe = synthetic_prompt_embeds(1, seed=100).half().to(DEV).repeat(B, 1, 1)
+    ne = synthetic_prompt_embeds(1, seed=101).half().to(DEV).repeat(B, 1, 1)
+    idx = [torch.randint(0, 11, (B, 3), generator=torch.Generator().manual_seed(10 + i)).to(DEV) for i in range(n)]
+
+    def run(flag):
+        sch.factor_net.forced_action_idx = list(idx)
+        return denoise_diffusion(None, sch, u, noise, ["a"] * B, None, cfg=3.0, num_inference_steps=n, prompt_embeds=pe,
+                                 negative_prompt_embeds=ne, identical_inputs=flag)
+    full, shared = run(False), run(True)
+    lat_f, conds_f, probs_f, act_f, masks_f, _ = full
+    lat_s, conds_s, probs_s, act_s, masks_s, _ = shared
+    assert torch.equal(act_f, act_s) and torch.equal(masks_f, masks_s) and torch.equal(conds_f["x"], conds_s["x"])
+    assert torch.allclose(probs_f, probs_s, rtol=1e-5, atol=1e-7)
+    assert conds_s["epsilon"].shape == conds_f["epsilon"].shape == (B, n - 1, 4, 4, 16, 16)
+    assert rel_l2(conds_s["epsilon"].float(), conds_f["epsilon"].float()) < 2e-3
+    assert rel_l2(lat_s.float(), lat_f.float()) < 2e-3
+    assert not torch.equal(lat_s[0], lat_s[1])                   # the trajectories do diverge (different sampled coefficients)
