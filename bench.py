@@ -170,8 +170,14 @@ def extra_rollout(unet, vae, dev, B=80, n=8, epochs=4, iters=2):
                                                     prompt_embeds=pe, negative_prompt_embeds=ne), iters)
     fl = unet.flops(2 * B) * n + vae.flops(8) * (2 * B / 8)
     tf = fl / (ms * 1e-3) / 1e12
+    # executed: the B rows are copies of one sample (repeat_random_sample, data_processing.py:65-83): steps 0 and 1 of the rollout run the
+    # denoiser for one row, the teacher latent is decoded once
+    fl_exec = unet.flops_executed(B, 2) * (n - 2) + unet.flops_executed(1, 2) * 2 + vae.flops(8) * (B / 8) + vae.flops(1)
     return {"workload": f"configs[4] on 1 GPU: PPO rollout B={B}, {n} steps, CFG 3, 2x{B} VAE decodes, image_psnr reward, {epochs} PPO epochs",
             "ms_per_iteration": ms, "trajectories_per_s": B / (ms * 1e-3), "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS,
+            "tflops_executed": fl_exec / (ms * 1e-3) / 1e12, "frac_of_mfma_peak_executed": fl_exec / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS,
+            "note": "tflops = algorithmic FLOPs of the reference's loop (B full trajectories, 2B decodes) / time; _executed = what the "
+                    "identical-input sharing actually runs",
             "loss_finite": bool(torch.isfinite(torch.as_tensor(float(out["loss"]))))}
 
 
@@ -399,7 +405,11 @@ def main():
                 pass
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
-                "launch_ms": fwd_ms, "flops_per_launch": flops_fwd}
+                "launch_ms": fwd_ms, "flops_per_launch": flops_fwd,
+                # flops_per_launch is the ALGORITHMIC count of the reference graph (32 x 803.27 GFLOP).  The executor evaluates
+                # the layers in front of the first cross attention once for both CFG halves (same latents and timestep: bit-identical
+                # results, tests/test_unet_gpu.py), so slightly fewer FLOPs are actually executed:
+                "flops_executed_per_launch": unet.flops_executed(B, 2) if args.guidance > 1 else flops_fwd}
 
     kernels = None
     if args.profile_kernels and rank == 0:

@@ -22,6 +22,7 @@
 //     run of tiles and the n-tiles of one pixel tile run back to back on it.
 #include "ops.h"
 #include <stdlib.h>
+#include <type_traits>
 
 extern int g_tune_halo;
 extern int g_tune_debug;
@@ -208,6 +209,8 @@ struct HaloParams {
     int NHALO, NQ;          // halo rows per tile ; DMA instructions (8 rows each) per halo
     int splits;             // split-K over channel chunks (gridDim.y); > 1 -> fp32 partials to `partial`
     float* partial;         // [splits][M][N]
+    int sched;              // kernel schedule variant (template SCHED): 0 lock-step groups as in round 1; 1 + static priority for group B;
+                            // 2 + group B's DMA issues among its MFMAs
 };
 
 constexpr int HALO_ROWS_MAX = 400;
@@ -230,7 +233,7 @@ struct PatchRows {          // tile-local pixel -> output row
 // 64 x 80, half the per-tile prologue / epilogue and half the halo traffic per FLOP); the weight tile of a step is [320 rows][32 k] = 64-byte
 // rows (chunk index XOR (row >> 1) & 3: conflict-free ds_read_b128 under gfx950's lane grouping), the same 20 KB and 20 DMA instructions as
 // the [160][64] tile of KH = 1, so buffers, rotation and the stagger are unchanged - a chunk is 18 steps instead of 9.
-template <bool UP, int BN, int KH = 1>
+template <bool UP, int BN, int KH = 1, int SCHED = 2>
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     static_assert(KH == 1 || KH == 2, "k halves per tap");
     constexpr int NT = BN / 32, MT = 4;
@@ -381,16 +384,27 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
             if (KH == 1) fw[2 / KH - 1][i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + wfrag1);
         }
     };
-    auto multiply = [&]() {
+    auto multiply_part = [&](auto i0_tag, auto i1_tag) {      // weight tiles [i0, i1) of the wave tile
+        constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < 2 / KH; ++ks)
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int i = I0; i < I1; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
     };
+    auto multiply = [&]() { multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{}); };
 
+    // Static priority for group B.  Without it the stagger barely pays: group A's MFMAs become ready a few hundred cycles into the step
+    // (when its fragment reads return) and then share the SIMD's matrix pipe 1:1 with group B's, so B finishes its 40 MFMAs at the END of
+    // the step instead of the middle, issues its fragment reads late, and both groups stand at the next barrier with B's reads still in
+    // flight -- the pipe idles for an LDS latency every step (measured with the staging switched off: 238 us -> 194 us on the 64 x 64
+    // 320 -> 320 layer once B wins the arbitration; pure MFMA issue of that loop: 177 us).  With priority B's MFMAs run first and
+    // uncontested, its reads overlap A's MFMAs, and vice versa.  (cs_set_tuning("conv_sched", 0) restores the old schedule.)
+    // What bounds this loop was measured with throw-away builds that skip parts of it (profiles/r02_conv_bound.txt): pure MFMA issue
+    // 177 us, + per-step barrier 184, + fragment reads 221, + staging 259 (round-1 schedule); no barrier at all 180.
+    if (SCHED >= 1 && groupB) __builtin_amdgcn_s_setprio(2);
     int it = 0, ab = 0, wb = 0;
     for (int c = c_begin; c < c_end; ++c, ab ^= 1) {
         const char* ha = lA + ab * A_BYTES;
@@ -398,13 +412,32 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
 #pragma unroll 1
         for (int t = 0; t < STEPS; ++t, ++it) {       // t: step inside the chunk (a tap, or half a tap when KH = 2)
             const int wnext = wb == (CS_HALO_NWB - 1) ? 0 : wb + 1;
-            if (t < STEPS - 1) stage_w(c, t + 1, wnext);
-            else if (c + 1 < c_end) stage_w(c + 1, 0, wnext);
-            if (t > 0 && t <= 8 && c + 1 < c_end) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
+            const bool do_w = t < STEPS - 1 || c + 1 < c_end;
+            const bool do_a = t > 0 && t <= 8 && c + 1 < c_end;
+            const int wc = t < STEPS - 1 ? c : c + 1, wt = t < STEPS - 1 ? t + 1 : 0;
             const char* tb = lB + wb * B_BYTES + (wn * (BN / 2)) * WROW;
-            if (groupB && it > 0) multiply();      // group B: step it-1, fragments read before the previous barrier
+            if (SCHED >= 2 && groupB) {
+                // group B's DMA issues go BETWEEN its MFMAs: a 1 KiB LDS-DMA instruction costs the issuing wave 100-200 cycles, and issued
+                // in front of the MFMAs (fine for group A, whose MFMAs wait for its fragment reads anyway) they left the matrix pipe
+                // empty at the start of every step
+                constexpr int C1 = NT / 3, C2 = 2 * NT / 3;
+                if (it > 0) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, C1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_w) stage_w(wc, wt, wnext);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it > 0) multiply_part(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_a) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (it > 0) multiply_part(std::integral_constant<int, C2>{}, std::integral_constant<int, NT>{});
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (do_w) stage_w(wc, wt, wnext);
+                if (do_a) { stage_a(c + 1, t - 1, ab ^ 1); halo_advance(); }
+                if (SCHED < 2 && groupB && it > 0) multiply();     // group B: step it-1, fragments read before the previous barrier
+            }
             read_frags(ha, tb, t);
-            if (!groupB) multiply();               // group A: this step
+            if (!groupB) multiply();                           // group A: this step
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             wb = wnext;
@@ -732,12 +765,33 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 }  // namespace
 
 int g_tune_debug = 0;
+int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
 int g_tune_biggemm = 1;
 
 double igemm_flops(const IgemmArgs& a) {
     const double M = (double)a.B * a.Ho * a.Wo;
     return 2.0 * M * a.N * (double)a.taps * (a.c0 + a.c1);
+}
+
+// one halo-conv instantiation per (upsample, tile width, k halves, schedule); the schedule comes from cs_set_tuning("conv_sched")
+template <bool UP, int BN, int KH, int SCHED>
+static int launch_halo_sched(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        constexpr size_t max_lds = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<UP, BN, KH, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv3_halo_kernel<UP, BN, KH, SCHED>), grid, dim3(512), lds, s, h);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+template <bool UP, int BN, int KH>
+static int launch_halo(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) {
+    if (h.sched <= 0) return launch_halo_sched<UP, BN, KH, 0>(h, grid, lds, s);
+    if (h.sched == 1) return launch_halo_sched<UP, BN, KH, 1>(h, grid, lds, s);
+    return launch_halo_sched<UP, BN, KH, 2>(h, grid, lds, s);
 }
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s) {
@@ -796,35 +850,17 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
             h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Ho = Ho; h.Wo = Wo;
             h.tw_shift = TW == 16 ? 4 : 3; h.trw_shift = 0; while ((1 << h.trw_shift) < TRW) ++h.trw_shift;
             h.PX = PX; h.PP = PP;
-            h.splits = splits; h.partial = a.splitk_ws;
-            constexpr size_t lds = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);
-            static bool configured = false;
-            if (!configured) {
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<false, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_halo_kernel<true, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                configured = true;
-            }
+            // schedule: the k32-step kernels (BN 320 / 256) gain 6-11 % from priority + interleaved DMA (A/B on one box, tools/ab_convsched.sh);
+            // the k64-step kernels (BN 160 / 128: 16 x 16 and 8 x 8 images) measured 0.207 -> 0.213 ms with it and keep the lock-step schedule
+            h.splits = splits; h.partial = a.splitk_ws; h.sched = g_tune_conv_sched < 0 ? (wide ? 2 : 0) : g_tune_conv_sched;
             const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * (wide ? 64 : 128));
             const dim3 grid(h.e.nblk, splits);
-            if (wide && hbn == 320) {
-                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 320, 2>), grid, dim3(512), l, s, h);
-                else hipLaunchKernelGGL((conv3_halo_kernel<false, 320, 2>), grid, dim3(512), l, s, h);
-            } else if (wide) {
-                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 256, 2>), grid, dim3(512), l, s, h);
-                else hipLaunchKernelGGL((conv3_halo_kernel<false, 256, 2>), grid, dim3(512), l, s, h);
-            } else if (hbn == 160) {
-                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 160>), grid, dim3(512), l, s, h);
-                else hipLaunchKernelGGL((conv3_halo_kernel<false, 160>), grid, dim3(512), l, s, h);
-            } else {
-                if (a.upsample) hipLaunchKernelGGL((conv3_halo_kernel<true, 128>), grid, dim3(512), l, s, h);
-                else hipLaunchKernelGGL((conv3_halo_kernel<false, 128>), grid, dim3(512), l, s, h);
-            }
+            int rc;
+            if (wide && hbn == 320) rc = a.upsample ? launch_halo<true, 320, 2>(h, grid, l, s) : launch_halo<false, 320, 2>(h, grid, l, s);
+            else if (wide) rc = a.upsample ? launch_halo<true, 256, 2>(h, grid, l, s) : launch_halo<false, 256, 2>(h, grid, l, s);
+            else if (hbn == 160) rc = a.upsample ? launch_halo<true, 160, 1>(h, grid, l, s) : launch_halo<false, 160, 1>(h, grid, l, s);
+            else rc = a.upsample ? launch_halo<true, 128, 1>(h, grid, l, s) : launch_halo<false, 128, 1>(h, grid, l, s);
+            if (rc != CS_OK) return rc;
             CS_CHECK_LAUNCH();
             if (splits > 1) {
                 const long total = (long)p.M * (p.N / 8);
