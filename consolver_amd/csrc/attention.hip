@@ -22,6 +22,7 @@
 #include <type_traits>
 
 int g_tune_attn_qt40 = 4;
+int g_tune_attn_prio = -1;     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
 
 namespace {
 
@@ -37,6 +38,7 @@ struct AttnParams {
     int splits, tiles_per_split, part_rows;
     float* part_o;       // [splits][part_rows][DH] unnormalised O, relative to the partial's own reference maximum
     float* part_ml;      // [splits][part_rows][2]  (reference maximum in log2 units, denominator)
+    int prio;            // 1: the wave in the odd hardware slot of its SIMD runs at raised priority (see the kernel)
 };
 
 typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -86,6 +88,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
+    // Two workgroups share a CU, so every SIMD hosts two waves that run this same loop (score MFMAs -> exp / convert VALU -> P V MFMAs ->
+    // barrier).  With equal priority their MFMA phases share the matrix pipe 1:1 and their VALU phases the issue port, so both finish
+    // every phase late; a static priority for ONE of the two (the wave in the odd hardware wave slot, HW_REG_HW_ID[3:0]) lets its MFMA
+    // phase run uncontested while the partner is in its VALU phase and vice versa -- the effect measured on the conv kernel's wave groups.
+    if (p.prio) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID (id 4), bits [3:0] = wave slot in the SIMD
+        if (slot & 1) __builtin_amdgcn_s_setprio(2);
+    }
     // Workgroup id -> XCD is id % 8 (round-robin dispatch); give every XCD a CONTIGUOUS range of (query block, head) items so that the ~64
     // workgroups resident on one XCD walk the same head's K/V at the same time and share it through that XCD's 4 MB L2 (in plain order an XCD
     // sees every 8th query block of every head: 8x the K/V bytes through its L2; FLUX: 4.45 MB of K/V per head, 1632 workgroups).
@@ -542,6 +552,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     p.H = a.H; p.Nq = a.Nq; p.Nk = a.Nk;
     p.c = a.scale * 1.4426950408889634f;
     p.bias = a.bias;
+    p.prio = g_tune_attn_prio < 0 ? (a.dh == 128 ? 1 : 0) : g_tune_attn_prio;
     if (a.bias) {
         if (a.dh != 64 || a.causal || a.Nk % 4) CS_FAIL(CS_E_UNSUPPORTED, "attention: the biased form is built for head dim 64, no mask, Nk %% 4 == 0");
         if (a.dtype == CS_BF16) return launch_attn<bf16_el, 64, 2, false, true>(p, a.B, s);

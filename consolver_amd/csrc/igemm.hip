@@ -564,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
     const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
 
+    if ((p.debug & 4096) && w >= 4) __builtin_amdgcn_s_setprio(2);      // (experiment: static priority for waves 4-7)
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
