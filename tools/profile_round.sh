@@ -27,7 +27,7 @@ print(out)
 # per-forward HBM-side traffic with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-B requests at 64 B -> x2;
 # WRITE_SIZE exact for 16-B/lane stores; both in KB.  tools/bench_unet.py 2 runs 6 forwards (3 warm-up + 2 timed + 1 profiled).
 fw = 6
-rec = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) over `python3 tools/bench_unet.py 2` = 6 UNet "
+rec = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no tracing) over 'python3 tools/bench_unet.py 2' = 6 UNet "
                  "forwards at effective batch 32 (3 warm-up + 2 timed + 1 profiled); tools/profile_round.sh $TAG",
        "forwards": fw, "FETCH_SIZE_KB_sum": out["fetch"]["sum_counter"], "WRITE_SIZE_KB_sum": out["write"]["sum_counter"],
        "dispatches": out["fetch"]["dispatches"],
