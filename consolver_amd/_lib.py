@@ -191,6 +191,12 @@ def lib():
         f.argtypes = args
     if l.cs_abi_version() != 2:
         raise RuntimeError("libconsolver_hip.so ABI version mismatch")
+    # CS_TUNE="key=value,..." applies kernel-selection knobs (cs_set_tuning) at load time: A/B runs of tests and tools without code changes
+    for kv in os.environ.get("CS_TUNE", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            if l.cs_set_tuning(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"CS_TUNE: {l.cs_last_error().decode()}")
     _lib = l
     return l
 

@@ -15,6 +15,8 @@
 #include "el.h"
 #include <algorithm>
 
+int g_tune_gemm2_prio = 0;
+
 namespace {
 
 constexpr int BK = 64;
@@ -52,7 +54,7 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 // of the 256 CUs for a whole tile time, appended to the image problem's tile list they ride in its last, partly empty round.
 // Split-K tail (single-problem launches): the launch covers tiles [id0, id0 + nblk) and, when splits > 1, blockIdx.y picks the k range;
 // the fp32 partial tiles go to `partial` ([tile - id0][split][256][256]) and g2_tail_reduce_kernel applies the epilogue.
-struct G2Pair { G2Params p[2]; int nblk0, nblk; int id0, splits; float* partial; };
+struct G2Pair { G2Params p[2]; int nblk0, nblk; int id0, splits; float* partial; int prio; };
 
 // Tile order: bands of GM row-tiles, row-tile fastest inside a band.  The ~32 tiles an XCD runs at once (consecutive ids) then cover
 // GM x (32 / GM) tiles: GM activation panels + 32/GM weight panels per k-step through that XCD's L2 instead of 1 + 32 in plain row-major
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
+    if (pp.prio == 1 && w >= 4) __builtin_amdgcn_s_setprio(2);          // (cs_set_tuning("gemm2_prio"): static priority experiment)
+    if (pp.prio == 2 && (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1)) __builtin_amdgcn_s_setprio(2);
     int id;
     {
         const int bid = blockIdx.x, xcd = bid & 7, q = pp.nblk >> 3, r = pp.nblk & 7;
@@ -437,7 +441,7 @@ size_t gemm2_tail_workspace_bytes(int tiles, int K) {
 }
 
 static int g2_run(G2Pair pp, int dtype, void* tail_ws, size_t tail_ws_bytes, hipStream_t s) {
-    pp.id0 = 0; pp.splits = 1; pp.partial = nullptr;
+    pp.id0 = 0; pp.splits = 1; pp.partial = nullptr; pp.prio = g_tune_gemm2_prio;
     const bool two = pp.nblk > pp.nblk0;
     int tail = 0;
     const int sp = tail_ws ? g2_tail_splits(pp.nblk, two ? std::min(pp.p[0].KT, pp.p[1].KT) : pp.p[0].KT, &tail) : 0;

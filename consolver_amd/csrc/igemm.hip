@@ -601,6 +601,132 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, (BNX == 320 ? 2 : 1)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same 256 x 320 tile in the halo conv kernel's LOOP STRUCTURE (round 2): k steps of 32 (one MFMA k-step), THREE LDS stages
+// of [256 + 320 rows][64 B] = 36 KB, waves 4-7 staggered by one step behind waves 0-3 with static priority and their LDS-DMA
+// issues placed among their MFMAs.  gemm_big_kernel's k64 steps need 112 fragment registers for a whole step, which the staggered
+// group would have to hold across the barrier next to 160 accumulators; at k32 it is 56.  Why the structure: profiles/r02_conv_bound.txt
+// (lock-step waves lose an LDS latency after every barrier; priority makes the stagger's overlap real).
+// 64-byte LDS rows, 16-byte chunk index XOR (row >> 1) & 3 (conflict-free ds_read_b128, as the conv kernel's k32 weight tile);
+// one DMA instruction = 16 rows.  Hazard rule as in the conv kernel: slab s is read during iteration s by both groups (group B's
+// reads may still be in flight when the barrier ending s opens), so its buffer is re-staged no earlier than iteration s + 2.
+// ------------------------------------------------------------------------------------------------
+template <bool GEGLU>
+__global__ __launch_bounds__(512, 2) void gemm_stag_kernel(IgemmParams p) {
+    constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4, KS = 32;
+    constexpr int A_BYTES = BMX * KS * 2, B_BYTES = BNX * KS * 2, STAGE = A_BYTES + B_BYTES;     // 16 KB + 20 KB
+    constexpr int APQ = BMX / 16, BPQ = BNX / 16;                 // DMA pieces per stage: 16 + 20
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    const int m_blk = tm * BMX, n_blk = tn * BNX;
+
+    // ---- staging: wave w issues A pieces {w, w + 8} and W pieces {w, w + 8, w + 16 (< 20)} -----------------
+    const int pch = lane & 3;
+    int a_row[2], a_chunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 16 * (w + 8 * j) + (lane >> 2);
+        const int m = m_blk + r;
+        a_chunk[j] = (pch ^ ((r >> 1) & 3)) * 8;
+        a_row[j] = (m < p.M) ? m : -1;
+    }
+    const f16* b_src[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = w + 8 * j;
+        const int r = 16 * (q < BPQ ? q : 0) + (lane >> 2);
+        b_src[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 3)) * 8;
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
+    const int KT32 = p.KT * 2;
+    auto stage = [&](int kt, int buf) {
+        const int cc = kt * KS;
+        const f16* src; int cs, coff;
+        if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
+        char* la = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = a_row[j] >= 0;
+            const uintptr_t real = (uintptr_t)(src + ((long)a_row[j] * cs + coff + a_chunk[j]));
+            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)ok;
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), la + (w + 8 * j) * 1024);
+        }
+        char* lb = smem + buf * STAGE + A_BYTES;
+        glds16(b_src[0] + (size_t)kt * KS, lb + w * 1024);
+        glds16(b_src[1] + (size_t)kt * KS, lb + (w + 8) * 1024);
+        if (w + 16 < BPQ) glds16(b_src[2] + (size_t)kt * KS, lb + (w + 16) * 1024);
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4;
+    const int frag_off = (lane & 15) * 64 + ((g ^ ((lane >> 1) & 3)) * 16);
+    f16x8 fa[MT], fw[NT];
+    auto read_frags = [&](int buf) {
+        const char* ta = smem + buf * STAGE + (wm * 64) * 64;
+        const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 64;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 1024 + frag_off);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + i * 1024 + frag_off);
+    };
+    auto multiply_part = [&](auto i0_tag, auto i1_tag) {
+        constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    };
+
+    const bool groupB = w >= 4;
+    if (groupB) __builtin_amdgcn_s_setprio(2);
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int buf = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < KT32; ++kt) {
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        const bool more = kt + 1 < KT32;
+        if (groupB) {
+            // multiply step kt - 1 (fragments read before the previous barrier), this wave's DMA issues in between
+            constexpr int C1 = NT / 2;
+            if (kt > 0) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, C1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) stage(kt + 1, nbuf);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt > 0) multiply_part(std::integral_constant<int, C1>{}, std::integral_constant<int, NT>{});
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (more) stage(kt + 1, nbuf);
+        }
+        read_frags(buf);
+        if (!groupB) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf = nbuf;
+    }
+    if (groupB) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{});     // drain: group B's last step
+    __syncthreads();                               // group B's last reads are consumed; the stage buffers become the epilogue patches
+    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+}
+
 template <int BN, bool CONV3, bool GEGLU>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int NT = BN / 32;          // 16-wide n tiles per wave (wave tile = 64 x BN/2)
@@ -766,6 +892,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 }  // namespace
 
 int g_tune_debug = 0;
+int g_tune_gemm_stag = 0;      // 1: 256 x 320 linear / 1x1 layers through gemm_stag_kernel instead of gemm_big_kernel<.,320>
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
 int g_tune_biggemm = 1;
@@ -883,6 +1010,19 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
+            }
+            if (g_tune_gemm_stag) {                      // round-2 loop structure (k32 steps, three stages, staggered wave groups)
+                constexpr size_t lds3 = 3 * (256 * 32 * 2 + 320 * 32 * 2);
+                static bool configured3 = false;
+                if (!configured3) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stag_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                    configured3 = true;
+                }
+                if (a.geglu) hipLaunchKernelGGL((gemm_stag_kernel<true>), dim3(p.nblk), dim3(512), lds3, s, p);
+                else hipLaunchKernelGGL((gemm_stag_kernel<false>), dim3(p.nblk), dim3(512), lds3, s, p);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
             }
             if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             else hipLaunchKernelGGL((gemm_big_kernel<false, 320>), dim3(p.nblk), dim3(512), lds, s, p);

@@ -8,6 +8,8 @@ extern int g_tune_debug;
 extern int g_tune_cfg_share;
 extern int g_tune_conv_sched;
 extern int g_tune_attn_prio;
+extern int g_tune_gemm_stag;
+extern int g_tune_gemm2_prio;
 extern int g_tune_biggemm;
 extern int g_tune_attn_qt40;
 
@@ -19,6 +21,8 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
+    if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
+    if (!strcmp(key, "gemm_stag")) { g_tune_gemm_stag = value; return CS_OK; }
     if (!strcmp(key, "attn_prio")) { g_tune_attn_prio = value; return CS_OK; }
     if (!strcmp(key, "conv_sched")) { if (value < -1 || value > 2) CS_FAIL(CS_E_ARG, "conv_sched must be -1 (auto), 0, 1 or 2"); g_tune_conv_sched = value; return CS_OK; }
     if (!strcmp(key, "attn_qt40")) { if (value != 2 && value != 4) CS_FAIL(CS_E_ARG, "attn_qt40 must be 2 or 4"); g_tune_attn_qt40 = value; return CS_OK; }

@@ -416,6 +416,40 @@ def gen_flux():
     print("flux fixtures written")
 
 
+def gen_forward_process():
+    """the forward-process members of the scheduler protocol (row a6): PPOScheduler.add_noise (scheduler_ppo.py:336-358) and
+    FMPPOScheduler.scale_noise (edit_ppo/scheduler_fmppo.py:457-484) of the imported reference, one subprocess-free pass each
+    (the two flavours ship same-named modules, so FLUX runs in a child process)."""
+    sys.path.insert(0, HERE)
+    import ref_stubs
+    flavour = os.environ.get("CS_GOLDEN_FLAVOUR", "sd")
+    ref_stubs.install(flavour)
+    import torch
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(8100)
+    x = rng.standard_normal((5, 4, 6, 6)).astype(np.float32)
+    n = rng.standard_normal((5, 4, 6, 6)).astype(np.float32)
+    if flavour == "sd":
+        with ref_stubs.quiet():
+            from scheduler_ppo import PPOScheduler
+            s = PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
+                             order_dim=4, scaler_dim=0, factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+        t = np.asarray([999, 874, 500, 1, 0], np.int64)
+        out = s.add_noise(torch.from_numpy(x), torch.from_numpy(n), torch.from_numpy(t))
+        np.savez_compressed(os.path.join(OUT, "forward_process_sd.npz"), x=x, noise=n, t=t, noisy=out.numpy())
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "forward_process"], env=dict(os.environ, CS_GOLDEN_FLAVOUR="flux"))
+    else:
+        with ref_stubs.quiet():
+            from scheduler_fmppo import FMPPOScheduler
+            s = FMPPOScheduler(shift=3.0, use_dynamic_shifting=True, order_dim=2, scaler_dim=0, mu_dim=0,
+                               factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+        s.set_timesteps(sigmas=np.linspace(1.0, 1 / 6, 6), mu=1.15)
+        ts = s.timesteps[[0, 2, 5, 3, 1]].clone()
+        out = s.scale_noise(torch.from_numpy(x), ts, torch.from_numpy(n))
+        np.savez_compressed(os.path.join(OUT, "forward_process_flux.npz"), x=x, noise=n, t=ts.numpy(), sigmas=s.sigmas.numpy(), noisy=out.numpy())
+    print("forward-process fixtures written:", flavour)
+
+
 def _ref_functions(path, names):
     """exec the named top-level function definitions of a reference file that cannot be imported as a whole (it pulls in
     the un-vendored diffusers package), from where the file lies -- nothing is copied into the repo."""
@@ -494,8 +528,8 @@ def gen_flux_rollout():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:
-        {"sd": gen_sd, "flux": gen_flux, "flux_rollout": gen_flux_rollout}[sys.argv[1]]()
+        {"sd": gen_sd, "flux": gen_flux, "flux_rollout": gen_flux_rollout, "forward_process": gen_forward_process}[sys.argv[1]]()
     else:
-        for fl in ("sd", "flux", "flux_rollout"):
+        for fl in ("sd", "flux", "flux_rollout", "forward_process"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), fl])
         os.system(f"ls -la {OUT}")

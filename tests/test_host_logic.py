@@ -230,3 +230,22 @@ def test_flux_driver_host_logic(tmp_path):
     assert gf.ensure_unique_path(str(f)).endswith("edited_image_1.jpg")
     (tmp_path / "edited_image_1.jpg").write_text("x")
     assert gf.ensure_unique_path(str(f)).endswith("edited_image_2.jpg")
+
+
+def test_forward_process_members_vs_reference(golden):
+    """row a6: PPOScheduler.add_noise (scheduler_ppo.py:336-358) and FMPPOScheduler.scale_noise (edit_ppo/scheduler_fmppo.py:457-484)
+    against the imported reference (oracle/make_golden.py forward_process).  Plain table look-ups + torch elementwise on the caller's
+    tensors (not on the sampling path), so they run on CPU tensors too."""
+    import consolver_amd
+    g = golden["forward_process_sd"]
+    s = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
+                                   order_dim=4, scaler_dim=0, factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+    out = s.add_noise(torch.from_numpy(g["x"]), torch.from_numpy(g["noise"]), torch.from_numpy(g["t"]))
+    np.testing.assert_allclose(out.numpy(), g["noisy"], rtol=1e-6, atol=1e-7)
+    g = golden["forward_process_flux"]
+    f = consolver_amd.FMPPOScheduler(shift=3.0, use_dynamic_shifting=True, order_dim=2, scaler_dim=0, mu_dim=0,
+                                     factor_net_kwargs=dict(hidden_dim=8, num_actions=3))
+    f.set_timesteps(sigmas=np.linspace(1.0, 1 / 6, 6), mu=1.15)
+    np.testing.assert_allclose(f.sigmas.numpy(), g["sigmas"], rtol=2e-7)
+    out = f.scale_noise(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["noise"]))
+    np.testing.assert_allclose(out.numpy(), g["noisy"], rtol=1e-6, atol=1e-7)
