@@ -72,39 +72,35 @@ def denoise_diffusion(scheduler, pipe, noise, text, image, cfg=2.5, num_inferenc
     scheduler.set_timesteps(sigmas=sigmas, mu=mu, device=device)
     timesteps = scheduler.timesteps
 
-    native = getattr(pipe.transformer, "is_consolver_hip", False)
-    conds_ = dict(x=[], epsilon=[])
-    actions_, probs_, masks_ = [], [], []
+    dit = pipe.transformer
+    native = getattr(dit, "is_consolver_hip", False)
+    # trajectory records of the steps i > 0 (:152-157), one list per field
+    rec = {"x": [], "epsilon": [], "probs": [], "actions": [], "masks": []}
     record_prev = getattr(scheduler, "record_conds", None)
     if record_prev is not None and not use_naive_scheduler:
         scheduler.record_conds = True           # conds['epsilon'] is materialised only for the rollout
     # t.expand(B).to(dtype) / 1000 for every step at once: the per-step scalar stays a device slice (no host sync)
     ts_model = timesteps.to(dtype) / 1000
     latents = initial_latents
-    L_lat = latents.size(1)
+    n_lat_tokens = latents.size(1)
+    common = dict(guidance=guidance, pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds, txt_ids=text_ids,
+                  img_ids=latent_ids, return_dict=False)
     try:
         for i, t in enumerate(timesteps):
-            timestep = ts_model[i].expand(batch_size)
+            t_in = ts_model[i].expand(batch_size)
             if native and image_latents is not None:
-                noise_pred = pipe.transformer(hidden_states=latents, timestep=timestep, guidance=guidance,
-                                              pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds,
-                                              txt_ids=text_ids, img_ids=latent_ids, return_dict=False, image_latents=image_latents)[0]
+                # [latents | image_latents] read in place; the prediction comes back for the latent rows only
+                velocity = dit(hidden_states=latents, timestep=t_in, image_latents=image_latents, **common)[0]
+            elif image_latents is not None:
+                velocity = dit(hidden_states=torch.cat([latents, image_latents], dim=1), timestep=t_in, **common)[0][:, :n_lat_tokens]
             else:
-                latent_model_input = torch.cat([latents, image_latents], dim=1) if image_latents is not None else latents
-                noise_pred = pipe.transformer(hidden_states=latent_model_input, timestep=timestep, guidance=guidance,
-                                              pooled_projections=pooled_prompt_embeds, encoder_hidden_states=prompt_embeds,
-                                              txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
-                noise_pred = noise_pred[:, :L_lat]
-            if use_naive_scheduler:
-                latents = scheduler.step(noise_pred, t, latents, return_dict=False)[0]
-            else:
-                latents, actions, probs, conds, masks = scheduler.step(noise_pred, t, latents, return_dict=False)
-                if i > 0:
-                    conds_["x"].append(conds["x"].unsqueeze(1))
-                    conds_["epsilon"].append(conds["epsilon"].unsqueeze(1))
-                    probs_.append(probs.unsqueeze(1))
-                    actions_.append(actions.unsqueeze(1))
-                    masks_.append(masks.unsqueeze(1))
+                velocity = dit(hidden_states=latents, timestep=t_in, **common)[0]
+            stepped = scheduler.step(velocity, t, latents, return_dict=False)
+            latents = stepped[0]
+            if not use_naive_scheduler and i > 0:
+                _, actions, probs, conds, masks = stepped
+                for key, val in (("x", conds["x"]), ("epsilon", conds["epsilon"]), ("probs", probs), ("actions", actions), ("masks", masks)):
+                    rec[key].append(val.unsqueeze(1))
     finally:
         if record_prev is not None:
             scheduler.record_conds = record_prev
@@ -118,5 +114,6 @@ def denoise_diffusion(scheduler, pipe, noise, text, image, cfg=2.5, num_inferenc
 
     if use_naive_scheduler:
         return latents_output, pred_images
-    conds_ = {k: torch.cat(v, dim=1) for k, v in conds_.items()}
-    return latents_output, pred_images, conds_, torch.cat(probs_, dim=1), torch.cat(actions_, dim=1), torch.cat(masks_, dim=1)
+    stacked = {key: torch.cat(vals, dim=1) for key, vals in rec.items()}
+    return (latents_output, pred_images, {"x": stacked["x"], "epsilon": stacked["epsilon"]}, stacked["probs"], stacked["actions"],
+            stacked["masks"])
