@@ -2,7 +2,8 @@
 oracle restatement (parity unpinned w.r.t. diffusers, see oracle/flux_oracle.py).
 
 Tolerance: bf16 storage (8-bit mantissa, eps 3.9e-3) of every activation through the blocks -> relative L2 of the
-velocity output <= 3e-2 for the reduced model in bf16, <= 6e-3 in f16 (stated here: looser than the solver gate)."""
+velocity output 4.9e-3 (reduced model) / 5.3e-3 (full width, 2 + 4 blocks) in bf16 and 6.1e-4 in f16, gated at measured + ~50 %
+(stated here: looser than the solver gate, which applies to the update given identical model outputs)."""
 import os
 
 import numpy as np
@@ -173,7 +174,7 @@ def test_layout_helpers_roundtrip():
     assert ids.shape == (24, 3) and ids[7].tolist() == [1.0, 1.0, 1.0] and ids[-1].tolist() == [1.0, 3.0, 5.0]
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 3e-2), (torch.float16, 6e-3)])
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 7.5e-3), (torch.float16, 1.0e-3)])      # measured 4.9e-3 / 6.1e-4 (+ ~50 %)
 def test_reduced_flux_dit_matches_oracle(dt, tol):
     cfg = dict(SMALL, dtype=dt)
     m = HipFluxTransformer2DModel(cfg, device=DEV)
@@ -225,7 +226,7 @@ def test_full_width_flux_dit_matches_oracle():
     want = FluxOracle(sd, m.config)(torch.cat([lat, img], 1).float(), t, guidance, pooled.float(), enc.float(), txt_ids, ids)[:, :Lq]
     err = rel_l2(got.float(), want)
     print("full-width flux (2 + 4 blocks, bf16) rel l2", err)
-    assert got.shape == (B, Lq, 64) and torch.isfinite(got.float()).all() and err < 3e-2, err
+    assert got.shape == (B, Lq, 64) and torch.isfinite(got.float()).all() and err < 8e-3, err      # measured 5.3e-3
 
 
 def test_flux_edit_loop_with_fmppo_scheduler():
@@ -462,7 +463,7 @@ def test_flux_rollout_on_hip_components_vs_oracle():
     e_lat = rel_l2(lat.float(), torch.from_numpy(lat_o))
     e_eps = rel_l2(conds["epsilon"].float(), torch.from_numpy(conds_o["epsilon"]))
     print("flux rollout (reduced DiT, bf16) vs oracle: latents", e_lat, "conds.epsilon", e_eps)
-    assert e_lat < 2e-2 and e_eps < 3e-2, (e_lat, e_eps)          # the bf16 DiT's own tolerance (test_reduced_flux_dit_matches_oracle: 3e-2)
+    assert e_lat < 7e-3 and e_eps < 8.5e-3, (e_lat, e_eps)        # measured 4.6e-3 / 5.6e-3: the bf16 DiT's own per-forward error level
 
     # ---- in-place joint input == materialised cat + slice
     t = torch.full((B,), 0.9567, device=DEV)
