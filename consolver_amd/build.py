@@ -20,6 +20,7 @@ SOURCES = {
     "solver.hip": ["-ffp-contract=off"],   # torch-like separate mul/add roundings
     "igemm.hip": [],
     "attention.hip": [],
+    "xattn.hip": [],
     "norm.hip": [],
     "misc.hip": [],
     "gemm2.hip": [],

@@ -54,6 +54,16 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s);
 
 int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s);
 
+// fused cross-attention sub-block (xattn.hip): out = h + to_out(softmax(scale * to_q(LayerNorm(h)) K^T) V) + bo; C = 320, 8 heads, Nk <= 80
+struct XattnArgs {
+    const f16* h; f16* out;                 // [M][C]; out may alias h
+    const f16* ln_g; const f16* ln_b; float ln_eps;
+    const f16* wq; const f16* wo; const f16* bo;
+    const f16* kv;                          // [M / HW samples][Nk][2 C]: K | V projections of the text context
+    int M, HW, Nk, C, heads; float scale;
+};
+int launch_xattn_block(const XattnArgs& a, hipStream_t s);
+
 // timestep sinusoid (flip_sin_to_cos, shift 0) -> Linear -> SiLU -> Linear -> SiLU (the SiLU that
 // every resnet applies before time_emb_proj) ; out_silu [Bt][D] fp16
 int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, const f16* b1, const f16* w2, const f16* b2,

@@ -6,6 +6,7 @@
 extern int g_tune_halo;
 extern int g_tune_debug;
 extern int g_tune_cfg_share;
+extern int g_tune_xattn_fused;
 extern int g_tune_conv_sched;
 extern int g_tune_attn_prio;
 extern int g_tune_gemm_stag;
@@ -20,6 +21,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
+    if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
     if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
     if (!strcmp(key, "gemm_stag")) { g_tune_gemm_stag = value; return CS_OK; }
@@ -49,6 +51,15 @@ int cs_op_linear(const void* x, int M, int K, const void* w, const void* bias, i
     a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out; a.geglu = geglu;
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
     return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_xattn_block(const void* h, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv, int Nk,
+                      const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* stream) {
+    XattnArgs a{};
+    a.h = (const f16*)h; a.out = (f16*)out; a.ln_g = (const f16*)ln_gamma; a.ln_b = (const f16*)ln_beta; a.ln_eps = ln_eps;
+    a.wq = (const f16*)wq; a.wo = (const f16*)wo; a.bo = (const f16*)bo; a.kv = (const f16*)kv;
+    a.M = M; a.HW = HW; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = scale;
+    return launch_xattn_block(a, (hipStream_t)stream);
 }
 
 int cs_op_geglu_pack(const void* w_host, const void* b_host, int Hd, int K, void* w_out_host, void* b_out_host) {

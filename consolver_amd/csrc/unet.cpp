@@ -24,6 +24,7 @@
 #include <cstring>
 #include <cmath>
 
+int g_tune_xattn_fused = 0;    // 1: the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip)
 int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
 
 namespace {
@@ -332,6 +333,16 @@ struct Run {
         launch(cross ? P_ATTN_CROSS : P_ATTN_SELF, fl, 2.0 * B * ((double)Nq * C * 2 + (double)Nk * C * 2), [&] { return launch_attention(a, s); });
     }
 
+    // fused LN2 -> to_q -> cross attention -> to_out + residual (xattn.hip); h_in may equal h_out
+    bool xattn_fusable(const Xformer& X, int HW) const { return g_tune_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
+    void xattn_fused(const Xformer& X, const f16* h_in, f16* h_out, const f16* kvl, int HW) {
+        XattnArgs a{};
+        a.h = h_in; a.out = h_out; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
+        a.M = B * HW; a.HW = HW; a.Nk = u->cfg.ctx_len; a.C = X.c; a.heads = u->cfg.num_heads; a.scale = 1.0f / sqrtf((float)(X.c / u->cfg.num_heads));
+        const double M = (double)B * HW, fl = 4.0 * M * X.c * X.c + 4.0 * M * u->cfg.ctx_len * X.c;
+        launch(P_ATTN_CROSS, fl, 2.0 * (3.0 * M * X.c), [&] { return launch_xattn_block(a, s); });
+    }
+
     // x: [B,HW,Cx] (+ optional skip [B,HW,Cs]) -> new tensor [B,HW,Cout]
     f16* resnet(const Resnet& r, const f16* x, int cx, const f16* skip, int cs, int H, int W) {
         const int HW = H * W; const size_t M = (size_t)B * HW;
@@ -366,13 +377,17 @@ struct Run {
         release(qkv);
         linear(g, M, C, X.wo1, X.bo1, C, h, h, 0);
         // cross attention (K/V of the text context are cached in kv)
-        layer_norm(X.ln2, h, M, g);
-        f16* q = alloc((size_t)M * C);
-        linear(g, M, C, X.wq2, nullptr, C, nullptr, q, 0);
         const f16* kvl = kv + X.kv_off * (size_t)B * L;
-        attention(true, q, C, kvl, 2 * C, kvl + C, 2 * C, g, C, HW, L, C);
-        release(q);
-        linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
+        if (xattn_fusable(X, HW)) {
+            xattn_fused(X, h, h, kvl, HW);
+        } else {
+            layer_norm(X.ln2, h, M, g);
+            f16* q = alloc((size_t)M * C);
+            linear(g, M, C, X.wq2, nullptr, C, nullptr, q, 0);
+            attention(true, q, C, kvl, 2 * C, kvl + C, 2 * C, g, C, HW, L, C);
+            release(q);
+            linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
+        }
         // feed forward (GEGLU fused into the first GEMM's epilogue)
         layer_norm(X.ln3, h, M, g);
         f16* ff = alloc((size_t)M * 4 * C);
@@ -419,23 +434,35 @@ f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, 
     R.attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g1, C, HW, HW, C);
     R.release(qkv);
     R.linear(g1, M1, C, X.wo1, X.bo1, C, h1, h1, 0);
-    R.layer_norm(X.ln2, h1, M1, g1);
-    f16* q = R.alloc((size_t)M1 * C);
-    R.linear(g1, M1, C, X.wq2, nullptr, C, nullptr, q, 0);
-    R.release(g1);
-    // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
-    f16* h = R.alloc((size_t)M * C);
-    f16* g = R.alloc((size_t)M * C);
     const f16* kvl = R.kv + X.kv_off * (size_t)Bfull * L;
-    for (int half = 0; half < 2; ++half) {
-        if (!R.dry && R.rc == CS_OK)
-            hipMemcpyAsync(h + (size_t)half * M1 * C, h1, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
-        const f16* kvh = kvl + (size_t)half * n_lat * L * 2 * C;
-        R.attention(true, q, C, kvh, 2 * C, kvh + C, 2 * C, g + (size_t)half * M1 * C, C, HW, L, C);
+    f16 *h, *g;
+    if (R.xattn_fusable(X, HW)) {
+        // the fused sub-block reads the shared residual stream and writes each half's own copy: no duplication copy, LN2 / to_q run per half
+        R.release(g1);
+        h = R.alloc((size_t)M * C);
+        g = R.alloc((size_t)M * C);
+        for (int half = 0; half < 2; ++half)
+            R.xattn_fused(X, h1, h + (size_t)half * M1 * C, kvl + (size_t)half * n_lat * L * 2 * C, HW);
+        R.release(h1);
+        R.B = Bfull;
+    } else {
+        R.layer_norm(X.ln2, h1, M1, g1);
+        f16* q = R.alloc((size_t)M1 * C);
+        R.linear(g1, M1, C, X.wq2, nullptr, C, nullptr, q, 0);
+        R.release(g1);
+        // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
+        h = R.alloc((size_t)M * C);
+        g = R.alloc((size_t)M * C);
+        for (int half = 0; half < 2; ++half) {
+            if (!R.dry && R.rc == CS_OK)
+                hipMemcpyAsync(h + (size_t)half * M1 * C, h1, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+            const f16* kvh = kvl + (size_t)half * n_lat * L * 2 * C;
+            R.attention(true, q, C, kvh, 2 * C, kvh + C, 2 * C, g + (size_t)half * M1 * C, C, HW, L, C);
+        }
+        R.release(q); R.release(h1);
+        R.B = Bfull;
+        R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
     }
-    R.release(q); R.release(h1);
-    R.B = Bfull;
-    R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
     R.layer_norm(X.ln3, h, M, g);
     f16* ff = R.alloc((size_t)M * 4 * C);
     R.linear(g, M, C, X.wff1, X.bff1, 8 * C, nullptr, ff, 1);
@@ -645,15 +672,22 @@ int cs_unet_finalize(CsUNet* u) {
 size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || batch <= 0) return 0;
-    run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
-    size_t peak = u->arena.peak;
-    if (batch % 2 == 0) {       // the CFG shared-prefix path allocates differently: take the larger peak (whatever the knob says now)
-        const int knob = g_tune_cfg_share;
-        g_tune_cfg_share = 1;
-        run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
-        g_tune_cfg_share = knob;
-        if (u->arena.peak > peak) peak = u->arena.peak;
+    // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
+    // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
+    size_t peak = 0;
+    const int knob_share = g_tune_cfg_share, knob_fused = g_tune_xattn_fused;
+    for (int fused = 0; fused < 2; ++fused) {
+        g_tune_xattn_fused = fused;
+        run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
+        peak = std::max(peak, u->arena.peak);
+        if (batch % 2 == 0) {
+            g_tune_cfg_share = 1;
+            run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+            peak = std::max(peak, u->arena.peak);
+            g_tune_cfg_share = knob_share;
+        }
     }
+    g_tune_xattn_fused = knob_fused;
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;
 }
 

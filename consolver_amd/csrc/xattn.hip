@@ -1,0 +1,349 @@
+// Fused cross-attention sub-block of the SD1.5 transformer block at C = 320 (8 heads x 40), the 64 x 64 level:
+//
+//     h_out = h + to_out( softmax(scale * to_q(LayerNorm2(h)) K^T) V ) + b_out        (K, V: the cached projections of the <= 80 text keys)
+//
+// replaces four kernels of the unfused executor (ln_kernel, gemm_big to_q, attn_kernel with 77 keys, gemm_big to_out + residual) whose
+// only job besides ~54 MFLOP per 128 rows is to move three [M, 320] intermediates through HBM (LayerNorm output, q, attention output:
+// 6 x 84 MB per block at batch 32).  Here a workgroup owns 128 token rows and keeps all three in LDS:
+//
+//   phase 0  rows -> registers -> LayerNorm (fp32 statistics, two-pass variance) -> fp16 tile XT in LDS, in the k-block layout the
+//            GEMM fragment reads want: [5 blocks of 64 columns][128 rows][128 B], 16-byte chunk index XOR (row >> 1) & 7;
+//            the V rows of the sample go to LDS in the same phase ([96 key rows][672 B], rows >= Nk zero);
+//   phase 1  q = XT Wq^T : ten k32 steps, 8 waves as 2 (rows) x 4 (columns), wave tile 64 x 80; the weight fragments come STRAIGHT from
+//            global / L2 into registers (a weight row's 8 consecutive k are one 16-byte load in MFMA A layout), two steps ahead of
+//            their MFMAs - no LDS stage, no barrier inside the k loop (a first version staged Wq by LDS-DMA: 5 barriers + DMA waits per
+//            GEMM for 40 MFMAs each); accumulators -> fp16 (rounded as stored q, then pre-scaled by scale * log2 e and rounded again,
+//            the unfused kernels' two rounding points) -> written over XT;
+//   phase 2  (K stays in global / L2 too: a key row's 8 consecutive channels are one 16-byte load in MFMA A layout);
+//   phase 3  each wave takes 16 query rows and loops over the 8 heads: S^T = K Q^T (10 MFMAs), masked softmax over <= 80 keys in
+//            registers, O^T = V^T P^T (9 MFMAs, V^T through the transposing LDS read), normalised O -> fp16 -> written over the
+//            head's q columns of XT (dead by then);
+//   phase 3' K fragments of the NEXT head are loaded while the current head computes;
+//   phase 4  out = XT Wo^T as phase 1, + bias -> fp16 -> LDS patch -> + residual (h re-read, L2-hot) -> fp16 -> 640-byte row stores.
+//
+// LDS: XT 80 KB + V tile 63 KB; the epilogue patch reuses XT.
+// The arithmetic class (fp16 storage points, fp32 accumulation) is the unfused path's; the softmax here subtracts the true row maximum
+// (the unfused kernel's max-free steady state is for thousands of keys).
+#include "ops.h"
+
+extern int g_tune_debug;
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) hf4* lds_hf4_ptr;
+__device__ __forceinline__ u32x2 tr_read(const char* lds_addr) {
+    hf4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_hf4_ptr)lds_addr);
+    union { hf4 a; u32x2 b; } u; u.a = r;
+    return u.b;
+}
+__device__ __forceinline__ unsigned pk(float a, float b) { union { f16x2 v; unsigned u; } x; x.v = f16x2{(f16)a, (f16)b}; return x.u; }
+__device__ __forceinline__ f16x8 frag_of(u32x4 v) { union { u32x4 u; f16x8 f; } x; x.u = v; return x.f; }
+
+struct XattnParams {
+    const f16* h;        // [M_in rows][320] block input (residual stream)
+    f16* out;            // [M rows][320]; may alias h
+    const f16* ln_g; const f16* ln_b; float ln_eps;
+    const f16* wq;       // [320][320]
+    const f16* wo; const f16* bo;
+    const f16* kv;       // [B][Nk][640]: k = cols 0..319, v = cols 320..639
+    int M, HW, Nk;       // rows of this launch, rows per sample, keys (<= 80)
+    float c;             // scale * log2(e)
+    int debug;           // timing experiments only (results wrong): bit 0 skip the attention phase, 1 skip the to_out GEMM, 2 skip the to_q GEMM,
+                         // 3 skip the LayerNorm phase's loads, 4 skip the epilogue's residual loads and stores
+};
+
+constexpr int C = 320, DH = 40, NH = 8, TM = 128;
+constexpr int XT_BYTES = 5 * TM * 128;            // 81920
+constexpr int VS = 672, VROWS = 96;               // V tile row stride (odd multiple of 32 B), rows incl. zero padding
+constexpr int PROW = 656;                         // epilogue patch row stride (bytes)
+
+__device__ __forceinline__ int xt_addr(int row, int col) {      // byte address of element (row, col) in XT (col multiple of 4 for 8-byte access)
+    return (col >> 6) * (TM * 128) + row * 128 + ((((col & 63) >> 3) ^ ((row >> 1) & 7)) << 4) + ((col & 7) << 1);
+}
+
+// max / sum over the lanes {l, l ^ 16, l ^ 32, l ^ 48} with the gfx950 permlane swaps (pure VALU, no LDS round trip)
+__device__ __forceinline__ float group_max(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    u = __float_as_uint(v);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// out-tile GEMM: acc[i][j] (n-tile i of the wave's 80 columns, m-tile j of its 64 rows) = XT(rows) . W^T, K = 320.
+// Activations from XT (LDS), weights straight from global in MFMA A layout, fetched two k32 steps ahead; no barrier.
+__device__ __forceinline__ void gemm_320(const f16* __restrict__ w, const char* XT, int lane, int wm, int wn, f32x4 (&acc)[5][4]) {
+    const int g = lane >> 4, i16 = lane & 15;
+    const f16* wrow = w + (size_t)(wn * 80 + i16) * C + 8 * g;           // + i * 16 rows, + step * 32 columns
+    u32x4 wf[3][5];
+    auto fetch = [&](int step, u32x4 (&dst)[5]) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) dst[i] = *reinterpret_cast<const u32x4*>(wrow + (size_t)i * 16 * C + step * 32);
+    };
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0, wf[0]);
+    fetch(1, wf[1]);
+    const int swz = (lane >> 1) & 7;
+#pragma unroll
+    for (int step = 0; step < 10; ++step) {
+        if (step + 2 < 10) fetch(step + 2, wf[(step + 2) % 3]);
+        const int kt = step >> 1, ks = step & 1;
+        const char* ta = XT + kt * (TM * 128) + (wm * 64) * 128 + i16 * 128 + (((ks * 4 + g) ^ swz) << 4);
+        f16x8 fa[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_of(wf[step % 3][i]), fa[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const XT = smem;
+    char* const VT = smem + XT_BYTES;               // V tile [96][672 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int m_blk = blockIdx.x * TM;
+    const int b = m_blk / p.HW;                      // the tile lies inside one sample (HW % 128 == 0)
+
+    // ---------------- phase 0: V rows -> LDS, LayerNorm of the wave's 16 rows -> XT ------------------------------------------------
+    {
+        // V of sample b: 96 x 40 chunks, 7.5 per thread: all loads first, then the LDS writes (rows >= Nk and the pad chunks: zero)
+        const f16* vsrc = p.kv + (size_t)b * p.Nk * (2 * C) + C;
+        u32x4 vt[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;      // 42 chunks per LDS row: 40 data + 2 pad
+            vt[k] = u32x4{0, 0, 0, 0};
+            if (id < VROWS * 42 && row < p.Nk && ch < 40) vt[k] = *reinterpret_cast<const u32x4*>(vsrc + (size_t)row * (2 * C) + ch * 8);
+        }
+        const bool act = lane < 40;                  // 40 chunks of 8 channels per row
+        f16x8 raw[16];                                // all 16 rows of the wave in flight at once: one memory round trip
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int m = m_blk + 16 * w + u;
+            raw[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (act && m < p.M && !(p.debug & 8)) raw[u] = *reinterpret_cast<const f16x8*>(p.h + (size_t)m * C + lane * 8);
+        }
+        float gam[8], bet[8];
+        if (act) {
+            const f16x8 gv = *reinterpret_cast<const f16x8*>(p.ln_g + lane * 8), bv = *reinterpret_cast<const f16x8*>(p.ln_b + lane * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gam[k] = (float)gv[k]; bet[k] = (float)bv[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;
+            if (id < VROWS * 42) *reinterpret_cast<u32x4*>(VT + row * VS + ch * 16) = vt[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float v[8];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = (float)raw[u][k]; s += v[k]; }
+            const float mean = wave_sum(s) * (1.0f / C);
+            float q = 0.f;
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[k] - mean; q += d * d; }
+            }
+            const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + p.ln_eps);
+            if (act) {
+                const int row = 16 * w + u;
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = pk((v[2 * k] - mean) * rstd * gam[2 * k] + bet[2 * k], (v[2 * k + 1] - mean) * rstd * gam[2 * k + 1] + bet[2 * k + 1]);
+                *reinterpret_cast<u32x4*>(XT + xt_addr(row, lane * 8)) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 1: q = LN(h) Wq^T -> XT (fp16, pre-scaled) ------------------------------------------------
+    f32x4 acc[5][4];
+    if (!(p.debug & 4)) gemm_320(p.wq, XT, lane, wm, wn, acc);
+    else { for (int i = 0; i < 5; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+    __syncthreads();                                 // every wave is done reading LN(h) from XT
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = wn * 80 + i * 16 + 4 * g, m = wm * 64 + j * 16 + i16;
+            float qv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qv[r] = (float)(f16)acc[i][j][r] * p.c;      // q as the unfused path stores it, then scaled
+            *reinterpret_cast<u32x2*>(XT + xt_addr(m, n)) = u32x2{pk(qv[0], qv[1]), pk(qv[2], qv[3])};
+        }
+    __syncthreads();
+
+    // ---------------- phase 3: attention, 16 queries per wave, heads in sequence ------------------------------------------------
+    if (!(p.debug & 1)) {
+        const f16* kbase = p.kv + (size_t)b * p.Nk * (2 * C);
+        const int qrow = 16 * w + i16;
+        auto load_k = [&](int hd, u32x4 (&kf)[5][2]) {
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                const int key = kt * 16 + i16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 t = {0, 0, 0, 0};
+                    if (key < p.Nk && (ks == 0 || g == 0))
+                        t = *reinterpret_cast<const u32x4*>(kbase + (size_t)key * (2 * C) + hd * DH + ks * 32 + 8 * g);
+                    kf[kt][ks] = t;
+                }
+            }
+        };
+        u32x4 kf[5][2];
+        load_k(0, kf);
+#pragma unroll
+        for (int hd = 0; hd < NH; ++hd) {
+            // Q fragments of this head (B operand: lane = query column, k = 8 g + j)
+            f16x8 qf[2];
+            {
+                const int c0 = hd * DH + 8 * g;                               // ks = 0: channels 0..31 of the head
+                qf[0] = *reinterpret_cast<const f16x8*>(XT + xt_addr(qrow, c0));
+                u32x4 z = {0, 0, 0, 0};
+                if (g == 0) z = *reinterpret_cast<const u32x4*>(XT + xt_addr(qrow, hd * DH + 32));
+                qf[1] = frag_of(z);
+            }
+            f32x4 s[5];
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt) {
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_of(kf[kt][0]), qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_of(kf[kt][1]), qf[1], s[kt], 0, 0, 0);
+            }
+            if (hd + 1 < NH) load_k(hd + 1, kf);                              // next head's K while this head's softmax / P V run
+            // masked softmax over the keys of query i16 (lane holds keys kt*16 + 4g + r)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kt * 16 + 4 * g + r >= p.Nk) s[kt][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            mx = group_max(mx);
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; l += e; }
+            l = group_sum(l);
+            // P fragments (B operand of the second product; MFMA k index 8g + j <-> key t2*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4))
+            f16x8 pf[3];
+#pragma unroll
+            for (int t2 = 0; t2 < 3; ++t2) {
+                u32x4 f;
+                f[0] = pk(s[2 * t2][0], s[2 * t2][1]); f[1] = pk(s[2 * t2][2], s[2 * t2][3]);
+                if (2 * t2 + 1 < 5) { f[2] = pk(s[2 * t2 + 1][0], s[2 * t2 + 1][1]); f[3] = pk(s[2 * t2 + 1][2], s[2 * t2 + 1][3]); }
+                else { f[2] = 0; f[3] = 0; }
+                pf[t2] = frag_of(f);
+            }
+            f32x4 o[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) o[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t2 = 0; t2 < 3; ++t2)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const char* addr = VT + (32 * t2 + 4 * g + (i16 >> 2)) * VS + (hd * DH + a * 16 + 4 * (i16 & 3)) * 2;
+                    const u32x2 lo = tr_read(addr);
+                    const u32x2 hi = tr_read(addr + 16 * VS);
+                    o[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_of(u32x4{lo[0], lo[1], hi[0], hi[1]}), pf[t2], o[a], 0, 0, 0);
+                }
+            // O^T: lane holds channels a*16 + 4g + r of query i16 -> fp16 over the head's (consumed) q columns
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int d = a * 16 + 4 * g;
+                if (d < DH)
+                    *reinterpret_cast<u32x2*>(XT + xt_addr(qrow, hd * DH + d)) = u32x2{pk(o[a][0] * inv, o[a][1] * inv), pk(o[a][2] * inv, o[a][3] * inv)};
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 4: out = O Wo^T + bias + h ------------------------------------------------------------------------------------
+    if (!(p.debug & 2)) gemm_320(p.wo, XT, lane, wm, wn, acc);
+    __syncthreads();                                 // every wave is done reading O from XT: it becomes the epilogue patch
+    {
+        char* const patch = smem;                    // [128 rows][PROW]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int n = wn * 80 + i * 16 + 4 * g;
+            const f16x4 bv = *reinterpret_cast<const f16x4*>(p.bo + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = wm * 64 + j * 16 + i16;
+                *reinterpret_cast<u32x2*>(patch + m * PROW + n * 2) =
+                    u32x2{pk(acc[i][j][0] + (float)bv[0], acc[i][j][1] + (float)bv[1]), pk(acc[i][j][2] + (float)bv[2], acc[i][j][3] + (float)bv[3])};
+            }
+        }
+        __syncthreads();
+        // 128 rows x 40 chunks = 5120 items, 10 per thread: all residual loads of the thread first, then the patch reads, then the stores
+        f16x8 res[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
+            res[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < p.M && !(p.debug & 16)) res[k] = *reinterpret_cast<const f16x8*>(p.h + (size_t)m * C + ch * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(patch + row * PROW + ch * 16);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)((float)v[e] + (float)res[k][e]);
+            if (m < p.M && !(p.debug & 16)) *reinterpret_cast<f16x8*>(p.out + (size_t)m * C + ch * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
+    if (!a.h || !a.out || !a.ln_g || !a.ln_b || !a.wq || !a.wo || !a.bo || !a.kv) CS_FAIL(CS_E_ARG, "xattn_block: null pointer");
+    if (a.C != 320 || a.heads != 8) CS_FAIL(CS_E_UNSUPPORTED, "xattn_block: built for C = 320, 8 heads (got C = %d, heads = %d)", a.C, a.heads);
+    if (a.Nk < 1 || a.Nk > 80) CS_FAIL(CS_E_SHAPE, "xattn_block: 1 <= Nk <= 80 (got %d)", a.Nk);
+    if (a.HW % TM) CS_FAIL(CS_E_SHAPE, "xattn_block: rows per sample must be a multiple of %d", TM);
+    if (a.M <= 0) return a.M < 0 ? CS_E_SHAPE : CS_OK;
+    if (a.M % a.HW) CS_FAIL(CS_E_SHAPE, "xattn_block: M must be a whole number of samples");
+    XattnParams p;
+    p.h = a.h; p.out = a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
+    p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = g_tune_debug;
+    constexpr size_t lds = (XT_BYTES + VROWS * VS > TM * PROW) ? XT_BYTES + VROWS * VS : TM * PROW;      // 146432
+    static bool configured = false;
+    if (!configured) {
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL(xattn_block_kernel, dim3(a.M / TM), dim3(512), lds, s, p);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

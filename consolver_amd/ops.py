@@ -103,6 +103,19 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return out
 
 
+def xattn_block(h, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None, out=None):
+    """fused cross-attention sub-block: out = h + to_out(softmax(scale q k^T) v) with q = LayerNorm(h) wq^T; h [M, C] (M = samples * hw rows),
+    kv [samples, Nk, 2C] = (K | V) projections of the context.  C = 320, 8 heads, Nk <= 80."""
+    _f16(h, "h")
+    M, Cc = h.shape
+    hw = hw or M // kv.shape[0]
+    if out is None:
+        out = torch.empty_like(h)
+    L.check(L.lib().cs_op_xattn_block(L.ptr(h), L.ptr(ln_gamma), L.ptr(ln_beta), float(eps), L.ptr(wq), L.ptr(kv), kv.shape[1], L.ptr(wo),
+                                      L.ptr(bo), M, hw, Cc, heads, float((Cc // heads) ** -0.5), L.ptr(out), L.stream_ptr(h.device)))
+    return out
+
+
 def set_tuning(key, value):
     """kernel-selection knob, e.g. set_tuning("conv_halo", 2) forces the halo-resident conv3x3 kernel."""
     L.check(L.lib().cs_set_tuning(key.encode(), int(value)))

@@ -48,6 +48,13 @@ size_t cs_op_group_norm_workspace(int B, int C);
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,
                      const void* gamma, const void* beta, void* workspace, void* out, void* stream);
 
+/* Fused cross-attention sub-block of the SD1.5 transformer block (diffusers BasicTransformerBlock: norm2 -> attn2 -> residual; reference
+ * call site denoise_ppo.py:89-94) at C = 320, 8 heads, <= 80 context keys:
+ *   out[M,C] = h + (softmax(scale * (LayerNorm(h) wq^T) K^T) V) wo^T + bo,   kv[M/HW][Nk][2C] = (K | V) projections of the context.
+ * One kernel instead of LayerNorm + to_q GEMM + attention + to_out GEMM: the three [M,C] intermediates stay in LDS.  out may alias h. */
+int cs_op_xattn_block(const void* h, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv, int Nk,
+                      const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* stream);
+
 /* LayerNorm over the last dim of x[M,C] */
 int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
 
@@ -98,6 +105,7 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "attn_qt40": query tiles per wave at head dim 40 (2 | 4, default 4);
  *   "conv_sched": halo 3x3 conv wave schedule: -1 auto (default: 2 for the 320 / 256-wide k32 kernels, 0 otherwise), 0 lock-step groups,
  *                1 + static priority for the staggered wave group, 2 + that group's LDS-DMA issues spread among its MFMAs;
+ *   "xattn_fused": 1: the cross-attention sub-block at C = 320 runs as one kernel (cs_op_xattn_block) inside cs_unet_forward;
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "debug":     1 skip the GEMM epilogue, 2 skip its k loop (timing experiments only: results are wrong) */
 int cs_set_tuning(const char* key, int value);

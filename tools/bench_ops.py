@@ -77,6 +77,20 @@ if which in ("gemm2",):
     g2(8192, 3072, 9216, "img qkv"); g2(512, 3072, 9216, "ctx qkv"); g2(8192, 3072, 3072, "img out", gated=True); g2(512, 3072, 3072, "ctx out", gated=True)
     g2(8192, 3072, 12288, "img ff1", act=1); g2(8192, 12288, 3072, "img ff2", gated=True); g2(512, 3072, 12288, "ctx ff1", act=1); g2(512, 12288, 3072, "ctx ff2", gated=True)
     g2(8704, 3072, 9216, "single qkv"); g2(8704, 3072, 12288, "single mlp", act=1); g2(8704, 15360, 3072, "single out", gated=True)
+if which in ("xattn",):
+    # fused cross-attention sub-block at the 64 x 64 level (batch 32) against the four kernels it replaces
+    C, HW, Nk = 320, 4096, 77
+    M = B * HW
+    h = rnd(M, C); gam, bet = rnd(C), rnd(C); wq = rnd(C, C, scale=C ** -0.5); wo = rnd(C, C, scale=C ** -0.5); bo = rnd(C); kv = rnd(B, Nk, 2 * C)
+    fl = 4.0 * M * C * C + 4.0 * M * Nk * C
+    ms = timeit(lambda: ops.xattn_block(h, gam, bet, wq, kv, wo, bo, hw=HW))
+    rows.append(("xattn_block fused L0", M, Nk, C, ms, fl / ms / 1e9))
+    def unfused():
+        ln = ops.layer_norm(h, gam, bet); q = ops.linear(ln, wq)
+        a = ops.attention(q.view(B, HW, C), kv[..., :C], kv[..., C:], 8)
+        return ops.linear(a.view(M, C), wo, bo, res=h)
+    ms = timeit(unfused)
+    rows.append(("LN + to_q + attn + to_out (4 kernels)", M, Nk, C, ms, fl / ms / 1e9))
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
 for r in rows:
     print(f"{r[0]:40s} {r[1]:8d} {r[2]:8d} {r[3]:6d} {r[4]:9.3f} {r[5] / 1e3:9.1f}")
