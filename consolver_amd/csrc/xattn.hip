@@ -8,12 +8,10 @@
 //
 //   phase 0  rows -> registers -> LayerNorm (fp32 statistics, two-pass variance) -> fp16 tile XT in LDS, in the k-block layout the
 //            GEMM fragment reads want: [5 blocks of 64 columns][128 rows][128 B], 16-byte chunk index XOR (row >> 1) & 7;
-//            the V rows of the sample go to LDS in the same phase ([96 key rows][672 B], rows >= Nk zero);
-//   phase 1  q = XT Wq^T : ten k32 steps, 8 waves as 2 (rows) x 4 (columns), wave tile 64 x 80; the weight fragments come STRAIGHT from
-//            global / L2 into registers (a weight row's 8 consecutive k are one 16-byte load in MFMA A layout), two steps ahead of
-//            their MFMAs - no LDS stage, no barrier inside the k loop (a first version staged Wq by LDS-DMA: 5 barriers + DMA waits per
-//            GEMM for 40 MFMAs each); accumulators -> fp16 (rounded as stored q, then pre-scaled by scale * log2 e and rounded again,
-//            the unfused kernels' two rounding points) -> written over XT;
+//            the V rows of the sample are fetched into registers in the same phase and written to LDS after phase 1 ([96 key rows][672 B]);
+//   phase 1  q = XT Wq^T : 5 k64-steps, Wq streamed by LDS-DMA through two 40 KB stages (the first one issued before phase 0), 8 waves as
+//            2 (rows) x 4 (columns), wave tile 64 x 80; accumulators -> fp16 (rounded as stored q, then pre-scaled by scale * log2 e and
+//            rounded again, the unfused kernels' two rounding points) -> written over XT;
 //   phase 2  (K stays in global / L2 too: a key row's 8 consecutive channels are one 16-byte load in MFMA A layout);
 //   phase 3  each wave takes 16 query rows and loops over the 8 heads: S^T = K Q^T (10 MFMAs), masked softmax over <= 80 keys in
 //            registers, O^T = V^T P^T (9 MFMAs, V^T through the transposing LDS read), normalised O -> fp16 -> written over the
@@ -21,7 +19,7 @@
 //   phase 3' K fragments of the NEXT head are loaded while the current head computes;
 //   phase 4  out = XT Wo^T as phase 1, + bias -> fp16 -> LDS patch -> + residual (h re-read, L2-hot) -> fp16 -> 640-byte row stores.
 //
-// LDS: XT 80 KB + V tile 63 KB; the epilogue patch reuses XT.
+// LDS: XT 80 KB + two weight stages 80 KB = 160 KB exactly (one workgroup per CU); the V tile reuses the stages, the epilogue patch XT.
 // The arithmetic class (fp16 storage points, fp32 accumulation) is the unfused path's; the softmax here subtracts the true row maximum
 // (the unfused kernel's max-free steady state is for thousands of keys).
 #include "ops.h"
@@ -60,6 +58,7 @@ struct XattnParams {
 
 constexpr int C = 320, DH = 40, NH = 8, TM = 128;
 constexpr int XT_BYTES = 5 * TM * 128;            // 81920
+constexpr int WST = 320 * 128;                    // 40960 per weight stage
 constexpr int VS = 672, VROWS = 96;               // V tile row stride (odd multiple of 32 B), rows incl. zero padding
 constexpr int PROW = 656;                         // epilogue patch row stride (bytes)
 
@@ -85,36 +84,50 @@ __device__ __forceinline__ float group_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// out-tile GEMM: acc[i][j] (n-tile i of the wave's 80 columns, m-tile j of its 64 rows) = XT(rows) . W^T, K = 320.
-// Activations from XT (LDS), weights straight from global in MFMA A layout, fetched two k32 steps ahead; no barrier.
-__device__ __forceinline__ void gemm_320(const f16* __restrict__ w, const char* XT, int lane, int wm, int wn, f32x4 (&acc)[5][4]) {
-    const int g = lane >> 4, i16 = lane & 15;
-    const f16* wrow = w + (size_t)(wn * 80 + i16) * C + 8 * g;           // + i * 16 rows, + step * 32 columns
-    u32x4 wf[3][5];
-    auto fetch = [&](int step, u32x4 (&dst)[5]) {
+// out-tile GEMM: acc[i][j] (n-tile i of the wave's 80 columns, m-tile j of its 64 rows) = XT(rows) . W^T, K = 320: five k64 steps, the
+// [320 rows][64 k] weight slab of a step staged by LDS-DMA into one of two 40 KB stages (chunk index XOR (row >> 1) & 7), one barrier per
+// step.  (Weights straight from global into registers - no stage, no barrier - were measured too: 49 us per GEMM against 20 us staged;
+// a lane group's 16-byte pieces of 16 different rows make poor vector-memory requests.)
+__device__ __forceinline__ const f16* w_piece_src(const f16* __restrict__ w, int w8, int lane, int j) {
+    const int r = 8 * (w8 + 8 * j) + (lane >> 3);
+    return w + (size_t)r * C + ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+}
+__device__ __forceinline__ void stage_w(const f16* __restrict__ w, char* WS, int w8, int lane, int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) dst[i] = *reinterpret_cast<const u32x4*>(wrow + (size_t)i * 16 * C + step * 32);
-    };
+    for (int j = 0; j < 5; ++j) glds16(w_piece_src(w, w8, lane, j) + kt * 64, WS + buf * WST + (w8 + 8 * j) * 1024);
+}
+template <bool PRESTAGED>
+__device__ __forceinline__ void gemm_320(const f16* __restrict__ w, char* smem, int w8, int lane, int wm, int wn, f32x4 (&acc)[5][4]) {
+    char* const XT = smem;
+    char* const WS = smem + XT_BYTES;
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(0, wf[0]);
-    fetch(1, wf[1]);
     const int swz = (lane >> 1) & 7;
+    if (!PRESTAGED) stage_w(w, WS, w8, lane, 0, 0);   // (PRESTAGED: the caller issued stage 0 before its own work)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < 5; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < 5) stage_w(w, WS, w8, lane, kt + 1, buf ^ 1);
+        const char* ta = XT + kt * (TM * 128) + (wm * 64) * 128;
+        const char* tb = WS + buf * WST + (wn * 80) * 128;
 #pragma unroll
-    for (int step = 0; step < 10; ++step) {
-        if (step + 2 < 10) fetch(step + 2, wf[(step + 2) % 3]);
-        const int kt = step >> 1, ks = step & 1;
-        const char* ta = XT + kt * (TM * 128) + (wm * 64) * 128 + i16 * 128 + (((ks * 4 + g) ^ swz) << 4);
-        f16x8 fa[4];
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = (lane & 15) * 128 + (((ks * 4 + (lane >> 4)) ^ swz) << 4);
+            f16x8 fa[4], fw[5];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048);
+            for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
+            for (int i = 0; i < 5; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + i * 2048 + fo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag_of(wf[step % 3][i]), fa[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 
@@ -129,17 +142,20 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
     const int m_blk = blockIdx.x * TM;
     const int b = m_blk / p.HW;                      // the tile lies inside one sample (HW % 128 == 0)
 
-    // ---------------- phase 0: V rows -> LDS, LayerNorm of the wave's 16 rows -> XT ------------------------------------------------
+    // ---------------- phase 0: LayerNorm of the wave's 16 rows -> XT; the V rows of the sample are fetched alongside ------------------
+    stage_w(p.wq, VT, w, lane, 0, 0);               // Wq's first k-step lands while the LayerNorm runs (VT = the weight stages for now)
+    // V of sample b: 96 rows x 42 chunks (40 data + 2 pad), 8 per thread: loads now, LDS writes after the to_q GEMM has released the stages
+    u32x4 vt[8];
     {
-        // V of sample b: 96 x 40 chunks, 7.5 per thread: all loads first, then the LDS writes (rows >= Nk and the pad chunks: zero)
         const f16* vsrc = p.kv + (size_t)b * p.Nk * (2 * C) + C;
-        u32x4 vt[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;      // 42 chunks per LDS row: 40 data + 2 pad
+            const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;
             vt[k] = u32x4{0, 0, 0, 0};
             if (id < VROWS * 42 && row < p.Nk && ch < 40) vt[k] = *reinterpret_cast<const u32x4*>(vsrc + (size_t)row * (2 * C) + ch * 8);
         }
+    }
+    {
         const bool act = lane < 40;                  // 40 chunks of 8 channels per row
         f16x8 raw[16];                                // all 16 rows of the wave in flight at once: one memory round trip
 #pragma unroll
@@ -154,31 +170,43 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) { gam[k] = (float)gv[k]; bet[k] = (float)bv[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;
-            if (id < VROWS * 42) *reinterpret_cast<u32x4*>(VT + row * VS + ch * 16) = vt[k];
-        }
+        // the 16 rows' reductions run as 16 independent butterflies (a row-at-a-time loop serialised 16 x 2 x 6 dependent cross-lane steps)
+        float mean[16], rstd[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            float v[8];
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { v[k] = (float)raw[u][k]; s += v[k]; }
-            const float mean = wave_sum(s) * (1.0f / C);
+            for (int k = 0; k < 8; ++k) s += (float)raw[u][k];
+            mean[u] = s;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) mean[u] += __shfl_xor(mean[u], o, 64);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            mean[u] *= (1.0f / C);
             float q = 0.f;
             if (act) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const float d = v[k] - mean; q += d * d; }
+                for (int k = 0; k < 8; ++k) { const float d = (float)raw[u][k] - mean[u]; q += d * d; }
             }
-            const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + p.ln_eps);
-            if (act) {
-                const int row = 16 * w + u;
+            rstd[u] = q;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) rstd[u] += __shfl_xor(rstd[u], o, 64);
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float rs = rsqrtf(rstd[u] * (1.0f / C) + p.ln_eps);
                 u32x4 o;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    o[k] = pk((v[2 * k] - mean) * rstd * gam[2 * k] + bet[2 * k], (v[2 * k + 1] - mean) * rstd * gam[2 * k + 1] + bet[2 * k + 1]);
-                *reinterpret_cast<u32x4*>(XT + xt_addr(row, lane * 8)) = o;
+                    o[k] = pk(((float)raw[u][2 * k] - mean[u]) * rs * gam[2 * k] + bet[2 * k],
+                              ((float)raw[u][2 * k + 1] - mean[u]) * rs * gam[2 * k + 1] + bet[2 * k + 1]);
+                *reinterpret_cast<u32x4*>(XT + xt_addr(16 * w + u, lane * 8)) = o;
             }
         }
     }
@@ -186,9 +214,8 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
 
     // ---------------- phase 1: q = LN(h) Wq^T -> XT (fp16, pre-scaled) ------------------------------------------------
     f32x4 acc[5][4];
-    if (!(p.debug & 4)) gemm_320(p.wq, XT, lane, wm, wn, acc);
-    else { for (int i = 0; i < 5; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
-    __syncthreads();                                 // every wave is done reading LN(h) from XT
+    if (!(p.debug & 4)) gemm_320<true>(p.wq, smem, w, lane, wm, wn, acc);       // ends with a barrier: XT and the stages are free
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); for (int i = 0; i < 5; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -199,6 +226,12 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
             for (int r = 0; r < 4; ++r) qv[r] = (float)(f16)acc[i][j][r] * p.c;      // q as the unfused path stores it, then scaled
             *reinterpret_cast<u32x2*>(XT + xt_addr(m, n)) = u32x2{pk(qv[0], qv[1]), pk(qv[2], qv[3])};
         }
+    // ---------------- phase 2: the V rows fetched in phase 0 -> LDS ([96][672 B], rows >= Nk and the pad chunks zero) ---------------
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int id = tid + 512 * k, row = id / 42, ch = id - row * 42;
+        if (id < VROWS * 42) *reinterpret_cast<u32x4*>(VT + row * VS + ch * 16) = vt[k];
+    }
     __syncthreads();
 
     // ---------------- phase 3: attention, 16 queries per wave, heads in sequence ------------------------------------------------
@@ -289,8 +322,7 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
     __syncthreads();
 
     // ---------------- phase 4: out = O Wo^T + bias + h ------------------------------------------------------------------------------------
-    if (!(p.debug & 2)) gemm_320(p.wo, XT, lane, wm, wn, acc);
-    __syncthreads();                                 // every wave is done reading O from XT: it becomes the epilogue patch
+    if (!(p.debug & 2)) gemm_320<false>(p.wo, smem, w, lane, wm, wn, acc);     // ends with a barrier: XT becomes the epilogue patch
     {
         char* const patch = smem;                    // [128 rows][PROW]
 #pragma unroll
@@ -337,7 +369,7 @@ int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
     XattnParams p;
     p.h = a.h; p.out = a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
     p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = g_tune_debug;
-    constexpr size_t lds = (XT_BYTES + VROWS * VS > TM * PROW) ? XT_BYTES + VROWS * VS : TM * PROW;      // 146432
+    constexpr size_t lds = XT_BYTES + 2 * WST;      // 163840: XT + two weight stages (the V tile reuses the stages, the epilogue patch XT)
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
