@@ -24,7 +24,7 @@
 #include <cstring>
 #include <cmath>
 
-int g_tune_xattn_fused = 0;    // 1: the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip)
+int g_tune_xattn_fused = 1;    // 1 (default): the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
 int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
 
 namespace {

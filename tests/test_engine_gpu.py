@@ -4,8 +4,8 @@ on identical seeded weights, prompts, noise and replayed action indices.
 
 The north_star 1e-3 gate applies to the SOLVER given identical eps (tests/test_solver_gpu.py).  This
 test additionally bounds the drift of the whole fp16 pipeline over the trajectory (the denoiser runs in
-fp16 with fp16 activation storage, 1.5e-3 per forward, see tests/test_unet_gpu.py): <= 1e-2 relative L2
-on the final latents after 4 steps (measured ~3e-3)."""
+fp16 with fp16 activation storage, 1.6e-3 per forward, see tests/test_parity_e2e_gpu.py for the 8-step full-size
+case and what that error is made of): measured 1.5e-3 ... 2.1e-3 on the final latents, gated at measured + ~35 %."""
 import os
 
 import numpy as np
@@ -78,7 +78,7 @@ def test_engine_trajectory_reduced_unet(use_graph):
     want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g)
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 4-step reduced-unet rel l2", err, "graph" if use_graph else "eager")
-    assert np.isfinite(got).all() and err < 1e-2, err
+    assert np.isfinite(got).all() and err < 2.6e-3, err          # measured 1.93e-3 (eager) / 1.45e-3 (graph: one index set), + ~35 %
 
 
 @pytest.mark.timeout(1200)
@@ -94,7 +94,7 @@ def test_engine_trajectory_full_sd15_two_steps():
     want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g)
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 2-step SD1.5 rel l2", err)
-    assert err < 1e-2, err
+    assert err < 2.8e-3, err                                     # measured 2.13e-3, + 30 % (8 steps on the full UNet: tests/test_parity_e2e_gpu.py)
 
 
 def test_engine_pixel_output_matches_decode_of_its_latents():

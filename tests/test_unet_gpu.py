@@ -2,8 +2,9 @@
 
 The oracle is "parity unpinned" w.r.t. diffusers (see oracle/unet_oracle.py); what is pinned here is
 that the HIP kernels compute the same function as the fp32 restatement on identical seeded weights.
-Tolerance: activations are stored in fp16 between ~400 kernels -> relative L2 of the eps output
-<= 5e-3 (measured ~1e-3), stated here because it is looser than the solver's 1e-3 gate.
+Tolerance: activations are stored in fp16 between ~400 kernels -> relative L2 of the eps output 1.5e-3 ... 1.6e-3,
+gated at measured + 30 %; stated here because it is looser than the solver's 1e-3 gate (what that error is made of and
+how it compares with a torch-fp16 evaluation of the same graph: tests/test_parity_e2e_gpu.py).
 """
 import pytest
 import torch
@@ -41,10 +42,10 @@ def test_reduced_unet_matches_oracle():
     assert got.shape == (4, 4, 16, 16) and got.dtype == torch.float16
     err = rel_l2(got, want)
     print('reduced unet rel l2', err)
-    assert err < 5e-3, err
+    assert err < 2.0e-3, err            # measured 1.48e-3
     # cached cross-attention K/V (second step, same ctx) and per-sample timesteps give the same function
     got2 = u(lat.half().to(DEV), torch.full((4,), float(t), device=DEV), encoder_hidden_states=ctx.half().to(DEV), dup=2, reuse_kv=True)[0]
-    assert rel_l2(got2, want) < 5e-3
+    assert rel_l2(got2, want) < 2.0e-3
     # un-duplicated batch path == dual batch path on the conditional half
     got3 = u(lat.half().to(DEV), t, encoder_hidden_states=ctx[2:].half().to(DEV), dup=1, reuse_kv=False)[0]
     assert torch.equal(got3, got[2:])
@@ -101,7 +102,7 @@ def test_full_sd15_unet_matches_oracle_cfg_batch():
     want = orc(torch.cat([lat.half().float()] * 2), 499, ctx.half().float())
     err = rel_l2(got, want)
     print('sd15 unet rel l2', err)
-    assert err < 5e-3, err
+    assert err < 2.1e-3, err            # measured 1.61e-3 (a plain torch-fp16 evaluation of the same graph: 2.9e-3, tests/test_parity_e2e_gpu.py)
     assert torch.isfinite(got).all()
     # determinism
     again = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
