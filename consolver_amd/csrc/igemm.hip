@@ -48,6 +48,20 @@ struct IgemmParams {
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
 };
 
+// timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
+#define CS_TRACE_SLOTS 8192
+__device__ unsigned long long g_trace[CS_TRACE_SLOTS * 6];
+__device__ __forceinline__ void trace_stamp(int debug, int slot, int which) {
+    if ((debug & 16384) && threadIdx.x == 0 && slot < CS_TRACE_SLOTS) {
+        g_trace[slot * 6 + which] = wall_clock64();
+        if (which == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);     // HW_REG_XCC_ID
+            g_trace[slot * 6 + 5] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
 // layers were bound by L2->LDS traffic (the activation panel was re-staged N/160 times), not MFMA.
 // Two LDS stages (144 KB), one workgroup per CU, 9 DMA issues per wave per 80 MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <bool GEGLU, int BNX>
+template <bool GEGLU, int BNX, bool RING = false>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     // BNX = 320: wave tile 64 x 160 (every SD1.5 width >= 320 with enough rows); BNX = 160: wave tile 64 x 80 for the 1280-wide layers
     // at 16 x 16 (M = 8192: 32 x 8 = 256 tiles = one per CU, where 256 x 320 tiles would leave half the chip idle)
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         const int r = 8 * (w * 4 + j) + (lane >> 3);
         const int m = m_blk + r;
         a_chunk[j] = (pch ^ ((r >> 1) & 7)) * 8;
-        a_row[j] = (m < p.M) ? m : -1;
+        a_row[j] = (m < p.M && !(p.debug & 65536)) ? m : -1;                                           // (timing experiment: every activation piece from the zero page)
     }
     const f16* b_src[BPW];
 #pragma unroll
@@ -565,16 +579,44 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     const int frag_off1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
 
     if ((p.debug & 4096) && w >= 4) __builtin_amdgcn_s_setprio(2);      // (experiment: static priority for waves 4-7)
+    // (experiment, debug bit 8192 + count in bits 16..: the first-round workgroups on every other CU start late, so that half the chip is in
+    //  its store phase while the other half is in its k loop instead of all CUs storing at once)
+    if ((p.debug & 8192) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < (p.debug >> 16); ++i) __builtin_amdgcn_s_sleep(127);
+    trace_stamp(p.debug, blockIdx.x, 0);
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    trace_stamp(p.debug, blockIdx.x, 1);
 
     const int KTX = (p.debug & 2) ? 0 : p.KT;
     for (int kt = 0; kt < KTX; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < p.KT) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < p.KT && !(p.debug & 32768)) stage((p.debug & 131072) ? 0 : kt + 1, buf ^ 1);     // (timing experiments: no staging / the same k step every time)
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
         const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
+        if constexpr (RING) {
+            // fragment reads run a RING of two weight fragments ahead of the MFMAs that consume them, and the second half-step's
+            // activation fragments are read under the first half's last MFMAs: every wait is a counted lgkmcnt(N > 0).  (The compiler's
+            // own order is read two fragments -> lgkmcnt(0) -> eight MFMAs, ten exposed LDS latencies per k step.)
+            constexpr int NQ = 2 * NT;                                   // items: (half-step ks, weight tile i)
+            auto wr = [&](int q) { const int ks = q / NT, i = q - ks * NT; return *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? frag_off1 : frag_off0)); };
+            f16x8 fa[2][MT], fw[3];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fa[0][j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + frag_off0);
+            fw[0] = wr(0); fw[1] = wr(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ks = q / NT, i = q - ks * NT;
+                if (q + 2 < NQ) fw[(q + 2) % 3] = wr(q + 2);
+                if (ks == 0 && i >= NT - MT) fa[1][i - (NT - MT)] = *reinterpret_cast<const f16x8*>(ta + (i - (NT - MT)) * 2048 + frag_off1);
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[q % 3], fa[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? frag_off1 : frag_off0;
@@ -596,9 +638,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    trace_stamp(p.debug, blockIdx.x, 2);
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
     if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, (BNX == 320 ? 2 : 1)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    trace_stamp(p.debug, blockIdx.x, 3);
+    if (p.debug & 16384) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p.debug, blockIdx.x, 4); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -892,6 +937,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 }  // namespace
 
 int g_tune_debug = 0;
+int g_tune_gemm_ring = 1;      // 1: gemm_big_kernel with the hand-placed fragment-read ring (0: the compiler's order)
 int g_tune_gemm_stag = 0;      // 1: 256 x 320 linear / 1x1 layers through gemm_stag_kernel instead of gemm_big_kernel<.,320>
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
@@ -1024,6 +1070,18 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
                 CS_CHECK_LAUNCH();
                 return CS_OK;
             }
+            if (g_tune_gemm_ring) {
+                static bool configured_r = false;
+                if (!configured_r) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    configured_r = true;
+                }
+                if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
+                else hipLaunchKernelGGL((gemm_big_kernel<false, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
+            }
             if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             else hipLaunchKernelGGL((gemm_big_kernel<false, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();
@@ -1039,6 +1097,16 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
             if (!configured) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
+            }
+            if (g_tune_gemm_ring) {
+                static bool configured_r = false;
+                if (!configured_r) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    configured_r = true;
+                }
+                hipLaunchKernelGGL((gemm_big_kernel<false, 160, true>), dim3(p.nblk), dim3(512), lds, s, p);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
             }
             hipLaunchKernelGGL((gemm_big_kernel<false, 160>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();
@@ -1057,4 +1125,10 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     }
     if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
     return conv3 ? launch_variant<160, true, false>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
+}
+
+// timing experiments only: copy the per-workgroup stamps of the last gemm_big_kernel launches run with debug bit 16384 to host memory
+int debug_trace_read(void* dst, size_t bytes) {
+    if (bytes > sizeof(unsigned long long) * CS_TRACE_SLOTS * 6) bytes = sizeof(unsigned long long) * CS_TRACE_SLOTS * 6;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? CS_OK : CS_E_HIP;
 }

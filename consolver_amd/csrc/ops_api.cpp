@@ -5,6 +5,8 @@
 
 extern int g_tune_halo;
 extern int g_tune_debug;
+extern int g_tune_gemm_ring;
+int debug_trace_read(void* dst, size_t bytes);
 extern int g_tune_cfg_share;
 extern int g_tune_xattn_fused;
 extern int g_tune_conv_sched;
@@ -21,6 +23,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
+    if (!strcmp(key, "gemm_ring")) { g_tune_gemm_ring = value ? 1 : 0; return CS_OK; }
     if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
     if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
@@ -162,5 +165,7 @@ int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int 
 int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream) {
     return launch_layer_norm((const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)out, M, C, eps, (hipStream_t)stream);
 }
+
+int cs_debug_trace_read(void* dst_host, size_t bytes) { return debug_trace_read(dst_host, bytes); }
 
 }  // extern "C"

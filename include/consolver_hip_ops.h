@@ -107,8 +107,18 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                1 + static priority for the staggered wave group, 2 + that group's LDS-DMA issues spread among its MFMAs;
  *   "xattn_fused": 1 (default): the cross-attention sub-block at C = 320 runs as one kernel (cs_op_xattn_block) inside cs_unet_forward;
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
- *   "debug":     1 skip the GEMM epilogue, 2 skip its k loop (timing experiments only: results are wrong) */
+ *   "gemm_ring": 1 (default) the 256-row GEMM kernel reads its LDS fragments through a hand-placed ring, 0 the compiler's order;
+ *   "gemm_stag": 1 the staggered k32 three-stage variant of that kernel (measured experiment, default 0);
+ *   "attn_prio" / "gemm2_prio": static wave priority experiments (attn_prio -1 = auto: head dim 128 only);
+ *   "debug":     timing experiments only (results are wrong or the run is slowed): 1 skip the GEMM epilogue, 2 skip its k loop,
+ *                4096 static priority in the GEMM kernel, 8192 + (n << 16) late start of every other CU by n x s_sleep(127),
+ *                16384 per-workgroup stamps (cs_debug_trace_read), 32768 no staging inside the k loop, 65536 activations from the
+ *                zero page, 131072 the same k step staged every time; the halo conv kernel has its own bits (csrc/igemm.hip) */
 int cs_set_tuning(const char* key, int value);
+/* Timing experiments only: with cs_set_tuning("debug", 16384) every workgroup of the 256-row GEMM kernel records wall-clock stamps
+ * (100 MHz) -- [slot][6] uint64: entry, first stage landed, k loop done, epilogue issued, stores drained, (XCC id << 32 | HW_ID) --
+ * which this call copies to host memory (at most 8192 slots; tools/gemm_timeline.py). */
+int cs_debug_trace_read(void* dst_host, size_t bytes);
 
 #ifdef __cplusplus
 }
