@@ -50,14 +50,15 @@ struct IgemmParams {
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
 #define CS_TRACE_SLOTS 8192
-__device__ unsigned long long g_trace[CS_TRACE_SLOTS * 6];
+#define CS_TRACE_W 12
+__device__ unsigned long long g_trace[CS_TRACE_SLOTS * CS_TRACE_W];
 __device__ __forceinline__ void trace_stamp(int debug, int slot, int which) {
     if ((debug & 16384) && threadIdx.x == 0 && slot < CS_TRACE_SLOTS) {
-        g_trace[slot * 6 + which] = wall_clock64();
+        g_trace[slot * CS_TRACE_W + which] = wall_clock64();
         if (which == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID
             const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);     // HW_REG_XCC_ID
-            g_trace[slot * 6 + 5] = ((unsigned long long)xcc << 32) | hw;
+            g_trace[slot * CS_TRACE_W + 5] = ((unsigned long long)xcc << 32) | hw;
         }
     }
 }
@@ -568,6 +569,22 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
             if (NBP % 8 == 0 || w + 8 * j < NBP) glds16(b_src[j] + (size_t)kt * BK, lb + (w + 8 * j) * 1024);
     };
 
+    // one DMA piece of a stage: n = 0..3 the wave's activation pieces (HBM / L2), 4.. its weight pieces (L2)
+    auto stage_piece = [&](int kt, int buf, int n) {
+        if (n < 4) {
+            const int cc = kt * BK;
+            const f16* src; int cs, coff;
+            if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
+            const bool ok = a_row[n] >= 0;
+            const uintptr_t real = (uintptr_t)(src + ((long)a_row[n] * cs + coff + a_chunk[n]));
+            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)ok;
+            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), smem + buf * STAGE + (w * 4 + n) * 1024);
+        } else {
+            const int j = n - 4;
+            if (NBP % 8 == 0 || w + 8 * j < NBP) glds16(b_src[j] + (size_t)kt * BK, smem + buf * STAGE + A_BYTES + (w + 8 * j) * 1024);
+        }
+    };
+
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -590,16 +607,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     trace_stamp(p.debug, blockIdx.x, 1);
 
     const int KTX = (p.debug & 2) ? 0 : p.KT;
+    // (debug bit 16384: where a k step's time goes, in shader-clock cycles summed over the k loop: DMA issue / MFMAs + fragment reads /
+    //  wait for the DMA / barrier; waves 0 and 4 of each workgroup, slots [6..9] and [10..11] of the trace record hold wave 0's sums and stamps)
+    const bool tr = (p.debug & 16384) && lane == 0 && w == 0 && blockIdx.x < CS_TRACE_SLOTS;
+    unsigned long long tsum[4] = {0, 0, 0, 0}, tc0 = 0;
+    if (tr) tc0 = __builtin_readcyclecounter();
     for (int kt = 0; kt < KTX; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < p.KT && !(p.debug & 32768)) stage((p.debug & 131072) ? 0 : kt + 1, buf ^ 1);     // (timing experiments: no staging / the same k step every time)
+        unsigned long long ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
+        if (p.debug & 16384) ta_ = __builtin_readcyclecounter();
+        const bool do_stage = kt + 1 < p.KT && !(p.debug & 32768);                                     // (timing experiments: no staging / the same k step every time)
+        const int kt_stage = (p.debug & 131072) ? 0 : kt + 1;
+        if (do_stage && !RING) stage(kt_stage, buf ^ 1);
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
         const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
+        if (p.debug & 16384) { __builtin_amdgcn_sched_barrier(0); tb_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (RING) {
             // fragment reads run a RING of two weight fragments ahead of the MFMAs that consume them, and the second half-step's
             // activation fragments are read under the first half's last MFMAs: every wait is a counted lgkmcnt(N > 0).  (The compiler's
             // own order is read two fragments -> lgkmcnt(0) -> eight MFMAs, ten exposed LDS latencies per k step.)
+            // The next stage's DMA pieces go BETWEEN the items, one per SP items, activations first: 72 KB per step through the CU's 64 B/clk
+            // vector-memory path is ~1150 cycles, and issued as one burst at the top of the step every wave of the CU sat in it while the
+            // matrix pipe idled (stamps: 0.57 us of a 2.3 us step, profiles/r02_gemm_timeline.txt).
             constexpr int NQ = 2 * NT;                                   // items: (half-step ks, weight tile i)
+            constexpr int NP = 4 + BPW, SP = (NQ >= 2 * NP) ? 2 : 1;
             auto wr = [&](int q) { const int ks = q / NT, i = q - ks * NT; return *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? frag_off1 : frag_off0)); };
             f16x8 fa[2][MT], fw[3];
 #pragma unroll
@@ -615,6 +646,10 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
                 for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[q % 3], fa[ks][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (q % SP == 0 && q / SP < NP) {
+                    if (do_stage) stage_piece(kt_stage, buf ^ 1, q / SP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else
 #pragma unroll
@@ -635,8 +670,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
                         acc[half * NH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * NH + i][j], 0, 0, 0);
             }
         }
+        if (p.debug & 16384) { __builtin_amdgcn_sched_barrier(0); tc_ = __builtin_readcyclecounter(); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.debug & 16384) td_ = __builtin_readcyclecounter();
         __syncthreads();
+        if (tr) { const unsigned long long te_ = __builtin_readcyclecounter(); tsum[0] += tb_ - ta_; tsum[1] += tc_ - tb_; tsum[2] += td_ - tc_; tsum[3] += te_ - td_; }
+    }
+    if (tr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g_trace[blockIdx.x * CS_TRACE_W + 6 + k] = tsum[k];
+        g_trace[blockIdx.x * CS_TRACE_W + 10] = tc0; g_trace[blockIdx.x * CS_TRACE_W + 11] = __builtin_readcyclecounter();
     }
     trace_stamp(p.debug, blockIdx.x, 2);
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
@@ -1129,6 +1172,6 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 
 // timing experiments only: copy the per-workgroup stamps of the last gemm_big_kernel launches run with debug bit 16384 to host memory
 int debug_trace_read(void* dst, size_t bytes) {
-    if (bytes > sizeof(unsigned long long) * CS_TRACE_SLOTS * 6) bytes = sizeof(unsigned long long) * CS_TRACE_SLOTS * 6;
+    if (bytes > sizeof(unsigned long long) * CS_TRACE_SLOTS * CS_TRACE_W) bytes = sizeof(unsigned long long) * CS_TRACE_SLOTS * CS_TRACE_W;
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? CS_OK : CS_E_HIP;
 }

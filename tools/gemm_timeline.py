@@ -27,7 +27,7 @@ for tag, M, K, N, res, geglu in shapes:
     call(); torch.cuda.synchronize()
     lib.cs_set_tuning(b"debug", 0)
     nwg = min(8192, (M // 256) * (N // 320))
-    buf = np.zeros((8192, 6), dtype=np.uint64)
+    buf = np.zeros((8192, 12), dtype=np.uint64)
     L.check(lib.cs_debug_trace_read(buf.ctypes.data_as(C.c_void_p), buf.nbytes))
     t = buf[:nwg, :5].astype(np.int64)
     hw = buf[:nwg, 5]
@@ -38,6 +38,13 @@ for tag, M, K, N, res, geglu in shapes:
     print(f"== {tag}  M={M} K={K} N={N}: {nwg} workgroups, {len(np.unique(cu))} distinct CU keys, kernel span {us.max():.1f} us")
     print("   median per workgroup, us: prologue %.2f | k loop %.2f | epilogue issue %.2f | store drain %.2f | total %.2f" %
           (np.median(ph[:, 0]), np.median(ph[:, 1]), np.median(ph[:, 2]), np.median(ph[:, 3]), np.median(us[:, 4] - us[:, 0])))
+    # k loop split (wave 0 of each workgroup, shader-clock cycles converted with the workgroup's own wall-clock span)
+    cyc = buf[:nwg, 6:12].astype(np.float64)
+    span_cyc = cyc[:, 5] - cyc[:, 4]; span_us = us[:, 2] - us[:, 1]
+    mhz = np.median(span_cyc / np.maximum(span_us, 1e-3))
+    parts = np.median(cyc[:, 0:4], axis=0) / mhz
+    print("   k loop split, us per workgroup (counter %.0f MHz): DMA issue %.2f | MFMAs + fragment reads %.2f | wait for the DMA %.2f | barrier %.2f ; steps %d"
+          % (mhz, parts[0], parts[1], parts[2], parts[3], K // 64))
     gaps, firsts = [], []
     for c in np.unique(cu):
         idx = np.where(cu == c)[0]
