@@ -46,6 +46,7 @@ struct IgemmParams {
     int tiles_n, nblk;
     float* partial;     // split-K scratch of the generic kernel ([splits][M][N] fp32) or null
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
+    float* gn_stats;    // GroupNorm partial sums of the output, [M / 64][N / 2][2], written by the epilogue (IgemmArgs::gn_stats) or null
 };
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
@@ -108,6 +109,8 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 struct LinearRows {
     int m_base, M;
     __device__ __forceinline__ int operator()(int row) const { const int m = m_base + row; return m < M ? m : -1; }
+    // index of the wave's 64-row block in the [B][HoWo / 64] statistics grid (rows are sample-major and HoWo % 64 == 0), or -1
+    __device__ __forceinline__ int stat_slot(int) const { return m_base < M ? m_base >> 6 : -1; }
 };
 
 // RSPLIT > 1 trades column groups for row groups: the patch holds 64 / RSPLIT rows x ALL the wave's columns, so a pass stores
@@ -122,6 +125,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     constexpr int CH = COLS / 8;                              // 16-byte chunks per row
     const int g4 = (lane >> 4) * 4, i16 = lane & 15;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    // GroupNorm statistics of the output (p.gn_stats): the final fp16 values of a pass are written back into the patch, and lanes
+    // 0 .. COLS/4-1 then walk its rows with four columns each: v_dot2_f32_f16 against (1, 1) and against the value itself gives the sum and
+    // the sum of squares of a channel PAIR per instruction (a group always holds whole pairs).
+    const bool stats = !GEGLU && GROUP == NT && p.gn_stats != nullptr;
+    float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
 #pragma unroll
     for (int grp = 0; grp < NT / GROUP; ++grp)
 #pragma unroll
@@ -188,11 +196,30 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
+                    if (stats) *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = o;
                 } else {
                     *reinterpret_cast<f16x8*>(p.out + off) = v;
                 }
+            } else if (stats) {
+                *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         }
+        if (stats && lane < COLS / 4) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll 8
+            for (int r = 0; r < RT * 16; ++r) {
+                union { u32x2 u; h2 h[2]; } v;
+                v.u = *reinterpret_cast<const u32x2*>(wave_lds + r * ROWB + lane * 8);
+                st_sum[0] = __builtin_amdgcn_fdot2(v.h[0], one, st_sum[0], false); st_sq[0] = __builtin_amdgcn_fdot2(v.h[0], v.h[0], st_sq[0], false);
+                st_sum[1] = __builtin_amdgcn_fdot2(v.h[1], one, st_sum[1], false); st_sq[1] = __builtin_amdgcn_fdot2(v.h[1], v.h[1], st_sq[1], false);
+            }
+        }
+    }
+    if (stats && lane < COLS / 4) {
+        const int slot = rows.stat_slot(p.HoWo);
+        if (slot >= 0)
+            *reinterpret_cast<f32x4*>(p.gn_stats + ((size_t)slot * (p.N >> 1) + (n_base >> 1) + lane * 2) * 2) = f32x4{st_sum[0], st_sq[0], st_sum[1], st_sq[1]};
     }
 }
 
@@ -241,6 +268,16 @@ struct PatchRows {          // tile-local pixel -> output row
         const int fy = rem >> tw_shift, fx = rem & ((1 << tw_shift) - 1);
         const int b = b0 + img;
         return b < B ? (b * Ho + y0 + fy) * Wo + x0 + fx : -1;
+    }
+    // the wave's 64 pixels are a quarter of a 16 x 16 patch (or a whole 8 x 8 image / a part of a small image): any bijection of the
+    // (patch, quarter) pairs of an image onto [0, HoWo / 64) serves as the block index
+    __device__ __forceinline__ int stat_slot(int HoWo) const {
+        const int img = o_base >> trw_shift, b = b0 + img;
+        if (b >= B || trw_shift < 6) return -1;
+        const int th_shift = trw_shift - tw_shift;
+        const int patch = ((y0 >> th_shift) * (Wo >> tw_shift)) + (x0 >> tw_shift);
+        const int sub = (o_base & ((1 << trw_shift) - 1)) >> 6;
+        return b * (HoWo >> 6) + (patch << (trw_shift - 6)) + sub;
     }
 };
 
@@ -980,6 +1017,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 }  // namespace
 
 int g_tune_debug = 0;
+int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
 int g_tune_gemm_ring = 1;      // 1: gemm_big_kernel with the hand-placed fragment-read ring (0: the compiler's order)
 int g_tune_gemm_stag = 0;      // 1: 256 x 320 linear / 1x1 layers through gemm_stag_kernel instead of gemm_big_kernel<.,320>
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
@@ -1011,7 +1049,7 @@ static int launch_halo(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s
     return launch_halo_sched<UP, BN, KH, 2>(h, grid, lds, s);
 }
 
-int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done) {
     const int cin = a.c0 + a.c1;
     if (!a.a0 || !a.w || !a.out) CS_FAIL(CS_E_ARG, "igemm: a0, w, out required");
     if (a.taps != 1 && a.taps != 9) CS_FAIL(CS_E_ARG, "igemm: taps must be 1 or 9");
@@ -1027,6 +1065,9 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
     p.debug = g_tune_debug; p.partial = nullptr;
+    // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
+    const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
+    p.gn_stats = stats_ok ? a.gn_stats : nullptr;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
     if (a.N % 128 == 0) bn = 128;
@@ -1079,6 +1120,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
             else rc = a.upsample ? launch_halo<true, 128, 1>(h, grid, l, s) : launch_halo<false, 128, 1>(h, grid, l, s);
             if (rc != CS_OK) return rc;
             CS_CHECK_LAUNCH();
+            *stats_done = stats_ok && splits == 1;
             if (splits > 1) {
                 const long total = (long)p.M * (p.N / 8);
                 int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
@@ -1092,7 +1134,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (g_tune_biggemm && !conv3 && a.N % 320 == 0) {
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 320;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 2) {
-            p.tiles_n = tn; p.nblk = tiles_m * tn;
+            p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
             constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
             static bool configured = false;
             if (!configured) {
@@ -1134,7 +1176,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     if (g_tune_biggemm && !conv3 && !a.geglu && a.N % 160 == 0) {       // too few 256 x 320 tiles: 256 x 160 tiles, same 8-wave structure
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 160;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 3) {
-            p.tiles_n = tn; p.nblk = tiles_m * tn;
+            p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
             constexpr size_t lds = 2 * (256 * BK * 2 + 160 * BK * 2);
             static bool configured = false;
             if (!configured) {
@@ -1166,8 +1208,18 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
                (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
         if (splits > 1) p.partial = a.splitk_ws;
     }
+    *stats_done = stats_ok && splits == 1;
     if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
     return conv3 ? launch_variant<160, true, false>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
+}
+
+int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+    bool stats_done = false;
+    const int rc = launch_igemm_impl(a, s, &stats_done);
+    if (rc != CS_OK || !a.gn_stats || stats_done) return rc;
+    // the chosen kernel has no statistics epilogue (split-K forms) or the knob is off: a statistics pass over the output, same layout
+    if (a.geglu || (a.Ho * a.Wo) % 64) CS_FAIL(CS_E_ARG, "igemm: gn_stats needs Ho * Wo %% 64 == 0 and no GEGLU");
+    return launch_gn_stats64(a.out, a.B, a.Ho * a.Wo, a.N, a.gn_stats, s);
 }
 
 // timing experiments only: copy the per-workgroup stamps of the last gemm_big_kernel launches run with debug bit 16384 to host memory

@@ -6,9 +6,11 @@
 namespace {
 
 // ---------------------------------------------------------------------------- GroupNorm
-// pass 1: per (sample, row split) per-channel partial sums.  blockDim = (C/8) * R with R rows in
-// flight, so a thread's 8-channel vector index is fixed while it strides over rows.
-__global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_off, int Ctot, float* __restrict__ partial) {
+// pass 1: per (sample, row split) partial sums of channel PAIRS (2q, 2q+1) -- a group always holds whole pairs (C / groups is even) --
+// into partial[b][s][C/2][2] (sum, sum of squares).  The same layout the conv / GEMM epilogues write when they produce the statistics of
+// their own output (IgemmArgs::gn_stats).  blockDim = (C/8) * R with R rows in flight, so a thread's 8-channel vector index is fixed
+// while it strides over rows.
+__global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [R][C/8][16]
     const int CV = C >> 3;
     const int cv = threadIdx.x % CV, rr = threadIdx.x / CV, R = blockDim.x / CV;
@@ -43,23 +45,27 @@ __global__ void gn_stats_kernel(const f16* __restrict__ x, int C, int HW, int c_
 #pragma unroll
             for (int k = 0; k < 8; ++k) { sum[k] += o[k]; sq[k] += o[8 + k]; }
         }
-        float* dst = partial + (((size_t)b * S + s) * Ctot + c_off + cv * 8) * 2;
+        float* dst = partial + (((size_t)b * S + s) * (C >> 1) + cv * 4) * 2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { dst[2 * k] = sum[k]; dst[2 * k + 1] = sq[k]; }
+        for (int k = 0; k < 4; ++k) { dst[2 * k] = sum[2 * k] + sum[2 * k + 1]; dst[2 * k + 1] = sq[2 * k] + sq[2 * k + 1]; }
     }
 }
 
-// pass 2: one workgroup per (sample, group): reduce the splits, group statistics, per-channel scale/shift
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int S, int Ctot, int groups, int HW, float eps,
-                                                          const f16* __restrict__ gamma, const f16* __restrict__ beta, float* __restrict__ scale_shift) {
+// pass 2: one workgroup per (sample, group): reduce the splits of both sources, group statistics, per-channel scale/shift.
+// A group of the concatenated channel axis may straddle the two sources (960 = 640 + 320 channels: 30 per group), so the source is
+// chosen per pair.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ p0, int S0, int c0, const float* __restrict__ p1, int S1, int c1,
+                                                          int groups, int HW, float eps, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                          float* __restrict__ scale_shift) {
     __shared__ float red[2][4];
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int cpg = Ctot / groups;
+    const int Ctot = c0 + c1, cpg = Ctot / groups, ppg = cpg >> 1, q0 = c0 >> 1, q1 = c1 >> 1;
     float a = 0.f, q = 0.f;
-    for (int i = tid; i < S * cpg; i += 256) {            // (split, channel) pairs of this group
-        const int s = i / cpg, c = g * cpg + (i - s * cpg);
-        const float* p = partial + (((size_t)b * S + s) * Ctot + c) * 2;
-        a += p[0]; q += p[1];
+    const int Smax = S0 > S1 ? S0 : S1;
+    for (int i = tid; i < Smax * ppg; i += 256) {            // (split, pair) items of this group
+        const int s = i / ppg, pr = g * ppg + (i - s * ppg);
+        if (pr < q0) { if (s < S0) { const float* p = p0 + (((size_t)b * S0 + s) * q0 + pr) * 2; a += p[0]; q += p[1]; } }
+        else if (s < S1) { const float* p = p1 + (((size_t)b * S1 + s) * q1 + (pr - q0)) * 2; a += p[0]; q += p[1]; }
     }
     a = wave_sum(a); q = wave_sum(q);
     if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = q; }
@@ -178,27 +184,43 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
 
 }  // namespace
 
+// standalone statistics of one [B][HW][C] tensor into partial[B][S][C/2][2]
+static int launch_gn_stats(const f16* x, int B, int HW, int C, int S, float* partial, hipStream_t s) {
+    const int CV = C / 8;
+    int R = 256 / CV; if (R < 1) R = 1;
+    const int T = CV * R;
+    if (T > 1024) CS_FAIL(CS_E_SHAPE, "group_norm: C=%d too wide", C);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(S, B), dim3(T), (size_t)T * 16 * sizeof(float), s, x, C, HW, partial);
+    return CS_OK;
+}
+
+int launch_gn_stats64(const f16* x, int B, int HW, int C, float* partial, hipStream_t s) {
+    if (HW % 64 || C % 8) CS_FAIL(CS_E_SHAPE, "gn_stats64: HW=%d C=%d", HW, C);
+    const int rc = launch_gn_stats(x, B, HW, C, HW / 64, partial, s);
+    CS_CHECK_LAUNCH();
+    return rc;
+}
+
 int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
     const int Ctot = a.c0 + a.c1;
     if (!a.x0 || !a.out || !a.partial || !a.gamma || !a.beta) CS_FAIL(CS_E_ARG, "group_norm: null pointer");
-    if (a.c0 % 8 || a.c1 % 8 || Ctot % a.groups) CS_FAIL(CS_E_SHAPE, "group_norm: channels (%d,%d) groups %d", a.c0, a.c1, a.groups);
+    if (a.c0 % 8 || a.c1 % 8 || Ctot % a.groups || (Ctot / a.groups) % 2) CS_FAIL(CS_E_SHAPE, "group_norm: channels (%d,%d) groups %d", a.c0, a.c1, a.groups);
     if (a.B <= 0 || a.HW <= 0) return a.B < 0 ? CS_E_SHAPE : CS_OK;
     const int smax = a.splits > 0 ? a.splits : GN_SPLITS;
     int S = smax;
     while (S > 1 && (a.HW % S)) S >>= 1;
-    float* scale_shift = a.partial + (size_t)a.B * smax * Ctot * 2;
-    for (int src = 0; src < 2; ++src) {
-        const f16* x = src ? a.x1 : a.x0;
-        const int C = src ? a.c1 : a.c0;
-        if (!C) continue;
-        const int CV = C / 8;
-        int R = 256 / CV; if (R < 1) R = 1;
-        const int T = CV * R;
-        if (T > 1024) CS_FAIL(CS_E_SHAPE, "group_norm: C=%d too wide", C);
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(S, a.B), dim3(T), (size_t)T * 16 * sizeof(float), s, x, C, a.HW, src ? a.c0 : 0, Ctot, a.partial);
-    }
+    // workspace: [source 0 partials][source 1 partials][scale / shift]; a source whose producer already wrote its partial sums
+    // (stats0 / stats1, S0 / S1 splits per sample) skips the statistics pass
+    float* part0 = a.partial;
+    float* part1 = a.partial + (size_t)a.B * smax * a.c0;
+    float* scale_shift = a.partial + (size_t)a.B * smax * Ctot;
+    const float* p0 = a.stats0; int S0 = a.stats0 ? a.S0 : S;
+    const float* p1 = a.stats1; int S1 = a.stats1 ? a.S1 : S;
+    if (!p0) { const int rc = launch_gn_stats(a.x0, a.B, a.HW, a.c0, S, part0, s); if (rc != CS_OK) return rc; p0 = part0; }
+    if (a.c1 && !p1) { const int rc = launch_gn_stats(a.x1, a.B, a.HW, a.c1, S, part1, s); if (rc != CS_OK) return rc; p1 = part1; }
+    if (!a.c1) { p1 = p0; S1 = 0; }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s,
-                       a.partial, S, Ctot, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
+                       p0, S0, a.c0, p1, S1, a.c1, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
     int chunks = (a.HW * (Ctot / 8) + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
     if (chunks < 1) chunks = 1;
     if (chunks > a.HW) chunks = a.HW;

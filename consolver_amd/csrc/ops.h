@@ -20,6 +20,9 @@ struct IgemmArgs {
     f16* out;               // [M][N] (GEGLU: [M][N/2])
     int geglu;              // rows of w pre-permuted in (value16 | gate16) blocks; out = v * gelu(g)
     float* splitk_ws; size_t splitk_ws_bytes;   // optional fp32 scratch for split-K on small images (may be null)
+    // optional: GroupNorm statistics of the OUTPUT, written by the epilogue (or by a statistics pass when the chosen kernel cannot):
+    // gn_stats[B][Ho*Wo/64][N/2][2] = (sum, sum of squares) of channel pairs over each 64-row block of a sample; needs Ho*Wo % 64 == 0, no GEGLU
+    float* gn_stats;
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);
@@ -48,7 +51,11 @@ struct GroupNormArgs {
     int splits;                             // 0 -> GN_SPLITS; larger for big images (VAE decoder), power of two
     float* partial;                         // workspace >= B * (splits + 1) * C * 2 floats
     f16* out;
+    // optional: partial sums of a source already written by its producer (IgemmArgs::gn_stats layout [B][S][C/2][2]); null -> computed here
+    const float* stats0; int S0; const float* stats1; int S1;
 };
+// statistics of a [B][HW][C] tensor in the producer layout: partial[B][HW/64][C/2][2] (sum, sum of squares of channel pairs per 64-row block)
+int launch_gn_stats64(const f16* x, int B, int HW, int C, float* partial, hipStream_t s);
 #define GN_SPLITS 16
 int launch_group_norm(const GroupNormArgs& a, hipStream_t s);
 

@@ -6,6 +6,7 @@
 extern int g_tune_halo;
 extern int g_tune_debug;
 extern int g_tune_gemm_ring;
+extern int g_tune_gn_fuse;
 int debug_trace_read(void* dst, size_t bytes);
 extern int g_tune_cfg_share;
 extern int g_tune_xattn_fused;
@@ -24,6 +25,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
     if (!strcmp(key, "gemm_ring")) { g_tune_gemm_ring = value ? 1 : 0; return CS_OK; }
+    if (!strcmp(key, "gn_fuse")) { g_tune_gn_fuse = value ? 1 : 0; return CS_OK; }
     if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
     if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
@@ -45,6 +47,21 @@ int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, 
     a.taps = taps; a.stride = stride; a.upsample = upsample; a.N = N; a.w = (const f16*)w; a.bias = (const f16*)bias;
     a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
     a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
+                    const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
+                    void* splitk_ws, size_t splitk_ws_bytes, float* gn_stats, void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x0; a.a1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi;
+    if (stride != 1 && stride != 2) CS_FAIL(CS_E_ARG, "conv2d: stride must be 1 or 2");
+    a.Ho = upsample ? 2 * Hi : (stride == 2 ? Hi / 2 : Hi);
+    a.Wo = upsample ? 2 * Wi : (stride == 2 ? Wi / 2 : Wi);
+    a.taps = taps; a.stride = stride; a.upsample = upsample; a.N = N; a.w = (const f16*)w; a.bias = (const f16*)bias;
+    a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes; a.gn_stats = gn_stats;
+    if (gn_stats && (a.Ho * a.Wo) % 64) CS_FAIL(CS_E_SHAPE, "conv2d_gn: Ho * Wo = %d must be a multiple of 64", a.Ho * a.Wo);
     return launch_igemm(a, (hipStream_t)stream);
 }
 
@@ -159,6 +176,16 @@ int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int 
     GroupNormArgs a{};
     a.x0 = (const f16*)x0; a.x1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
     a.gamma = (const f16*)gamma; a.beta = (const f16*)beta; a.partial = (float*)workspace; a.out = (f16*)out;
+    return launch_group_norm(a, (hipStream_t)stream);
+}
+
+int cs_op_group_norm_pre(const void* x0, int c0, const float* stats0, const void* x1, int c1, const float* stats1, int B, int HW, int groups,
+                         float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream) {
+    if (HW % 64) CS_FAIL(CS_E_SHAPE, "group_norm_pre: HW = %d must be a multiple of 64", HW);
+    GroupNormArgs a{};
+    a.x0 = (const f16*)x0; a.x1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
+    a.gamma = (const f16*)gamma; a.beta = (const f16*)beta; a.partial = (float*)workspace; a.out = (f16*)out;
+    a.stats0 = stats0; a.S0 = HW / 64; a.stats1 = stats1; a.S1 = HW / 64;
     return launch_group_norm(a, (hipStream_t)stream);
 }
 

@@ -26,7 +26,8 @@ def pack_conv_weight(w):
 _SPLITK_WS = {}
 
 
-def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, splitk=True):
+def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, splitk=True, gn_stats=False):
+    """gn_stats=True: also return the GroupNorm partial sums of the output, fp32 [B, Ho*Wo/64, N/2, 2] (cs_op_conv2d_gn)."""
     _f16(x0, "x0")
     B, Hi, Wi, c0 = x0.shape
     c1 = x1.shape[-1] if x1 is not None else 0
@@ -40,6 +41,12 @@ def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, t
         ws = _SPLITK_WS.get(x0.device)
         if ws is None:
             ws = _SPLITK_WS[x0.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x0.device)
+    if gn_stats:
+        st = torch.zeros(B, Ho * Wo // 64, N // 2, 2, dtype=torch.float32, device=x0.device)
+        L.check(L.lib().cs_op_conv2d_gn(L.ptr(x0), c0, L.ptr(x1), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
+                                        L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(out),
+                                        L.ptr(ws), ws.numel() if ws is not None else 0, L.ptr(st), L.stream_ptr(x0.device)))
+        return out, st
     L.check(L.lib().cs_op_conv2d(L.ptr(x0), c0, L.ptr(x1), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
                                  L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(out),
                                  L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x0.device)))
@@ -82,7 +89,8 @@ def attention(q, k, v, heads, scale=None, q_stride=None, k_stride=None, v_stride
     return out
 
 
-def group_norm(x0, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None):
+def group_norm(x0, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None, stats0=None, stats1=None):
+    """stats0 / stats1: partial sums of x0 / x1 written by their producer (conv2d(gn_stats=True)); that source's statistics pass is skipped."""
     _f16(x0, "x0")
     B = x0.shape[0]
     c0 = x0.shape[-1]
@@ -90,6 +98,10 @@ def group_norm(x0, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None):
     HW = x0.numel() // (B * c0)
     ws = torch.empty(int(L.lib().cs_op_group_norm_workspace(B, c0 + c1)), dtype=torch.uint8, device=x0.device)
     out = torch.empty(x0.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x0.device)
+    if stats0 is not None or stats1 is not None:
+        L.check(L.lib().cs_op_group_norm_pre(L.ptr(x0), c0, L.ptr(stats0), L.ptr(x1), c1, L.ptr(stats1), B, HW, groups, float(eps), int(silu),
+                                             L.ptr(gamma), L.ptr(beta), L.ptr(ws), L.ptr(out), L.stream_ptr(x0.device)))
+        return out
     L.check(L.lib().cs_op_group_norm(L.ptr(x0), c0, L.ptr(x1), c1, B, HW, groups, float(eps), int(silu), L.ptr(gamma),
                                      L.ptr(beta), L.ptr(ws), L.ptr(out), L.stream_ptr(x0.device)))
     return out

@@ -29,6 +29,15 @@ int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, 
                  const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
                  void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 
+/* cs_op_conv2d that also leaves the GroupNorm statistics of its OUTPUT in gn_stats (device, fp32):
+ *   gn_stats[B][Ho*Wo/64][N/2][2] = (sum, sum of squares) of the channel pair (2q, 2q+1) over each 64-pixel block of a sample
+ * (the block order inside a sample is the kernel's own; only sums over all blocks are meaningful).  Written by the conv epilogue from the
+ * final fp16 values (after bias / temb / residual), or by a statistics pass when the chosen kernel has none (split-K forms).
+ * Needs Ho*Wo % 64 == 0.  Consumer: cs_op_group_norm_pre.  (diffusers ResnetBlock2D: norm2 follows conv1, the next block's norm1 follows conv2.) */
+int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
+                    const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
+                    void* splitk_ws, size_t splitk_ws_bytes, float* gn_stats, void* stream);
+
 /* out[M,N] = x[M,K] w[N,K]^T + bias + res ; geglu != 0: w rows pre-permuted in (16 value | 16 gate)
  * blocks (see cs_op_geglu_pack) and out[M,N/2] = value * gelu(gate). */
 int cs_op_linear(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, void* out, int geglu, void* stream);
@@ -47,6 +56,11 @@ int cs_op_attention(const void* q, int q_stride, const void* k, int k_stride, co
 size_t cs_op_group_norm_workspace(int B, int C);
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,
                      const void* gamma, const void* beta, void* workspace, void* out, void* stream);
+
+/* cs_op_group_norm with the statistics pass skipped for the sources whose producer already wrote them (cs_op_conv2d_gn layout, HW/64
+ * blocks per sample); stats0 / stats1 may be NULL (that source is then reduced here).  HW % 64 == 0. */
+int cs_op_group_norm_pre(const void* x0, int c0, const float* stats0, const void* x1, int c1, const float* stats1, int B, int HW, int groups,
+                         float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream);
 
 /* Fused cross-attention sub-block of the SD1.5 transformer block (diffusers BasicTransformerBlock: norm2 -> attn2 -> residual; reference
  * call site denoise_ppo.py:89-94) at C = 320, 8 heads, <= 80 context keys:
@@ -107,6 +121,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                1 + static priority for the staggered wave group, 2 + that group's LDS-DMA issues spread among its MFMAs;
  *   "xattn_fused": 1 (default): the cross-attention sub-block at C = 320 runs as one kernel (cs_op_xattn_block) inside cs_unet_forward;
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
+ *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
+ *                cs_op_conv2d_gn, 0 always a separate statistics pass;
  *   "gemm_ring": 1 (default) the 256-row GEMM kernel reads its LDS fragments through a hand-placed ring, 0 the compiler's order;
  *   "gemm_stag": 1 the staggered k32 three-stage variant of that kernel (measured experiment, default 0);
  *   "attn_prio" / "gemm2_prio": static wave priority experiments (attn_prio -1 = auto: head dim 128 only);

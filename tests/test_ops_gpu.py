@@ -278,6 +278,70 @@ def test_group_norm(B, HW, c0, c1, silu, eps):
     assert float((out.float() - ref).abs().max()) < 6e-3
 
 
+GN_FUSE_CASES = [
+    # B, H, cin, c1 (second input source), N, taps, stride, up, temb, res   -- which kernel the shape selects
+    (2, 64, 64, 0, 320, 9, 1, False, True, False),     # halo conv, 256 x 320 k32 tiles (resnet conv1: + temb)
+    (2, 32, 128, 0, 640, 9, 1, False, False, True),    # halo conv wide tiles, + residual (resnet conv2)
+    (3, 16, 128, 0, 160, 9, 1, False, True, True),     # halo conv 256 x 160
+    (4, 8, 320, 0, 320, 9, 1, False, False, True),     # 8 x 8 images: four per tile, one per wave
+    (2, 16, 64, 0, 320, 9, 1, True, False, False),     # fused x2 upsample (32 x 32 out)
+    (2, 32, 128, 0, 128, 9, 2, False, False, False),   # stride-2 downsample: generic kernel
+    (8, 8, 1280, 0, 320, 9, 1, False, False, True),    # split-K form: statistics pass fallback
+    (32, 64, 320, 0, 320, 1, 1, False, False, True),   # 1x1 (proj_out + residual): 256 x 320 GEMM
+    (2, 16, 640, 0, 1280, 1, 1, False, False, True),   # 1x1, few tiles: generic / 256 x 160 GEMM
+    (2, 8, 64, 64, 128, 9, 1, False, True, True),      # two-source input (generic kernel)
+]
+
+
+@pytest.mark.parametrize("case", GN_FUSE_CASES)
+def test_conv_output_group_norm_statistics(case):
+    """cs_op_conv2d_gn: the partial sums the epilogue (or the fallback pass) leaves equal the sums of the fp16 output it stored, and
+    cs_op_group_norm_pre on them equals cs_op_group_norm on the tensor."""
+    B, H, cin, c1, N, taps, stride, up, use_t, use_r = case
+    k = 3 if taps == 9 else 1
+    x0 = rnd(B, H, H, cin, seed=1)
+    x1 = rnd(B, H, H, c1, seed=2) if c1 else None
+    w = rnd(N, cin + c1, k, k, seed=3, scale=(1.0 / ((cin + c1) * taps)) ** 0.5)
+    bias = rnd(N, seed=4, scale=0.1)
+    temb = rnd(B, N, seed=5, scale=0.5) if use_t else None
+    Ho = 2 * H if up else (H // 2 if stride == 2 else H)
+    res = rnd(B, Ho, Ho, N, seed=6) if use_r else None
+    wp = ops.pack_conv_weight(w)
+    plain = ops.conv2d(x0, wp, bias, x1=x1, taps=taps, stride=stride, upsample=up, temb=temb, res=res)
+    out, st = ops.conv2d(x0, wp, bias, x1=x1, taps=taps, stride=stride, upsample=up, temb=temb, res=res, gn_stats=True)
+    assert torch.equal(out, plain)                                   # the statistics do not change what is stored
+    assert st.shape == (B, Ho * Ho // 64, N // 2, 2)
+    o = out.float().reshape(B, Ho * Ho, N // 2, 2)
+    want_sum, want_sq = o.sum(dim=(1, 3)).double(), (o * o).sum(dim=(1, 3)).double()
+    got = st.double().sum(dim=1)                                     # over the 64-pixel blocks of a sample
+    scale = (o * o).sum(dim=(1, 3)).double().sqrt().clamp_min(1.0)
+    assert float(((got[..., 0] - want_sum).abs() / (scale * (Ho * Ho) ** 0.5)).max()) < 2e-5
+    assert float(((got[..., 1] - want_sq).abs() / want_sq.clamp_min(1e-6)).max()) < 2e-5
+    g, b = (1 + 0.2 * rnd(N, seed=7)), 0.1 * rnd(N, seed=8)
+    flat = out.reshape(B, Ho * Ho, N)
+    G = 32 if (N // 32) % 2 == 0 else 16                             # the statistics are kept per channel PAIR: even channels per group
+    a = ops.group_norm(flat, g, b, G, 1e-5, True)
+    c = ops.group_norm(flat, g, b, G, 1e-5, True, stats0=st)
+    assert rel_l2(c.float(), a.float()) < 2e-4
+    ref = F.silu(F.group_norm(flat.float().transpose(1, 2), G, g.float(), b.float(), 1e-5)).transpose(1, 2)
+    assert rel_l2(c.float(), ref) < 1e-3
+
+
+def test_group_norm_two_sources_with_one_precomputed():
+    """skip-concat GroupNorm (960 = 640 + 320 channels: groups straddle the sources) with the statistics of one / both sources supplied."""
+    B, H = 2, 16
+    a_in, b_in = rnd(B, H, H, 128, seed=1), rnd(B, H, H, 64, seed=2)
+    wa = rnd(640, 128, 3, 3, seed=3, scale=(1.0 / (128 * 9)) ** 0.5); wb = rnd(320, 64, 3, 3, seed=4, scale=(1.0 / (64 * 9)) ** 0.5)
+    xa, sa = ops.conv2d(a_in, ops.pack_conv_weight(wa), None, gn_stats=True)
+    xb, sb = ops.conv2d(b_in, ops.pack_conv_weight(wb), None, gn_stats=True)
+    xa, xb = xa.reshape(B, H * H, 640), xb.reshape(B, H * H, 320)
+    g, b = (1 + 0.2 * rnd(960, seed=7)), 0.1 * rnd(960, seed=8)
+    ref = F.silu(F.group_norm(torch.cat([xa, xb], -1).float().transpose(1, 2), 32, g.float(), b.float(), 1e-5)).transpose(1, 2)
+    for s0, s1 in ((sa, sb), (sa, None), (None, sb)):
+        out = ops.group_norm(xa, g, b, 32, 1e-5, True, x1=xb, stats0=s0, stats1=s1)
+        assert rel_l2(out.float(), ref) < 1e-3
+
+
 @pytest.mark.parametrize("M,C", [(7, 320), (256, 640), (1000, 1280)])
 def test_layer_norm(M, C):
     x = rnd(M, C, seed=1) * 3 + 1
