@@ -25,6 +25,7 @@
 #include <cmath>
 
 int g_tune_xattn_fused = 1;    // 1 (default): the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
+extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
 int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
 
 namespace {
@@ -283,7 +284,17 @@ struct Run {
         }
         return (f16*)p;
     }
-    void release(const void* p) { u->arena.free(const_cast<void*>(p)); }
+    // GroupNorm statistics a producer left for a tensor (IgemmArgs::gn_stats): tensor -> partial sums, alive as long as the tensor
+    struct StatRec { float* stats; int S; };
+    std::map<const void*, StatRec> stat_of;
+    void release(const void* p) {
+        auto it = stat_of.find(p);
+        if (it != stat_of.end()) { u->arena.free(it->second.stats); stat_of.erase(it); }
+        u->arena.free(const_cast<void*>(p));
+    }
+    bool stats_fusable(int HW, int C) const { return g_tune_gn_fuse != 0 && HW % 64 == 0 && C % 2 == 0; }
+    // partial-sum buffer for a [Bt][HW][C] tensor about to be produced (Bt samples); registered under `out` by the caller
+    float* alloc_stats(int Bt, int HW, int C) { return (float*)alloc((size_t)Bt * (HW / 64) * C * 2); }      // C/2 pairs x 2 floats = C floats = 2C halfs
 
     template <typename F> void launch(int cls, double flops, double bytes, F&& f) {
         if (dry) { u->dry_flops += flops; return; }
@@ -299,9 +310,16 @@ struct Run {
         }
     }
 
+    // want_stats: the output feeds a GroupNorm (or a skip connection that does): its statistics come out of the epilogue.
+    // stats_into: write them into this (larger) buffer instead of a fresh one, nothing registered (two launches filling one tensor).
     void conv(const Conv& c, const f16* a0, int c0, const f16* a1, int c1, int Hi, int Wi, int Ho, int Wo, int stride, int up,
-              const f16* temb, const f16* res, f16* out) {
+              const f16* temb, const f16* res, f16* out, bool want_stats = false, float* stats_into = nullptr) {
         IgemmArgs a{};
+        if (stats_into) a.gn_stats = stats_into;
+        else if (want_stats && stats_fusable(Ho * Wo, c.cout)) {
+            a.gn_stats = alloc_stats(B, Ho * Wo, c.cout);
+            if (a.gn_stats) stat_of[out] = {a.gn_stats, Ho * Wo / 64};
+        }
         a.a0 = a0; a.a1 = a1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.taps = c.taps; a.stride = stride;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res; a.out = out; a.geglu = 0;
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
@@ -320,7 +338,12 @@ struct Run {
         GroupNormArgs a{};
         a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = u->cfg.norm_num_groups; a.eps = n.eps; a.silu = silu;
         a.gamma = n.g; a.beta = n.b; a.partial = gn_ws; a.out = out;
-        launch(P_GROUPNORM, 0, 2.0 * 3.0 * B * HW * (double)(c0 + c1), [&] { return launch_group_norm(a, s); });
+        auto i0 = stat_of.find(x0);
+        if (i0 != stat_of.end()) { a.stats0 = i0->second.stats; a.S0 = i0->second.S; }
+        auto i1 = x1 ? stat_of.find(x1) : stat_of.end();
+        if (i1 != stat_of.end()) { a.stats1 = i1->second.stats; a.S1 = i1->second.S; }
+        const double passes = 2.0 + ((a.stats0 ? 0.0 : (double)c0) + (x1 && !a.stats1 ? (double)c1 : 0.0)) / (double)(c0 + c1);
+        launch(P_GROUPNORM, 0, 2.0 * passes * B * HW * (double)(c0 + c1), [&] { return launch_group_norm(a, s); });
     }
     void layer_norm(const Norm& n, const f16* x, int M, f16* out) {
         launch(P_LAYERNORM, 0, 2.0 * 2.0 * M * (double)n.c, [&] { return launch_layer_norm(x, n.g, n.b, out, M, n.c, n.eps, s); });
@@ -349,7 +372,7 @@ struct Run {
         f16* n1 = alloc(M * (cx + cs));
         group_norm(r.n1, x, cx, skip, cs, HW, true, n1);
         f16* h1 = alloc(M * r.cout);
-        conv(r.c1, n1, cx + cs, nullptr, 0, H, W, H, W, 1, 0, tproj + r.temb_off, nullptr, h1);
+        conv(r.c1, n1, cx + cs, nullptr, 0, H, W, H, W, 1, 0, tproj + r.temb_off, nullptr, h1, true);      // -> norm2
         release(n1);
         f16* n2 = alloc(M * r.cout);
         group_norm(r.n2, h1, r.cout, nullptr, 0, HW, true, n2);
@@ -357,7 +380,7 @@ struct Run {
         f16* out = alloc(M * r.cout);
         const f16* res = x;
         if (r.has_sc) { conv(r.sc, x, cx, skip, cs, H, W, H, W, 1, 0, nullptr, nullptr, out); res = out; }
-        conv(r.c2, n2, r.cout, nullptr, 0, H, W, H, W, 1, 0, nullptr, res, out);
+        conv(r.c2, n2, r.cout, nullptr, 0, H, W, H, W, 1, 0, nullptr, res, out, true);                     // -> the next block's GroupNorm / a skip
         release(n2);
         return out;
     }
@@ -395,7 +418,7 @@ struct Run {
         linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, h, 0);
         release(ff);
         // proj_out + residual with the block input
-        conv(X.proj_out, h, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x, g);
+        conv(X.proj_out, h, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x, g, true);
         release(h);
         return g;
     }
@@ -469,10 +492,13 @@ f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, 
     R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, h, 0);
     R.release(ff);
     // proj_out + residual with the block input, which exists once: one launch per half
+    float* st = R.stats_fusable(HW, C) ? R.alloc_stats(Bfull, HW, C) : nullptr;     // one statistics buffer for the full batch, filled per half
     R.B = n_lat;
     for (int half = 0; half < 2; ++half)
-        R.conv(X.proj_out, h + (size_t)half * M1 * C, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x_half, g + (size_t)half * M1 * C);
+        R.conv(X.proj_out, h + (size_t)half * M1 * C, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x_half, g + (size_t)half * M1 * C, false,
+               st ? st + (size_t)half * n_lat * (HW / 64) * C : nullptr);
     R.B = Bfull;
+    if (st) R.stat_of[g] = {st, HW / 64};
     R.release(h);
     return g;
 }
@@ -536,7 +562,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
         }
         if (u->has_down[i]) {
             f16* d = R.alloc((size_t)B * (H / 2) * (W / 2) * ch);
-            R.conv(u->down_samp[i], h, ch, nullptr, 0, H, W, H / 2, W / 2, 2, 0, nullptr, nullptr, d);
+            R.conv(u->down_samp[i], h, ch, nullptr, 0, H, W, H / 2, W / 2, 2, 0, nullptr, nullptr, d, true);
             H /= 2; W /= 2; h = d; skips.push_back({h, ch});
         }
     }
@@ -559,7 +585,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
         }
         if (u->has_up[i]) {
             f16* d = R.alloc((size_t)B * (2 * H) * (2 * W) * ch);
-            R.conv(u->up_samp[i], h, ch, nullptr, 0, H, W, 2 * H, 2 * W, 1, 1, nullptr, nullptr, d);
+            R.conv(u->up_samp[i], h, ch, nullptr, 0, H, W, 2 * H, 2 * W, 1, 1, nullptr, nullptr, d, true);
             R.release(h); H *= 2; W *= 2; h = d;
         }
     }
@@ -675,9 +701,10 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
     // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
     size_t peak = 0;
-    const int knob_share = g_tune_cfg_share, knob_fused = g_tune_xattn_fused;
-    for (int fused = 0; fused < 2; ++fused) {
-        g_tune_xattn_fused = fused;
+    const int knob_share = g_tune_cfg_share, knob_fused = g_tune_xattn_fused, knob_gn = g_tune_gn_fuse;
+    for (int variant = 0; variant < 4; ++variant) {
+        const int fused = variant & 1;
+        g_tune_xattn_fused = fused; g_tune_gn_fuse = variant >> 1;
         run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
         peak = std::max(peak, u->arena.peak);
         if (batch % 2 == 0) {
@@ -687,7 +714,7 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
             g_tune_cfg_share = knob_share;
         }
     }
-    g_tune_xattn_fused = knob_fused;
+    g_tune_xattn_fused = knob_fused; g_tune_gn_fuse = knob_gn;
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;
 }
 

@@ -167,3 +167,29 @@ def test_fused_cross_attention_block_matches_the_four_kernel_path():
     assert e_ff < 1.25 * (e_fused ** 2 + e_four ** 2) ** 0.5          # two independent roundings of the same fp32 function
     assert e_fused < 1.15 * e_four + 1e-4          # the fusion costs no accuracy
     assert e_fused < 3.0e-3 and e_four < 3.0e-3
+
+
+def test_group_norm_statistics_from_the_producers_match_the_statistics_pass():
+    """cs_unet_forward with the GroupNorm statistics taken from the producing conv / 1x1 epilogues (gn_fuse = 1, default) against the same
+    forward with a statistics pass per GroupNorm: the same sums in a different order."""
+    from consolver_amd import ops
+    for cfg_over, n_lat in ((dict(layers_per_block=1, sample_size=16), 2), ({}, 1)):
+        u, orc = build(cfg_over)
+        S = u.config["sample_size"]
+        g = torch.Generator().manual_seed(5)
+        lat = torch.randn(n_lat, 4, S, S, generator=g).half().to(DEV)
+        ctx = synthetic_prompt_embeds(2 * n_lat, seed=19).half().to(DEV)
+        try:
+            ops.set_tuning("gn_fuse", 0)
+            sep = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+            ops.set_tuning("gn_fuse", 1)
+            fused = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+        finally:
+            ops.set_tuning("gn_fuse", 1)
+        want = orc(torch.cat([lat.cpu().float()] * 2), 499, ctx.cpu().float())
+        e_fs, e_f, e_s = rel_l2(fused, sep), rel_l2(fused, want), rel_l2(sep, want)
+        print(f"sample_size {S}: fused vs pass {e_fs:.3e}; vs fp32 oracle: fused {e_f:.3e}, pass {e_s:.3e}")
+        assert torch.isfinite(fused).all()
+        assert e_fs < 1.25 * (e_f ** 2 + e_s ** 2) ** 0.5              # two rounding realisations of the same fp32 function (any perturbation decorrelates the fp16 roundings downstream)
+        assert e_f < 1.1 * e_s + 1e-4
+        del u
