@@ -92,5 +92,18 @@ if which in ("xattn",):
     ms = timeit(unfused)
     rows.append(("LN + to_q + attn + to_out (4 kernels)", M, Nk, C, ms, fl / ms / 1e9))
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
+if which in ("gn",):
+    # GroupNorm + SiLU: statistics pass + finalize + apply ("full") against finalize + apply on producer-written partial sums ("pre")
+    for H, c0, c1, tag in [(64, 320, 0, "L0"), (64, 320, 320, "L0 cat"), (64, 640, 320, "L0 cat"), (32, 640, 0, "L1"), (32, 1280, 640, "L1 cat"),
+                           (16, 1280, 0, "L2"), (16, 1280, 1280, "L2 cat"), (8, 1280, 1280, "L3 cat")]:
+        x0 = rnd(B, H * H, c0); x1 = rnd(B, H * H, c1) if c1 else None
+        C = c0 + c1
+        g, b = rnd(C), rnd(C)
+        s0 = torch.zeros(B, H * H // 64, c0 // 2, 2, device=dev); s1 = torch.zeros(B, H * H // 64, max(c1, 2) // 2, 2, device=dev) if c1 else None
+        byt = 2.0 * B * H * H * C
+        ms = timeit(lambda: ops.group_norm(x0, g, b, 32, 1e-5, True, x1=x1))
+        rows.append((f"group_norm full {tag}", B * H * H, C, 0, ms, 3 * byt / ms / 1e9))
+        ms = timeit(lambda: ops.group_norm(x0, g, b, 32, 1e-5, True, x1=x1, stats0=s0, stats1=s1))
+        rows.append((f"group_norm pre  {tag}", B * H * H, C, 0, ms, 2 * byt / ms / 1e9))
 for r in rows:
     print(f"{r[0]:40s} {r[1]:8d} {r[2]:8d} {r[3]:6d} {r[4]:9.3f} {r[5] / 1e3:9.1f}")
