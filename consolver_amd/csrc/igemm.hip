@@ -47,6 +47,7 @@ struct IgemmParams {
     float* partial;     // split-K scratch of the generic kernel ([splits][M][N] fp32) or null
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
     float* gn_stats;    // GroupNorm partial sums of the output, [M / 64][N / 2][2], written by the epilogue (IgemmArgs::gn_stats) or null
+    int gm;             // gemm_big_kernel tile order: bands of gm tile rows walked column-major (1 = plain row-major)
 };
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
 // layers were bound by L2->LDS traffic (the activation panel was re-staged N/160 times), not MFMA.
 // Two LDS stages (144 KB), one workgroup per CU, 9 DMA issues per wave per 80 MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <bool GEGLU, int BNX, bool RING = false>
+template <bool GEGLU, int BNX, int RING = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     // BNX = 320: wave tile 64 x 160 (every SD1.5 width >= 320 with enough rows); BNX = 160: wave tile 64 x 80 for the 1280-wide layers
     // at 16 x 16 (M = 8192: 32 x 8 = 256 tiles = one per CU, where 256 x 320 tiles would leave half the chip idle)
@@ -567,7 +568,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    // tile order: an XCD's ~32 resident workgroups hold consecutive ids.  Row-major order makes them 32 / tiles_n activation panels x ALL
+    // tiles_n weight panels per k step through that XCD's L2; bands of gm tile rows walked column-major make it gm x 32 / gm
+    // (the FLUX GEMM's order, csrc/gemm2.hip).
+    int tm, tn;
+    if (p.gm > 1) {
+        const int tiles_m = p.nblk / p.tiles_n;
+        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
+        const int gsz = min(p.gm, tiles_m - band * p.gm);
+        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
+    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
     const int m_blk = tm * BMX, n_blk = tn * BNX;
 
     const int pch = lane & 7;
@@ -649,6 +659,79 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     const bool tr = (p.debug & 16384) && lane == 0 && w == 0 && blockIdx.x < CS_TRACE_SLOTS;
     unsigned long long tsum[4] = {0, 0, 0, 0}, tc0 = 0;
     if (tr) tc0 = __builtin_readcyclecounter();
+    if constexpr (RING >= 2) {
+        // PIPELINED form (the FLUX GEMM's structure, csrc/gemm2.hip, on this tile): the per-step barrier sits at three quarters of the step.
+        // Before it a wave has ALL of the stage's fragments in registers (the last NT/2 weight fragments are read ahead into a five-slot
+        // ring), so after it (i) the buffer just released is re-filled in place with stage kt + 2 while (ii) the remaining MFMAs of step kt
+        // issue and (iii) the first fragments of step kt + 1 are read from the other buffer underneath them: no wave stands behind the
+        // barrier with an empty matrix pipe waiting for an LDS read.  A stage's DMA pieces are issued one per item: the first NPOST after the
+        // barrier of step kt - 2 + ... (activations, HBM), the rest in the first items of the step before its use (weights, L2).
+        constexpr int NQ = 2 * NT, NP = 4 + BPW, NPOST = NT / 2, QB = NQ - NPOST, APP = (MT + NPOST - 1) / NPOST;
+        static_assert(NQ % 5 == 0 && NP - NPOST <= QB - 1 && NPOST >= 2, "ring / piece placement");
+        const bool staging = !(p.debug & 32768);
+        auto rd_w = [&](const char* tbx, int q) { const int ks = q / NT, i = q - ks * NT; return *reinterpret_cast<const f16x8*>(tbx + i * 2048 + (ks ? frag_off1 : frag_off0)); };
+        // weight fragments are read LA items ahead of their MFMAs into the five-slot ring (slot = item index % 5, continuous across steps)
+        constexpr int LA = 2;                                          // (3 and 4 measured the same: profiles/r02_ab_gemm_pipe.txt)
+        static_assert(LA >= 1 && LA <= 4, "lookahead");
+        auto upto = [](int q) { return q + LA < NQ - 2 ? q + LA : NQ - 2; };      // highest fragment of this stage issued before item q's MFMAs (q < QB)
+        f16x8 fa[2][MT], fw[5];
+        if (p.KT > 1 && staging) {
+#pragma unroll
+            for (int n = 0; n < NPOST; ++n) stage_piece(1, 1, n);
+        }
+        {
+            const char* ta0 = smem + (wm * 64) * 128;
+            const char* tb0 = smem + A_BYTES + (wn * (BNX / 2)) * 128;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) fa[0][j] = *reinterpret_cast<const f16x8*>(ta0 + j * 2048 + frag_off0);
+#pragma unroll
+            for (int r = 0; r < LA; ++r) fw[r] = rd_w(tb0, r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (int kt = 0; kt < KTX; ++kt) {
+            const int buf = kt & 1;
+            const char* ta = smem + buf * STAGE + (wm * 64) * 128;
+            const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
+            const char* tan = smem + (buf ^ 1) * STAGE + (wm * 64) * 128;
+            const char* tbn = smem + (buf ^ 1) * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
+            const bool more = kt + 1 < p.KT, more2 = kt + 2 < p.KT;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ks = q / NT, i = q - ks * NT;
+                if (q == QB && more) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // stage kt + 1 has landed; this wave's reads of stage kt are done
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (q < QB) {                          // (at item QB - 1: the rest of this stage; its last fragment shares that item's ring slot -> after its MFMAs)
+                    const int lo = (q == 0 ? LA - 1 : upto(q - 1)) + 1, hi = q == QB - 1 ? NQ - 2 : upto(q);
+#pragma unroll
+                    for (int r = lo; r <= hi; ++r) fw[r % 5] = rd_w(tb, r);
+                } else if (q + LA >= NQ && more) fw[(q + LA) % 5] = rd_w(tbn, q + LA - NQ);
+                if (ks == 0 && i >= NT - MT) fa[1][i - (NT - MT)] = *reinterpret_cast<const f16x8*>(ta + (i - (NT - MT)) * 2048 + frag_off1);
+                if (q >= QB && more) {
+#pragma unroll
+                    for (int t = 0; t < APP; ++t) {
+                        const int j = (q - QB) * APP + t;
+                        if (j < MT) fa[0][j] = *reinterpret_cast<const f16x8*>(tan + j * 2048 + frag_off0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[q % 5], fa[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == QB - 1) { fw[(NQ - 1) % 5] = rd_w(tb, NQ - 1); __builtin_amdgcn_sched_barrier(0); }
+                if (q >= QB) {
+                    if (staging && more2 && q - QB < NP) stage_piece(kt + 2, buf, q - QB);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (q < NP - NPOST) {
+                    if (staging && more) stage_piece(kt + 1, buf ^ 1, NPOST + q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();                            // the stage buffers become the epilogue patches
+    } else
     for (int kt = 0; kt < KTX; ++kt) {
         const int buf = kt & 1;
         unsigned long long ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
@@ -659,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
         const char* ta = smem + buf * STAGE + (wm * 64) * 128;
         const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
         if (p.debug & 16384) { __builtin_amdgcn_sched_barrier(0); tb_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr (RING) {
+        if constexpr (RING == 1) {
             // fragment reads run a RING of two weight fragments ahead of the MFMAs that consume them, and the second half-step's
             // activation fragments are read under the first half's last MFMAs: every wait is a counted lgkmcnt(N > 0).  (The compiler's
             // own order is read two fragments -> lgkmcnt(0) -> eight MFMAs, ten exposed LDS latencies per k step.)
@@ -1018,7 +1101,8 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 
 int g_tune_debug = 0;
 int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
-int g_tune_gemm_ring = 1;      // 1: gemm_big_kernel with the hand-placed fragment-read ring (0: the compiler's order)
+int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
+int g_tune_gemm_ring = 2;      // gemm_big_kernel k loop: 2 pipelined (barrier at 3/4 of the step, in-place refill; default), 1 fragment ring + spread DMA, 0 the compiler's order
 int g_tune_gemm_stag = 0;      // 1: 256 x 320 linear / 1x1 layers through gemm_stag_kernel instead of gemm_big_kernel<.,320>
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
@@ -1068,6 +1152,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
     p.gn_stats = stats_ok ? a.gn_stats : nullptr;
+    p.gm = 1;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
     if (a.N % 128 == 0) bn = 128;
@@ -1135,6 +1220,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 320;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 2) {
             p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
+            p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
             static bool configured = false;
             if (!configured) {
@@ -1162,6 +1248,18 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                     CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     configured_r = true;
                 }
+                if (g_tune_gemm_ring >= 2) {
+                    static bool configured_2 = false;
+                    if (!configured_2) {
+                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        configured_2 = true;
+                    }
+                    if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320, 2>), dim3(p.nblk), dim3(512), lds, s, p);
+                    else hipLaunchKernelGGL((gemm_big_kernel<false, 320, 2>), dim3(p.nblk), dim3(512), lds, s, p);
+                    CS_CHECK_LAUNCH();
+                    return CS_OK;
+                }
                 if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
                 else hipLaunchKernelGGL((gemm_big_kernel<false, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
                 CS_CHECK_LAUNCH();
@@ -1177,6 +1275,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 160;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 3) {
             p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
+            p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 160 * BK * 2);
             static bool configured = false;
             if (!configured) {
@@ -1188,6 +1287,16 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 if (!configured_r) {
                     CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     configured_r = true;
+                }
+                if (g_tune_gemm_ring >= 2) {
+                    static bool configured_2 = false;
+                    if (!configured_2) {
+                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                        configured_2 = true;
+                    }
+                    hipLaunchKernelGGL((gemm_big_kernel<false, 160, 2>), dim3(p.nblk), dim3(512), lds, s, p);
+                    CS_CHECK_LAUNCH();
+                    return CS_OK;
                 }
                 hipLaunchKernelGGL((gemm_big_kernel<false, 160, true>), dim3(p.nblk), dim3(512), lds, s, p);
                 CS_CHECK_LAUNCH();

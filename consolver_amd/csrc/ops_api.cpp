@@ -6,6 +6,7 @@
 extern int g_tune_halo;
 extern int g_tune_debug;
 extern int g_tune_gemm_ring;
+extern int g_tune_gemm_gm;
 extern int g_tune_gn_fuse;
 int debug_trace_read(void* dst, size_t bytes);
 extern int g_tune_cfg_share;
@@ -24,7 +25,8 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
-    if (!strcmp(key, "gemm_ring")) { g_tune_gemm_ring = value ? 1 : 0; return CS_OK; }
+    if (!strcmp(key, "gemm_ring")) { if (value < 0 || value > 2) CS_FAIL(CS_E_ARG, "gemm_ring: 0, 1 or 2"); g_tune_gemm_ring = value; return CS_OK; }
+    if (!strcmp(key, "gemm_gm")) { g_tune_gemm_gm = value; return CS_OK; }
     if (!strcmp(key, "gn_fuse")) { g_tune_gn_fuse = value ? 1 : 0; return CS_OK; }
     if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }

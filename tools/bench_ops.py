@@ -77,6 +77,20 @@ if which in ("gemm2",):
     g2(8192, 3072, 9216, "img qkv"); g2(512, 3072, 9216, "ctx qkv"); g2(8192, 3072, 3072, "img out", gated=True); g2(512, 3072, 3072, "ctx out", gated=True)
     g2(8192, 3072, 12288, "img ff1", act=1); g2(8192, 12288, 3072, "img ff2", gated=True); g2(512, 3072, 12288, "ctx ff1", act=1); g2(512, 12288, 3072, "ctx ff2", gated=True)
     g2(8704, 3072, 9216, "single qkv"); g2(8704, 3072, 12288, "single mlp", act=1); g2(8704, 15360, 3072, "single out", gated=True)
+if which in ("gemm2f16",):
+    # the FLUX transformer GEMM (256 x 256 tiles, software-pipelined k loop with two stages in flight) in fp16 on the UNet linear shapes whose N is a
+    # multiple of 256, next to cs_op_linear (256 x 320 tiles): is its loop structure worth porting to the UNet GEMM?
+    from consolver_amd import _lib as L
+    for tag, M, K, N in [("square", 8192, 8192, 8192), ("qkv L2", 8192, 1280, 3840), ("ff2 L2", 8192, 5120, 1280), ("out L2", 8192, 1280, 1280),
+                         ("ff1 L1 (no geglu)", 32768, 640, 5120), ("ff1 L0 (no geglu)", 131072, 320, 2560), ("ff1 L2 (no geglu)", 8192, 1280, 10240)]:
+        x = rnd(M, K); w = rnd(N, K, scale=K ** -0.5); b = rnd(N)
+        out = torch.empty(M, N, device=dev, dtype=torch.float16); st = L.stream_ptr(x.device)
+        ms2 = timeit(lambda: L.check(L.lib().cs_op_gemm2(L.ptr(x), M, K, L.ptr(w), L.ptr(b), N, None, None, N, M, 0, L.ptr(out), N, 0, 1, st)))
+        o2 = out.clone()
+        ms1 = timeit(lambda: ops.linear(x, w, b, out=out))
+        err = float((o2.float() - out.float()).norm() / out.float().norm())
+        rows.append((f"gemm2 f16 {tag}", M, K, N, ms2, 2.0 * M * K * N / ms2 / 1e9))
+        rows.append((f"linear    {tag} (diff {err:.1e})", M, K, N, ms1, 2.0 * M * K * N / ms1 / 1e9))
 if which in ("xattn",):
     # fused cross-attention sub-block at the 64 x 64 level (batch 32) against the four kernels it replaces
     C, HW, Nk = 320, 4096, 77
