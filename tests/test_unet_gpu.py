@@ -193,3 +193,18 @@ def test_group_norm_statistics_from_the_producers_match_the_statistics_pass():
         assert e_fs < 1.25 * (e_f ** 2 + e_s ** 2) ** 0.5              # two rounding realisations of the same fp32 function (any perturbation decorrelates the fp16 roundings downstream)
         assert e_f < 1.1 * e_s + 1e-4
         del u
+
+
+@pytest.mark.parametrize("sample_size,n_lat", [(24, 3), (8, 5), (40, 1)])
+def test_unet_at_sizes_where_only_some_levels_take_the_fused_paths(sample_size, n_lat):
+    """latent sizes that are not powers of two / tiny: 24 x 24 (576 = 9 x 64 pixels: statistics epilogue through the generic conv kernel, 12 x 12
+    and below fall back to the statistics pass), 8 x 8 (every level below 64 pixels but the first), 40 x 40 -- against the fp32 oracle."""
+    u, orc = build(dict(layers_per_block=1, sample_size=sample_size))
+    g = torch.Generator().manual_seed(13)
+    lat = torch.randn(n_lat, 4, sample_size, sample_size, generator=g)
+    ctx = synthetic_prompt_embeds(2 * n_lat, seed=23)
+    got = u(lat.half().to(DEV), 301, encoder_hidden_states=ctx.half().to(DEV), dup=2, reuse_kv=False)[0]
+    want = orc(torch.cat([lat.half().float()] * 2), 301, ctx.half().float())
+    err = rel_l2(got, want)
+    print(f"sample_size {sample_size}: rel l2 vs fp32 oracle {err:.3e}")
+    assert torch.isfinite(got).all() and err < 2.5e-3, err
