@@ -42,9 +42,12 @@ for tag, M, K, N, res, geglu in shapes:
     cyc = buf[:nwg, 6:12].astype(np.float64)
     span_cyc = cyc[:, 5] - cyc[:, 4]; span_us = us[:, 2] - us[:, 1]
     mhz = np.median(span_cyc / np.maximum(span_us, 1e-3))
-    parts = np.median(cyc[:, 0:4], axis=0) / mhz
-    print("   k loop split, us per workgroup (counter %.0f MHz): DMA issue %.2f | MFMAs + fragment reads %.2f | wait for the DMA %.2f | barrier %.2f ; steps %d"
-          % (mhz, parts[0], parts[1], parts[2], parts[3], K // 64))
+    if mhz > 0:
+        parts = np.median(cyc[:, 0:4], axis=0) / mhz
+        print("   k loop split, us per workgroup (counter %.0f MHz): DMA issue %.2f | MFMAs + fragment reads %.2f | wait for the DMA %.2f | barrier %.2f ; steps %d"
+              % (mhz, parts[0], parts[1], parts[2], parts[3], K // 64))
+    else:
+        print("   k loop split: n/a (the in-loop cycle stamps exist in the gemm_ring = 0 / 1 loops only: CS_TUNE=gemm_ring=1)")
     gaps, firsts = [], []
     for c in np.unique(cu):
         idx = np.where(cu == c)[0]
