@@ -52,7 +52,8 @@ int cs_op_attention(const void* q, int q_stride, const void* k, int k_stride, co
                     int B, int H, int Nq, int Nk, int dh, float scale, void* stream);
 
 /* GroupNorm(groups) [+ SiLU] over the channel concatenation of x0/x1 ([B,HW,c0], [B,HW,c1]) -> out [B,HW,c0+c1].
- * workspace: cs_op_group_norm_workspace(B, c0 + c1) bytes. */
+ * workspace: cs_op_group_norm_workspace(B, c0 + c1) bytes.  c0, c1 multiples of 8; (c0 + c1) / groups EVEN (the partial sums are kept per
+ * channel pair; every SD1.5 / AutoencoderKL width / 32 is): CS_E_SHAPE otherwise. */
 size_t cs_op_group_norm_workspace(int B, int C);
 int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int HW, int groups, float eps, int silu,
                      const void* gamma, const void* beta, void* workspace, void* out, void* stream);
