@@ -106,6 +106,18 @@ if which in ("xattn",):
     ms = timeit(unfused)
     rows.append(("LN + to_q + attn + to_out (4 kernels)", M, Nk, C, ms, fl / ms / 1e9))
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
+if which in ("convgn",):
+    # cost of the GroupNorm-statistics epilogue: the same conv / 1x1 with and without gn_stats
+    for H, cin, cout, taps, res, tag in [(64, 320, 320, 9, True, "L0 conv2"), (64, 960, 320, 9, False, "L0 up conv1"), (32, 640, 640, 9, True, "L1 conv2"),
+                                         (16, 1280, 1280, 9, True, "L2 conv2"), (64, 320, 320, 1, True, "L0 proj_out"), (32, 640, 640, 1, True, "L1 proj_out")]:
+        x = rnd(B, H, H, cin); k = 3 if taps == 9 else 1
+        w = ops.pack_conv_weight(rnd(cout, cin, k, k, scale=(cin * taps) ** -0.5)); b = rnd(cout)
+        r = rnd(B, H, H, cout) if res else None
+        fl = 2.0 * B * H * H * taps * cin * cout
+        ms0 = timeit(lambda: ops.conv2d(x, w, b, taps=taps, res=r))
+        ms1 = timeit(lambda: ops.conv2d(x, w, b, taps=taps, res=r, gn_stats=True))
+        rows.append((f"{tag} plain", B * H * H, taps * cin, cout, ms0, fl / ms0 / 1e9))
+        rows.append((f"{tag} + gn_stats ({(ms1 / ms0 - 1) * 100:+.1f} %)", B * H * H, taps * cin, cout, ms1, fl / ms1 / 1e9))
 if which in ("gn",):
     # GroupNorm + SiLU: statistics pass + finalize + apply ("full") against finalize + apply on producer-written partial sums ("pre")
     for H, c0, c1, tag in [(64, 320, 0, "L0"), (64, 320, 320, "L0 cat"), (64, 640, 320, "L0 cat"), (32, 640, 0, "L1"), (32, 1280, 640, "L1 cat"),
