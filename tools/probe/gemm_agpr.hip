@@ -129,6 +129,141 @@ __global__ __launch_bounds__(256, 1) void gemm_agpr_kernel(const f16* __restrict
     }
 }
 
+// Variant 3: the pipelined step of gemm_big_kernel<.,.,2> on this tile (LDS-DMA staging, AGPR accumulators): barrier at item 12 of 16 with all of the
+// stage's fragments in registers (eight-slot weight-fragment ring); after it the released buffer is re-filled in place with stage kt + 2 (pieces
+// 0..3) and the next step's first fragments are read under the last 32 MFMAs; the other 12 pieces of a stage go one per item into the next step.
+template <int MODE>   // 0: LDS-DMA pieces; 1: no staging inside the loop (timing floor: MFMAs + fragment reads + barrier; results wrong);
+                      // 2: register staging at the same positions: ds_write_b128 of the piece loaded one step earlier, then its register is re-loaded with the following stage
+__global__ __launch_bounds__(256, 1) void gemm_agpr_pipe_kernel(const f16* __restrict__ A, const f16* __restrict__ W, f16* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_n = N / BN;
+    int id;
+    { const int nb = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nb >> 3, r = nb & 7; id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3); }
+    const int GM = 4, band = id / (GM * tiles_n), rem = id - band * (GM * tiles_n), gsz = min(GM, M / BM - band * GM);
+    const int tn = rem / gsz, tm = band * GM + (rem - tn * gsz);
+    const int m_blk = tm * BM, n_blk = tn * BN;
+    const int KT = K / BK;
+    const int pch = lane & 7, lrow = lane >> 3;
+    const f16* a_src[8]; const f16* b_src[8]; int lds_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = w + 4 * j, r = 8 * q + lrow, sw = (pch ^ ((r >> 1) & 7)) * 8;
+        a_src[j] = A + (size_t)(m_blk + r) * K + sw;
+        b_src[j] = W + (size_t)(n_blk + r) * K + sw;
+        lds_off[j] = q * 1024;
+    }
+    // piece n = 0..15 of a stage: even -> activations, odd -> weights
+    auto piece = [&](int kt, int buf, int n) {
+        const int j = n >> 1;
+        glds16(((n & 1) ? b_src[j] : a_src[j]) + (size_t)kt * BK, smem + buf * STAGE + ((n & 1) ? A_BYTES : 0) + lds_off[j]);
+    };
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int swz = (lane >> 1) & 7;
+    const int fo0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16, fo1 = (lane & 15) * 128 + ((4 + (lane >> 4)) ^ swz) * 16;
+    constexpr int NQ = 2 * NT, QB = 12, NPOST = NQ - QB;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) piece(0, 0, n);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (KT > 1) {
+#pragma unroll
+        for (int n = 0; n < NPOST; ++n) piece(1, 1, n);
+    }
+    auto rd_w = [&](const char* tb, int q) { const int ks = q / NT, i = q - ks * NT; return *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? fo1 : fo0)); };
+    f16x8 fa[2][MT], fw[8];
+    {
+        const char* ta0 = smem + (wm * 128) * 128; const char* tb0 = smem + A_BYTES + (wn * 128) * 128;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) fa[0][j] = *reinterpret_cast<const f16x8*>(ta0 + j * 2048 + fo0);
+        fw[0] = rd_w(tb0, 0); fw[1] = rd_w(tb0, 1);
+    }
+    // MODE 2: st[n] holds piece n of the stage that position n writes next: stage 2 for the post-barrier pieces 0..3, stage 1 for pieces 4..15
+    auto psrc = [&](int kt, int n) { const int j = n >> 1; const int kc = kt < KT ? kt : KT - 1; return ((n & 1) ? b_src[j] : a_src[j]) + (size_t)kc * BK; };
+    auto pdst = [&](int buf, int n) { return smem + buf * STAGE + ((n & 1) ? A_BYTES : 0) + lds_off[n >> 1] + lane * 16; };
+    u32x4 st[16];
+    if (MODE == 2) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) st[n] = *reinterpret_cast<const u32x4*>(psrc(n < NPOST ? 2 : 1, n));
+    }
+    asm volatile("s_nop 7\n s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        const char* ta = smem + buf * STAGE + (wm * 128) * 128;
+        const char* tb = smem + buf * STAGE + A_BYTES + (wn * 128) * 128;
+        const char* tan = smem + (buf ^ 1) * STAGE + (wm * 128) * 128;
+        const char* tbn = smem + (buf ^ 1) * STAGE + A_BYTES + (wn * 128) * 128;
+        const int k1 = kt + 1 < KT ? kt + 1 : KT - 1, k2 = kt + 2 < KT ? kt + 2 : KT - 1;      // (past the end: harmless re-loads, the step stays branch-free)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int ks = q / NT, i = q - ks * NT;
+            if (q == QB) {
+                if (MODE == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (register staging: the loads in flight are for LATER stages)
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q < QB - 1) fw[(q + 2) % 8] = rd_w(tb, q + 2);
+            else if (q == QB - 1) {
+#pragma unroll
+                for (int r = q + 2; r < NQ; ++r) fw[r % 8] = rd_w(tb, r);
+            } else if (q + 2 >= NQ) fw[(q + 2) % 8] = rd_w(tbn, q + 2 - NQ);
+            if (ks == 0) fa[1][i] = *reinterpret_cast<const f16x8*>(ta + i * 2048 + fo1);
+            if (q >= QB) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[0][(q - QB) * 2 + t] = *reinterpret_cast<const f16x8*>(tan + ((q - QB) * 2 + t) * 2048 + fo0);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) mfma_a(acc[i][j], fw[q % 8], fa[ks][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 0) {
+                if (q >= QB) piece(k2, buf, q - QB);                   // refill of the buffer just released
+                else piece(k1, buf ^ 1, NPOST + q);                    // the rest of the stage started after the previous step's barrier
+            }
+            if (MODE == 2) {
+                // (loads as inline asm with a hand-counted vmcnt(15) instead of the compiler's waits -- it puts vmcnt(0) in front of the first write
+                //  after the loop's back edge -- measured SLOWER: 1.05 vs 0.96 ms on 8192^3)
+                const int n = q >= QB ? q - QB : NPOST + q;
+                *reinterpret_cast<u32x4*>(pdst(q >= QB ? buf : (buf ^ 1), n)) = st[n];
+                st[n] = *reinterpret_cast<const u32x4*>(psrc(q >= QB ? kt + 3 : kt + 2, n));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = m_blk + wm * 128 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n_blk + wn * 128 + i * 16 + 4 * (lane >> 4);
+            f16x4 o = {(f16)acc[i][j][0], (f16)acc[i][j][1], (f16)acc[i][j][2], (f16)acc[i][j][3]};
+            *reinterpret_cast<f16x4*>(C + (size_t)m * N + n) = o;
+        }
+    }
+}
+
+template <int MODE>
+static float run_pipe(const f16* A, const f16* W, f16* C, int M, int N, int K, int reps) {
+    auto gemm_agpr_pipe_kernel = ::gemm_agpr_pipe_kernel<MODE>;
+    hipFuncSetAttribute((const void*)gemm_agpr_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    const int grid = (M / BM) * (N / BN);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(gemm_agpr_pipe_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, A, W, C, M, N, K);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_agpr_pipe_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, A, W, C, M, N, K);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
 template <int REGSTAGE, bool ASM>
 static float run(const f16* A, const f16* W, f16* C, int M, int N, int K, int reps) {
     auto k = gemm_agpr_kernel<REGSTAGE, ASM>;
@@ -144,7 +279,7 @@ static float run(const f16* A, const f16* W, f16* C, int M, int N, int K, int re
 }
 
 int main() {
-    const int shapes[][3] = {{8192, 8192, 8192}, {8192, 3840, 1280}, {8192, 10240, 1280}, {32768, 5120, 640}, {131072, 2560, 320}};
+    const int shapes[][3] = {{8192, 8192, 8192}, {131072, 256, 2880}, {32768, 512, 5760}, {8192, 3840, 1280}, {8192, 10240, 1280}, {32768, 5120, 640}, {131072, 2560, 320}};
     for (auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         std::vector<f16> hA((size_t)M * K), hW((size_t)N * K);
@@ -162,6 +297,9 @@ int main() {
         t[2] = run<1, false>(A, W, C, M, N, K, 5);
         t[3] = run<1, true>(A, W, C, M, N, K, 5);
         t[4] = run<2, true>(A, W, C, M, N, K, 5);
+        const float tn = run_pipe<1>(A, W, C, M, N, K, 5);
+        const float tp = run_pipe<0>(A, W, C, M, N, K, 5);
+        const float tr = run_pipe<2>(A, W, C, M, N, K, 5);
         // check the last variant on a few entries
         std::vector<f16> hC((size_t)M * N);
         hipMemcpy(hC.data(), C, hC.size() * 2, hipMemcpyDeviceToHost);
@@ -172,8 +310,8 @@ int main() {
             const double got = (double)(float)hC[(size_t)m * N + n];
             maxrel = fmax(maxrel, fabs(got - ref) / (fabs(ref) + 0.05));
         }
-        printf("M=%6d N=%6d K=%5d  dma/builtin %.3f ms (%.2f PF) | dma/asm-agpr %.3f (%.2f) | regstage/builtin %.3f (%.2f) | regstage/asm-agpr %.3f (%.2f) | pipelined regstage/asm-agpr %.3f (%.2f) | check (last variant) max rel %.2e\n",
-               M, N, K, t[0], fl / t[0] / 1e12, t[1], fl / t[1] / 1e12, t[2], fl / t[2] / 1e12, t[3], fl / t[3] / 1e12, t[4], fl / t[4] / 1e12, maxrel);
+        printf("M=%6d N=%6d K=%5d  dma/builtin %.3f ms (%.2f PF) | dma/asm-agpr %.3f (%.2f) | regstage/builtin %.3f (%.2f) | regstage/asm-agpr %.3f (%.2f) | pipelined regstage/asm-agpr %.3f (%.2f) | pipelined-barrier dma/asm-agpr %.3f (%.2f), without staging %.3f (%.2f), register staging %.3f (%.2f) | check (last variant) max rel %.2e\n",
+               M, N, K, t[0], fl / t[0] / 1e12, t[1], fl / t[1] / 1e12, t[2], fl / t[2] / 1e12, t[3], fl / t[3] / 1e12, t[4], fl / t[4] / 1e12, tp, fl / tp / 1e12, tn, fl / tn / 1e12, tr, fl / tr / 1e12, maxrel);
         hipFree(A); hipFree(W); hipFree(C);
     }
     return 0;
