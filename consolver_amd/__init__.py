@@ -6,7 +6,8 @@ Public surface mirrors the reference's plugin API for this path:
 ``unet(latents, t, encoder_hidden_states=..., return_dict=False)[0]``.  Everything computes in
 hand-written HIP kernels behind ``include/consolver_hip.h``; there is no CPU fallback.
 """
-from .scheduling_ppo import PPOScheduler, SolverConfig, SolverOutput  # noqa: F401
+from .scheduling_ppo import PPOScheduler, SolverOutput  # noqa: F401
+from ._scheduler_base import HAVE_DIFFUSERS, SolverConfig  # noqa: F401
 from .scheduling_fmppo import FMPPOScheduler  # noqa: F401
 from .factor_net import FactorNetPPO, FluxFactorNetPPO  # noqa: F401
 

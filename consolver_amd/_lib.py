@@ -70,6 +70,8 @@ SYMBOLS = {
     "cs_target_arch": (C.c_char_p, []),
     "cs_factor_probs": (C.c_int, [C.POINTER(CsFactorNet), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cs_cosine_features": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_cosine_features_cfg": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     "cs_sample_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_gather_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_action_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

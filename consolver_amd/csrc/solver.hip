@@ -316,25 +316,43 @@ __global__ __launch_bounds__(1024) void factor_probs_kernel(CsFactorNet n, const
 
 struct HistPtrs { const void* p[CS_MAX_ORDER]; };
 
+// CFG form (eu != null): hist[0] is the TEXT branch and the newest history entry is the combined eps u + g (c - u), rounded to
+// the model dtype exactly as lms_step_kernel rounds it; it is formed on the fly and the blocks of feature 1 also write it to
+// eps_out (every launch has them, whatever m is), so the update kernel that follows takes it as an already combined eps.
 template <typename T>
-__global__ __launch_bounds__(256) void cosine_kernel(HistPtrs h, int m, int order, int64_t elems, float* out) {
+__global__ __launch_bounds__(256) void cosine_kernel(HistPtrs h, int m, int order, int64_t elems, float* out, const void* eu, float g, void* eps_out) {
     // grid (order-1, B): cos(hist[i], hist[0]), i = blockIdx.x + 1
     const int i = blockIdx.x + 1, b = blockIdx.y;
     __shared__ float red[3][4];
     float dot = 0.f, na = 0.f, nb = 0.f;
-    if (i < m) {
+    const bool writer = eps_out != nullptr && i == 1;
+    if (i < m || writer) {
         constexpr int V = Io<T>::VEC;
         const int64_t base = (int64_t)b * elems, nvec = elems / V;
         for (int64_t v = threadIdx.x; v < nvec; v += blockDim.x) {
             float a[V], c[V];
-            Io<T>::load(h.p[i], base + v * V, a);
             Io<T>::load(h.p[0], base + v * V, c);
+            if (eu) {
+                float u[V];
+                Io<T>::load(eu, base + v * V, u);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { dot += a[j] * c[j]; na += a[j] * a[j]; nb += c[j] * c[j]; }
+                for (int j = 0; j < V; ++j) c[j] = Io<T>::round(u[j] + g * (c[j] - u[j]));
+                if (writer) Io<T>::store(eps_out, base + v * V, c);
+            }
+            if (i < m) {
+                Io<T>::load(h.p[i], base + v * V, a);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { dot += a[j] * c[j]; na += a[j] * a[j]; nb += c[j] * c[j]; }
+            }
         }
         for (int64_t t = nvec * V + threadIdx.x; t < elems; t += blockDim.x) {
-            float a = Io<T>::load1(h.p[i], base + t), c = Io<T>::load1(h.p[0], base + t);
-            dot += a * c; na += a * a; nb += c * c;
+            float c = Io<T>::load1(h.p[0], base + t);
+            if (eu) {
+                const float u = Io<T>::load1(eu, base + t);
+                c = Io<T>::round(u + g * (c - u));
+                if (writer) Io<T>::store1(eps_out, base + t, c);
+            }
+            if (i < m) { const float a = Io<T>::load1(h.p[i], base + t); dot += a * c; na += a * a; nb += c * c; }
         }
     }
     dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb);
@@ -453,21 +471,28 @@ int cs_factor_probs(const CsFactorNet* n, const float* x, int x_row_stride, cons
     return CS_OK;
 }
 
-int cs_cosine_features(const void* const* hist, int m, int order, int B, int64_t elems, int dtype, float* out, void* stream) {
+int cs_cosine_features_cfg(const void* const* hist, int m, int order, int B, int64_t elems, int dtype, const void* eps_uncond, float guidance,
+                           void* eps_out, float* out, void* stream) {
     if (B <= 0 || elems <= 0) return B < 0 || elems < 0 ? CS_E_SHAPE : CS_OK;
     if (!hist || !out) CS_FAIL(CS_E_ARG, "use_conv=True requires epsilon (factor_net_ppo.py:109-110)");
     if (order < 2 || order > CS_MAX_ORDER || m < 1 || m > order) CS_FAIL(CS_E_ARG, "bad order/m (%d,%d)", order, m);
+    if (eps_uncond && !eps_out) CS_FAIL(CS_E_ARG, "eps_out is required with eps_uncond (the combined eps is the history entry)");
+    if (!eps_uncond && eps_out) CS_FAIL(CS_E_ARG, "eps_out without eps_uncond");
     HistPtrs h;
     for (int k = 0; k < CS_MAX_ORDER; ++k) h.p[k] = (k < m) ? hist[k] : nullptr;
     for (int k = 0; k < m; ++k) if (!h.p[k]) CS_FAIL(CS_E_ARG, "hist[%d] is NULL", k);
     dim3 grid(order - 1, B), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CS_F32) hipLaunchKernelGGL(cosine_kernel<float>, grid, block, 0, s, h, m, order, elems, out);
-    else if (dtype == CS_F16) hipLaunchKernelGGL(cosine_kernel<f16>, grid, block, 0, s, h, m, order, elems, out);
-    else if (dtype == CS_BF16) hipLaunchKernelGGL(cosine_kernel<bf16_tag>, grid, block, 0, s, h, m, order, elems, out);
+    if (dtype == CS_F32) hipLaunchKernelGGL(cosine_kernel<float>, grid, block, 0, s, h, m, order, elems, out, eps_uncond, guidance, eps_out);
+    else if (dtype == CS_F16) hipLaunchKernelGGL(cosine_kernel<f16>, grid, block, 0, s, h, m, order, elems, out, eps_uncond, guidance, eps_out);
+    else if (dtype == CS_BF16) hipLaunchKernelGGL(cosine_kernel<bf16_tag>, grid, block, 0, s, h, m, order, elems, out, eps_uncond, guidance, eps_out);
     else CS_FAIL(CS_E_DTYPE, "bad dtype %d", dtype);
     CS_CHECK_LAUNCH();
     return CS_OK;
+}
+
+int cs_cosine_features(const void* const* hist, int m, int order, int B, int64_t elems, int dtype, float* out, void* stream) {
+    return cs_cosine_features_cfg(hist, m, order, B, elems, dtype, nullptr, 0.f, nullptr, out, stream);
 }
 
 static int launch_sample(const float* probs, const float* uni, const int64_t* idx_in, const float* av, int B, int A, int K,

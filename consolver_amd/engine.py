@@ -116,14 +116,16 @@ class SDSamplingEngine:
         if not use_graph:
             self.scheduler.set_timesteps(n, device=dev)
             self._t_dev = self.scheduler.timesteps.to(torch.float32)
-            return self._loop(ctx, bufs, n, B, do_cfg)
+            out = self._loop(ctx, bufs, n, B, do_cfg)
+            self.scheduler.verify_timesteps()     # (no device read unless a step resolved its timestep through the host counter)
+            return out
 
         # ---- whole-generation hipGraph: capture once per (B, n, cfg), replay afterwards ------------------
         key = (B, n, do_cfg, self.guidance_scale)
         if self._graph is None or self._graph_key != key:
             net = self.scheduler.factor_net
             if getattr(net, "sampler", None) == "multinomial" and net.forced_action_idx is None:
-                net.sampler = "inverse_cdf"          # graph-capturable RNG consumer
+                raise RuntimeError("use_graph=True needs a graph-capturable sampler: factor_net.sampler = 'inverse_cdf' (the default)")
             self._ctx_static = torch.empty_like(ctx)
             self._ctx_static.copy_(ctx)
             self.scheduler.set_timesteps(n, device=dev)

@@ -81,9 +81,11 @@ class FactorNetPPO(nn.Module):
         self.register_buffer("action_values", torch.from_numpy(self._grid()))
         # replay hook: when set ([B, A] int64), sample_action gathers these indices instead of drawing
         self.forced_action_idx = None
-        # "multinomial" = torch.multinomial on the default generator (the reference's only RNG consumer,
-        # factor_net_ppo.py:161); "inverse_cdf" = torch.rand + HIP inverse-CDF kernel (graph capturable)
-        self.sampler = "multinomial"
+        # "inverse_cdf" (default) = one torch.rand + the HIP inverse-CDF kernel (cs_sample_actions): 2 launches per step, graph
+        # capturable, eager == graph; "multinomial" = torch.multinomial on the default generator, the reference's RNG consumer
+        # (factor_net_ppo.py:161; ~15 small launches + a device assert per step).  Neither reproduces the reference's CUDA random
+        # stream on ROCm -- identical-seed parity is defined on replayed indices (forced_action_idx), SURVEY 7.3.
+        self.sampler = "inverse_cdf"
         self._w32 = None
         self._w32_key = None
 
@@ -117,8 +119,11 @@ class FactorNetPPO(nn.Module):
                              self.action_dims, self.num_actions, self.input_scale, self.inv_temperature)
 
     # -- kernels ---------------------------------------------------------------
-    def cosine_features(self, hist, m=None):
-        """hist: list of [B, ...] tensors newest first (len m) -> [B, order-1] fp32."""
+    def cosine_features(self, hist, m=None, cfg=None):
+        """hist: list of [B, ...] tensors newest first (len m) -> [B, order-1] fp32.
+
+        ``cfg=(eps_uncond, guidance, eps_out)``: ``hist[0]`` is the TEXT branch of a CFG dual batch; the newest entry
+        ``u + g (c - u)`` is formed inside the kernel (rounded as the update kernel rounds it) and written to ``eps_out``."""
         m = len(hist) if m is None else m
         e0 = L.require_cuda(hist[0], "epsilon")
         B = e0.shape[0]
@@ -126,12 +131,21 @@ class FactorNetPPO(nn.Module):
         out = torch.empty(B, self.order_dim - 1, dtype=torch.float32, device=e0.device)
         hs = [h.contiguous() for h in hist[:m]]
         arr = (C.c_void_p * L.CS_MAX_ORDER)(*[h.data_ptr() for h in hs])
-        L.check(L.lib().cs_cosine_features(arr, m, self.order_dim, B, elems, L.dtype_code(e0.dtype),
-                                           L.ptr(out), L.stream_ptr(e0.device)))
+        if cfg is None:
+            L.check(L.lib().cs_cosine_features(arr, m, self.order_dim, B, elems, L.dtype_code(e0.dtype),
+                                               L.ptr(out), L.stream_ptr(e0.device)))
+        else:
+            eu, g, eps_out = cfg
+            L.require_cuda(eu, "eps_uncond"), L.require_cuda(eps_out, "eps_out")
+            if not (eu.is_contiguous() and eps_out.is_contiguous()) or eu.dtype != e0.dtype or eps_out.dtype != e0.dtype:
+                raise ValueError("eps_uncond / eps_out must be contiguous tensors of the model-output dtype")
+            L.check(L.lib().cs_cosine_features_cfg(arr, m, self.order_dim, B, elems, L.dtype_code(e0.dtype), L.ptr(eu), float(g),
+                                                   L.ptr(eps_out), L.ptr(out), L.stream_ptr(e0.device)))
         return out
 
-    def probs_from(self, x, hist=None, m=None, batch=None):
-        """x: [B, 2] or [1, 2] (broadcast) conditioning; hist: eps history newest first (use_conv)."""
+    def probs_from(self, x, hist=None, m=None, batch=None, cfg=None):
+        """x: [B, 2] or [1, 2] (broadcast) conditioning; hist: eps history newest first (use_conv);
+        cfg: see ``cosine_features`` (use_conv under classifier-free guidance)."""
         x = L.require_cuda(x, "conds['x']").to(torch.float32).contiguous()
         B = batch if batch is not None else x.shape[0]
         stride = 0 if (x.shape[0] == 1 and B != 1) else x.shape[1]
@@ -139,7 +153,7 @@ class FactorNetPPO(nn.Module):
         if self.use_conv:
             if hist is None:
                 raise ValueError("use_conv=True requires the epsilon history")
-            cosf = self.cosine_features(hist, m)
+            cosf = self.cosine_features(hist, m, cfg)
         probs = torch.empty(B, self.action_dims, self.num_actions, dtype=torch.float32, device=x.device)
         net = self._net_struct()
         L.check(L.lib().cs_factor_probs(C.byref(net), L.ptr(x), stride, L.ptr(cosf), B, L.ptr(probs),

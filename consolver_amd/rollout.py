@@ -47,8 +47,6 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
     scheduler.set_timesteps(num_inference_steps, device=device)
     record_prev = scheduler.record_conds
     scheduler.record_conds = True
-    net = scheduler.factor_net.module if hasattr(scheduler.factor_net, "module") else scheduler.factor_net
-    fused_cfg = do_cfg and not net.use_conv
     native = getattr(unet, "is_consolver_hip", False)
     rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
     try:
@@ -72,10 +70,8 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
                 noise_pred = unet(lat_in, t, encoder_hidden_states=prompt_embeds, return_dict=False)[0]
             if do_cfg:
                 u, c = noise_pred[:batch_size], noise_pred[batch_size:]
-                if fused_cfg:
-                    out = scheduler.step(c, t, latents, return_dict=False, eps_uncond=u, guidance_scale=cfg)
-                else:
-                    out = scheduler.step(_cfg_combine(u, c, cfg), t, latents, return_dict=False)
+                # CFG combine fused into the update kernel (use_conv: into the cosine-feature kernel, cs_cosine_features_cfg)
+                out = scheduler.step(c, t, latents, return_dict=False, eps_uncond=u, guidance_scale=cfg)
             else:
                 out = scheduler.step(noise_pred, t, latents, return_dict=False)
             latents, actions, probs, conds, masks = out
@@ -87,22 +83,9 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
                 rec["masks"].append(masks.unsqueeze(1))
     finally:
         scheduler.record_conds = record_prev
+    # a step driven with a CUDA timestep that was not the grid entry the scheduler assumed must not reach the reward / update
+    # silently: one device->host read per rollout (the records below are about to be consumed on the host side anyway)
+    scheduler.verify_timesteps()
     cat = {k: torch.cat(v, dim=1) for k, v in rec.items()}
     return latents, {"x": cat["x"], "epsilon": cat["epsilon"]}, cat["probs"], cat["actions"], cat["masks"], prompt_embeds_txt
 
-
-def _cfg_combine(u, c, g):
-    """stand-alone CFG combine through the step kernel's CFG stage is not exposed separately;
-    for the use_conv configuration the combined eps must exist before the policy runs, so it is
-    produced by the Euler kernel with dt = 0 ... x' = x, eps_out = u + g (c - u)."""
-    import ctypes as C
-    out = torch.empty_like(c)
-    a = L.CsStepArgs()
-    a.x, a.eps_text, a.eps_uncond, a.guidance = c.data_ptr(), c.data_ptr(), u.data_ptr(), float(g)
-    a.m, a.order_dim, a.scaler_dim = 1, 2, 0
-    a.B, a.elems = c.shape[0], c.numel() // max(c.shape[0], 1)
-    a.io_dtype = a.out_dtype = L.dtype_code(c.dtype)
-    scratch = torch.empty_like(c)
-    a.x_out, a.eps_out, a.dt = scratch.data_ptr(), out.data_ptr(), 0.0
-    L.check(L.lib().cs_lms_euler_step(C.byref(a), L.stream_ptr(c.device)))
-    return out

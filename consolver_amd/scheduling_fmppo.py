@@ -11,7 +11,8 @@ Per step: policy MLP+softmax(logits/0.01) -> draw/gather -> ONE fused kernel
 ``x' = x_fp32 + (sigma_{i+1} - sigma_i) * sum_k c_k v_{t-k}`` rounded once to the model dtype.
 """
 import ctypes as C
-import inspect
+import os
+import warnings
 
 import numpy as np
 import torch
@@ -19,24 +20,27 @@ import torch
 from . import _lib as L
 from . import tables
 from .factor_net import FluxFactorNetPPO
-from .scheduling_ppo import HistoryMixin, SolverOutput, capture_config
+from ._scheduler_base import ConfigMixin, HAVE_DIFFUSERS, SchedulerMixin, register_to_config
+from .scheduling_ppo import HistoryMixin, SolverOutput
+
+# FLUX.1-Kontext-dev's published scheduler/scheduler_config.json: what from_pretrained falls back to offline
+KONTEXT_SCHEDULER_CONFIG = dict(shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                                base_image_seq_len=256, max_image_seq_len=4096)
 
 
-class FMPPOScheduler(HistoryMixin):
+class FMPPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
+    """``class FMPPOScheduler(SchedulerMixin, ConfigMixin)`` of edit_ppo/scheduler_fmppo.py:56 (mixins: see
+    ``_scheduler_base``)."""
     _compatibles = []
     order = 1
 
+    @register_to_config
     def __init__(self, num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=False, base_shift=0.5,
                  max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096, invert_sigmas=False,
                  shift_terminal=None, use_karras_sigmas=False, use_exponential_sigmas=False,
                  use_beta_sigmas=False, time_shift_type="exponential", stochastic_sampling=False,
                  order_dim=4, scaler_dim=2, mu_dim=1, use_conv=False, ppo_type="discrete",
                  factor_net_kwargs=None):
-        capture_config(self, FMPPOScheduler.__init__,
-                       (num_train_timesteps, shift, use_dynamic_shifting, base_shift, max_shift, base_image_seq_len,
-                        max_image_seq_len, invert_sigmas, shift_terminal, use_karras_sigmas, use_exponential_sigmas,
-                        use_beta_sigmas, time_shift_type, stochastic_sampling, order_dim, scaler_dim, mu_dim,
-                        use_conv, ppo_type, factor_net_kwargs), {})
         if sum([use_beta_sigmas, use_exponential_sigmas, use_karras_sigmas]) > 1:
             raise ValueError("Only one of `use_beta_sigmas`, `use_exponential_sigmas`, `use_karras_sigmas` can be used.")
         if time_shift_type not in {"exponential", "linear"}:
@@ -68,21 +72,23 @@ class FMPPOScheduler(HistoryMixin):
         self._cond_dev = None
 
     @classmethod
-    def from_config(cls, config, **kw):
-        c = dict(config)
-        c.update(kw)
-        return cls(**{k: v for k, v in c.items() if k in inspect.signature(cls.__init__).parameters})
-
-    @classmethod
-    def from_pretrained(cls, pretrained=None, subfolder=None, **kw):
-        """Hub configs are not reachable offline; FLUX.1-Kontext's published scheduler config
-         is the default and keyword overrides apply on top."""
-        base = dict(shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
-                    base_image_seq_len=256, max_image_seq_len=4096)
-        if isinstance(pretrained, dict):
-            base.update(pretrained)
-        base.update(kw)
-        return cls.from_config(base)
+    def from_pretrained(cls, pretrained_model_name_or_path=None, subfolder=None, return_unused_kwargs=False, **kw):
+        """``FMPPOScheduler.from_pretrained(repo, subfolder="scheduler", order_dim=..., ...)`` (edit_ppo/generate_ours.py:127-134).
+        A local directory holding ``scheduler_config.json`` (or, with diffusers installed, anything its loader resolves) is
+        loaded through the mixin; a hub id that cannot be resolved (no network) falls back to FLUX.1-Kontext's published
+        scheduler config with the keyword overrides on top."""
+        src = pretrained_model_name_or_path
+        if isinstance(src, dict):
+            return cls.from_config({**KONTEXT_SCHEDULER_CONFIG, **src}, return_unused_kwargs=return_unused_kwargs, **kw)
+        local = src is not None and os.path.exists(os.path.join(str(src), subfolder or "", cls.config_name))
+        if local or (HAVE_DIFFUSERS and src is not None):
+            try:
+                return super().from_pretrained(src, subfolder=subfolder, return_unused_kwargs=return_unused_kwargs, **kw)
+            except (EnvironmentError, OSError, ValueError) as e:
+                if local:
+                    raise
+                warnings.warn(f"{src!r} could not be resolved ({type(e).__name__}); using the published FLUX.1-Kontext scheduler config")
+        return cls.from_config(dict(KONTEXT_SCHEDULER_CONFIG), return_unused_kwargs=return_unused_kwargs, **kw)
 
     # ------------------------------------------------------------------ properties
     @property

@@ -14,39 +14,15 @@ look-ups -- no device->host synchronisation (the reference syncs three times
 per step: scheduler_ppo.py:207,243,288).
 """
 import ctypes as C
-import inspect
 
 import numpy as np
 import torch
 
 from . import _lib as L
 from . import tables
+from ._scheduler_base import (ConfigMixin, KARRAS_COMPATIBLES, SchedulerMixin, SolverConfig,  # noqa: F401
+                              register_to_config)
 from .factor_net import FactorNetPPO
-
-_KARRAS_COMPATIBLES = [
-    "DDIMScheduler", "DDPMScheduler", "PNDMScheduler", "LMSDiscreteScheduler", "EulerDiscreteScheduler",
-    "HeunDiscreteScheduler", "EulerAncestralDiscreteScheduler", "DPMSolverMultistepScheduler",
-    "DPMSolverSinglestepScheduler", "KDPM2DiscreteScheduler", "KDPM2AncestralDiscreteScheduler",
-    "DEISMultistepScheduler", "UniPCMultistepScheduler", "DPMSolverSDEScheduler", "EDMEulerScheduler",
-]
-
-
-class SolverConfig(dict):
-    """attribute *and* ``.get`` access like diffusers' FrozenDict
-    (edit_ppo/pipeline.py:1013-1016 uses ``scheduler.config.get``)."""
-
-    def __getattr__(self, k):
-        try:
-            return self[k]
-        except KeyError as e:
-            raise AttributeError(k) from e
-
-
-def capture_config(self, init, args, kwargs):
-    sig = inspect.signature(init)
-    bound = sig.bind(self, *args, **kwargs)
-    bound.apply_defaults()
-    self.config = SolverConfig({k: v for k, v in bound.arguments.items() if k != "self"})
 
 
 class SolverOutput(dict):
@@ -66,12 +42,15 @@ class HistoryMixin:
     record_conds = False     # materialise conds['epsilon'] (needed only by the PPO rollout)
     verbose = False          # print coefficients like the reference (forces a host sync)
 
-    def _policy(self, cond_row_f32, B, device):
-        """-> probs3 [B,A,K], actions [B,A], action_probs [B,A], idx"""
+    def _policy(self, cond_row_f32, B, device, cfg=None, newest=None):
+        """-> probs3 [B,A,K], actions [B,A], action_probs [B,A], idx.  ``cfg`` / ``newest``: use_conv under fused CFG -- the newest
+        history slot (``self.ets[-1]``, the buffer the combined eps is written to) is read through ``newest`` (the text branch)."""
         net = self.factor_net.module if hasattr(self.factor_net, "module") else self.factor_net
         hist = self.ets[::-1]
+        if newest is not None:
+            hist = [newest] + hist[1:]
         x = cond_row_f32
-        probs3 = net.probs_from(x, hist if net.use_conv else None, len(hist), batch=B)
+        probs3 = net.probs_from(x, hist if net.use_conv else None, len(hist), batch=B, cfg=cfg)
         actions, aprobs, idx = net.draw(probs3)
         return probs3, actions, aprobs, idx
 
@@ -105,17 +84,18 @@ class HistoryMixin:
         a.eps_out = eps_out.data_ptr() if eps_out is not None else None
 
 
-class PPOScheduler(HistoryMixin):
-    _compatibles = list(_KARRAS_COMPATIBLES)
+class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
+    """``class PPOScheduler(SchedulerMixin, ConfigMixin)`` of scheduler_ppo.py:48: diffusers' mixins when diffusers is
+    importable, the stand-alone ones of ``_scheduler_base`` otherwise -- either way ``config`` (backed by
+    ``_internal_dict``, which ``StableDiffusionPipeline.__init__`` rewrites when ``steps_offset != 1``),
+    ``save_config`` / ``from_config`` / ``save_pretrained`` / ``from_pretrained`` / ``compatibles``."""
+    _compatibles = list(KARRAS_COMPATIBLES)
     order = 1
 
+    @register_to_config
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  trained_betas=None, prediction_type="epsilon", timestep_spacing="leading", steps_offset=0,
                  order_dim=4, scaler_dim=2, use_conv=False, ppo_type="discrete", factor_net_kwargs=None):
-        capture_config(self, PPOScheduler.__init__,
-                       (num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, prediction_type,
-                        timestep_spacing, steps_offset, order_dim, scaler_dim, use_conv, ppo_type,
-                        factor_net_kwargs), {})
         if not (1 < order_dim <= L.CS_MAX_ORDER):
             # order_dim=1 raises IndexError inside the reference (scheduler_ppo.py:166 on an empty list)
             raise ValueError(f"order_dim must be in [2, {L.CS_MAX_ORDER}]")
@@ -143,12 +123,6 @@ class PPOScheduler(HistoryMixin):
         kw.setdefault("num_actions", 161)
         self.factor_net = FactorNetPPO(**kw)
         self._cond_table = None
-
-    @classmethod
-    def from_config(cls, config, **kw):
-        c = dict(config)
-        c.update(kw)
-        return cls(**{k: v for k, v in c.items() if k in inspect.signature(cls.__init__).parameters})
 
     # ------------------------------------------------------------------ protocol
     def set_timesteps(self, num_inference_steps, device=None):
@@ -186,9 +160,11 @@ class PPOScheduler(HistoryMixin):
         ``for t in scheduler.timesteps`` yields) is identified by its address.  Any other CUDA tensor
         (``t.clone()``, ``t + 0``, a caller's own grid) costs ONE ``.item()`` for the first such step after
         ``set_timesteps`` -- that anchors a host-side step counter on the grid -- and later steps take the
-        next grid entry from the counter, verified on the device without a sync (``verify_timesteps()`` /
-        the next ``set_timesteps`` raise if a step was driven with a different value).  The reference
-        itself syncs on every step (CPU table indexed by the CUDA timestep, scheduler_ppo.py:309-312)."""
+        next grid entry from the counter, verified on the device without a sync: the accumulated mismatch flag is
+        read ONCE when the trajectory ends (the step that consumes the last grid entry, see ``step``), by
+        ``verify_timesteps()`` (the rollout and the engine call it), and by the next ``set_timesteps`` -- a step
+        driven with a different value raises there, before its results are consumed.  The reference itself syncs
+        on every step (CPU table indexed by the CUDA timestep, scheduler_ppo.py:309-312)."""
         grid = self._timesteps
         if not isinstance(timestep, torch.Tensor):
             v = int(timestep)
@@ -278,9 +254,12 @@ class PPOScheduler(HistoryMixin):
         net = self.factor_net.module if hasattr(self.factor_net, "module") else self.factor_net
         cond_row = self._cond_row(t, prev_t, model_output.dtype, dev)
         if net.use_conv and eps_uncond is not None:
-            raise NotImplementedError("use_conv=True needs the combined eps before the policy runs; "
-                                      "combine CFG before step() in that configuration")
-        probs3, actions, aprobs, _ = self._policy(cond_row, B, dev)
+            # the policy's cosine features need the combined eps (scheduler_ppo.py:207-240 after denoise_ppo.py:96-100): the
+            # feature kernel forms u + g (c - u) on the fly, leaves it in eps_out, and the update kernel takes it as combined
+            probs3, actions, aprobs, _ = self._policy(cond_row, B, dev, cfg=(eps_uncond, guidance_scale, eps_out), newest=model_output)
+            model_output, eps_uncond, eps_out = eps_out, None, None
+        else:
+            probs3, actions, aprobs, _ = self._policy(cond_row, B, dev)
         masks = self._masks(B, net.action_dims, m, dev)
 
         prev = out if out is not None else torch.empty_like(sample)
@@ -289,6 +268,9 @@ class PPOScheduler(HistoryMixin):
         a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = self._ddim_scalars(t, prev_t)
         a.v_prediction = int(self.config.prediction_type == "v_prediction")
         L.check(L.lib().cs_lms_ddim_step(C.byref(a), L.stream_ptr(dev)))
+        if (self._t_mismatch is not None and self._step_counter is not None and self._step_counter >= len(self._timesteps)
+                and not torch.cuda.is_current_stream_capturing()):
+            self.verify_timesteps()       # end of the trajectory: one device->host read, before the caller consumes the result
 
         conds = {"x": cond_row.to(model_output.dtype).repeat(B, 1),
                  "epsilon": self._stack(B, a.elems, current) if (self.record_conds or net.use_conv) else None}

@@ -79,6 +79,16 @@ int cs_factor_probs(const CsFactorNet* net, const float* x, int x_row_stride, co
 int cs_cosine_features(const void* const* hist_host, int m, int order, int B, int64_t elems,
                        int dtype, float* out, void* stream);
 
+/* The same under classifier-free guidance with the combine fused (denoise_ppo.py:96-100 in
+ * front of scheduler_ppo.py:207-240): hist[0] is the TEXT branch, eps_uncond the other one,
+ * and the newest history entry is e = eps_uncond + guidance * (hist[0] - eps_uncond) rounded
+ * to `dtype` exactly as cs_lms_ddim_step rounds it.  e is formed on the fly for the features
+ * and written to eps_out [B, elems] (required), which the caller then passes to the update
+ * kernel as an already combined eps.  eps_uncond == NULL: identical to cs_cosine_features. */
+int cs_cosine_features_cfg(const void* const* hist_host, int m, int order, int B, int64_t elems,
+                           int dtype, const void* eps_uncond, float guidance, void* eps_out,
+                           float* out, void* stream);
+
 /* inverse-CDF categorical sampling from probs[B,A,K] with caller supplied
  * uniforms[B,A] in [0,1).  Writes idx[B,A] (int64), actions[B,A] = action_values[a, idx],
  * action_probs[B,A] = probs[b,a,idx].  Any output pointer may be NULL. */

@@ -224,7 +224,8 @@ def gen_sd():
         e = eps_model_np(latent_in.numpy(), key, noise_bank[key]) + 0.1 * ctx
         return (torch.from_numpy(e.astype(np.float32)),)
 
-    for ri, (o, sc, uc, n, cfg) in enumerate([(4, 0, False, 6, 3.0), (3, 1, True, 5, 1.0)]):
+    # (the third case: use_conv under classifier-free guidance -- the cosine features see the COMBINED eps, scheduler_ppo.py:207-240 behind denoise_ppo.py:96-100)
+    for ri, (o, sc, uc, n, cfg) in enumerate([(4, 0, False, 6, 3.0), (3, 1, True, 5, 1.0), (4, 0, True, 6, 3.0)]):
         noise_bank.clear()
         with ref_stubs.quiet():
             s = PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",

@@ -23,12 +23,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def make(cfg_over, seed=11):
+def make(cfg_over, seed=11, use_conv=False):
     unet = HipUNet2DConditionModel(cfg_over, device=DEV)
     sd = synthetic_unet_state_dict(unet.manifest(), seed=seed)
     unet.load_state_dict(sd)
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                                     timestep_spacing="trailing", order_dim=4, scaler_dim=0,
+                                     timestep_spacing="trailing", order_dim=4, scaler_dim=0, use_conv=use_conv,
                                      factor_net_kwargs=dict(hidden_dim=64, num_actions=11))
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
@@ -39,11 +39,11 @@ def make(cfg_over, seed=11):
     return unet, sd, sch, w
 
 
-def oracle_run(sd, cfg, w, noise, pe, ne, idx, n, guidance):
+def oracle_run(sd, cfg, w, noise, pe, ne, idx, n, guidance, use_conv=False, probs_out=None):
     torch.set_num_threads(16)
     orc_u = UNetOracle(sd, cfg)
     orc_s = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                                  timestep_spacing="trailing", order_dim=4, scaler_dim=0, num_actions=11, weights=w)
+                                  timestep_spacing="trailing", order_dim=4, scaler_dim=0, num_actions=11, weights=w, use_conv=use_conv)
     orc_s.set_timesteps(n)
     x = noise.float().numpy()
     ctx = torch.cat([ne, pe]).float()
@@ -51,7 +51,10 @@ def oracle_run(sd, cfg, w, noise, pe, ne, idx, n, guidance):
     for i, t in enumerate(orc_s.timesteps):
         e = orc_u(torch.from_numpy(np.concatenate([x, x])), int(t), ctx).numpy()
         e = so.round_f16(so.cfg_combine(so.round_f16(e[:B]), so.round_f16(e[B:]), guidance))
-        x = so.round_f16(orc_s.step(e, int(t), x, idx[i], cond_dtype="f16")["prev_sample"])
+        out = orc_s.step(e, int(t), x, idx[i], cond_dtype="f16")
+        if probs_out is not None:
+            probs_out.append(out["probs"])
+        x = so.round_f16(out["prev_sample"])
     return x
 
 
@@ -79,6 +82,38 @@ def test_engine_trajectory_reduced_unet(use_graph):
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 4-step reduced-unet rel l2", err, "graph" if use_graph else "eager")
     assert np.isfinite(got).all() and err < 2.6e-3, err          # measured 1.93e-3 (eager) / 1.45e-3 (graph: one index set), + ~35 %
+
+
+def test_engine_use_conv_under_cfg():
+    """``--use_conv`` (gen_ppo.py) in the fused engine: the policy's cosine features (factor_net_ppo.py:108-130) are taken over the
+    COMBINED eps (denoise_ppo.py:96-100 in front of scheduler_ppo.py:207-240) although the engine hands the scheduler the two CFG
+    branches -- cs_cosine_features_cfg forms the combine on the fly.  Selected-action probabilities depend on those features, so
+    they are compared too (the reduced UNet's eps error moves the cosines by ~1e-3)."""
+    unet, sd, sch, w = make(dict(layers_per_block=1, sample_size=16), use_conv=True)
+    assert sch.factor_net.mlp[0].in_features == 2 + 3
+    B, n, g = 2, 5, 3.0
+    idx = np.random.default_rng(8).integers(0, 11, size=(n, B, 3))
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
+    noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(44)).half()
+    eng = SDSamplingEngine(unet, sch, guidance_scale=g)
+    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+    got_probs = []
+    orig = sch.step
+    def step(*a, **k):
+        out = orig(*a, **k)
+        got_probs.append(out[2].float().cpu().numpy())
+        return out
+    sch.step = step
+    got = eng.generate(pe.to(DEV), ne.to(DEV), latents=noise.to(DEV), num_inference_steps=n).float().cpu().numpy()
+    sch.step = orig
+    want_probs = []
+    want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g, use_conv=True, probs_out=want_probs)
+    err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    perr = max(float(np.abs(a - b).max()) for a, b in zip(got_probs, want_probs))
+    print("engine use_conv + CFG 5-step rel l2", err, "max |dprob|", perr)
+    assert np.isfinite(got).all() and err < 2.6e-3, err
+    assert perr < 5e-3, perr
+    assert float(sch.factor_net.mlp[0].weight[:, 2:].abs().max()) > 0.1      # (the cosine inputs carry weight in this policy)
 
 
 @pytest.mark.timeout(1200)

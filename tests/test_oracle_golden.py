@@ -128,7 +128,7 @@ def test_sd_fp16_io_vs_fp32_oracle(golden):
 
 def test_sd_rollout_records(golden):
     g = golden["sd_rollout"]
-    for ri in range(2):
+    for ri in range(3):
         o, sc, uc, n = [int(v) for v in g[f"r{ri}_cfg"]]
         cfg = float(g[f"r{ri}_guidance"])
         sch = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",

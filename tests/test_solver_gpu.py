@@ -261,7 +261,7 @@ def test_sd_rollout_records_vs_golden(golden):
     from consolver_amd.rollout import denoise_diffusion
     g = golden["sd_rollout"]
     from oracle.make_golden import eps_model_np
-    for ri in range(2):
+    for ri in range(3):
         o, sc, uc, n = [int(v) for v in g[f"r{ri}_cfg"]]
         cfg = float(g[f"r{ri}_guidance"])
         s = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
