@@ -25,6 +25,7 @@
 #include <type_traits>
 
 extern int g_tune_halo;
+extern int g_tune_conv_lw;
 extern int g_tune_debug;
 extern int g_tune_biggemm;
 
@@ -515,6 +516,375 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Halo conv with DEDICATED LOADER WAVES (round 3).  What the 8-wave kernel above pays for staging is not bytes but ISSUE: one 1 KiB
+// LDS-DMA instruction costs the wave that issues it 25-40 cycles of MFMA issue whatever its form (global_load_lds with per-lane
+// 64-bit addresses, buffer_load ... lds with a scalar offset: tools/probe/dma_issue.hip, profiles/r03_probe_dma_issue.txt), and
+// next to nothing when ANOTHER wave of the SIMD issues it (80 MFMAs + 1 barrier per step: 1369 cycles with loader waves against
+// 1570-1670 with 5-8 pieces issued between the MFMAs; floor 1280).  So: 8 waves, waves 0-3 (one per SIMD) multiply and never
+// touch global memory, waves 4-7 (their SIMD partners) do nothing but stage.
+//   * tile 256 pixels (the 16 x 16 / multi-image patch of the kernel above) x BN channels, wave tile 64 pixels x BN channels,
+//     k step = one tap x 64 channels = 4 * BN/16 * 2 MFMAs per wave (80 at BN = 160);
+//   * LDS: two halo buffers (chunk c / c + 1) + THREE weight stages (the third removes the lgkmcnt(0) in front of the step barrier);
+//   * compute waves: the pipelined step of gemm_big_kernel -- weight fragments through a ring LA items ahead, the step's one
+//     barrier at item QB with every fragment of the stage in registers, the next step's first fragments read under the last MFMAs;
+//   * loader waves: after barrier K(g-1) (all reads of stage g - 1 are done) they issue stage g + 1's weights into that buffer
+//     and one slice of the next chunk's halo, wait for the weights with a COUNTED vmcnt (the halo slice may stay in flight for
+//     another step), and join barrier K(g).  All their per-piece addresses are computed once per tile.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) unsigned g_zero_region[(64 * 128 + 256) / 4];     // padding rows: the chunk offset (< 64 * 128 B) is added to every source
+
+// ---- hand-counted LDS reads for the one-wave-per-SIMD kernels: hipcc neither sees nor waits for these -----------------------------------
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+template <int OFF>
+__device__ __forceinline__ void lds_read(f16x8& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit unsigned offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(f16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+// in-place MFMA: with the builtin, hipcc gave every accumulator update of the fully unrolled 9-tap body a fresh register (dst != srcC) and spilled 880 bytes per lane
+__device__ __forceinline__ void mfma_inplace(f32x4& c, const f16x8& a, const f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+// conv3_lw_kernel: number of LDS reads issued AFTER the youngest read item q multiplies, counted up to and including item q's own reads (LDS returns in
+// order, so s_waitcnt lgkmcnt(that) is exactly "my operands have landed").  Reads in front of item p's MFMAs, in order: one weight fragment (for item p + LA),
+// then (p < MT) one k-half-1 activation fragment, then (p = QB, QB + 1) two next-step activation fragments.
+constexpr int lw_reads_of(int p, int MT, int QB) { return 1 + (p < MT ? 1 : 0) + ((p == QB || p == QB + 1) ? 2 : 0); }
+constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
+    // the weight fragment of item q was the FIRST read of item q - LA (mod NQ)
+    int n = 0;
+    for (int d = LA; d >= 0; --d) {                      // items q - LA .. q
+        const int pidx = ((q - d) % NQ + NQ) % NQ;
+        n += lw_reads_of(pidx, MT, QB);
+    }
+    int after_w = n - 1;                                  // everything after that first read
+    // items 0 and 1 also need all four next-step activation fragments, the last of which is the LAST read of item QB + 1 (previous step)
+    int after_a = after_w;
+    if (q < 2) {
+        int m = 0;
+        for (int pp = QB + 2; pp < NQ; ++pp) m += lw_reads_of(pp, MT, QB);
+        for (int pp = 0; pp <= q; ++pp) m += lw_reads_of(pp, MT, QB);
+        after_a = m;
+    }
+    return after_a < after_w ? after_a : after_w;
+}
+
+// TRACE: a separate instantiation with in-kernel cycle stamps (cs_set_tuning("debug", 16384), tools/conv_lw_trace.py).  It must be a compile-time
+// variant: s_memtime is a scalar-memory instruction and shares lgkmcnt with the LDS reads, so even a never-taken stamp makes hipcc wait lgkmcnt(0).
+// FAST (no fused upsample, 16 x 16 patches: HALO_W = 18, 324 halo rows, 41 pieces): every LDS address of the compute waves is a per-tile register plus an
+// IMMEDIATE, so a steady-state step issues no vector-ALU instruction at all.  A lone MFMA-issuing wave pays ~10 cycles of matrix-pipe time per VALU
+// instruction placed in its stream (tools/probe/mfma_stream.hip, profiles/r03_probe_mfma_stream.txt: 2 v_add per 4-MFMA item = +420 cycles per 80-MFMA
+// step) and the generic path's ~40 address instructions per step were 450 of its 1775 cycles.  What makes it possible:
+//   * the halo rows are swizzled by their COLUMN in the halo (hx & 7) instead of their row index: the 16 lanes of a fragment read rows of one halo line, so
+//     the swizzle term of lane fx under tap column dx is (fx + dx) & 7 -- three per-lane values for the whole tile, whatever the tap row or output row;
+//     (conflict-free like the row-index form: within a ds_read_b128 lane group the (row parity, 16-byte slot) pairs stay distinct because HALO_W is even);
+//   * taps and halo-buffer parity are compile-time (the chunk loop runs one of two 9-step bodies), the weight buffer of tap t is t % 3 (9 % 3 == 0), and
+//     (output row j + tap row dy) * 18 * 128 + parity * 41 KiB < 64 Ki fits the 16-bit offset field of ds_read.
+template <bool UP, int BN, bool TRACE = false, bool FAST = false>
+__global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
+    static_assert(!(FAST && UP), "the FAST addressing is for the plain 3x3 conv");
+    constexpr int NT = BN / 16, MT = 4;
+    constexpr int B_BYTES = BN * 128, NWB = 3;
+    constexpr int NBQ = BN / 8;                              // weight DMA pieces per stage (8 rows of 128 B each)
+    static_assert(NBQ % 4 == 0, "every loader wave issues the same number of weight pieces");
+    constexpr int WPL = NBQ / 4;                             // ... per loader wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int A_BYTES = FAST ? 41 * 1024 : p.NQ * 1024;          // halo buffer: NQ pieces of 8 rows (<= HALO_ROWS_MAX * 128)
+    char* const lA = smem;                    // [2][A_BYTES]
+    char* const lB = smem + 2 * A_BYTES;      // [NWB][B_BYTES]: stage g lives in buffer g % 3
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.e.nblk >> 3, r = p.e.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = id / p.e.tiles_n, tn = id - tm * p.e.tiles_n;
+    const int n_blk = tn * BN;
+    int b0, y0, x0;
+    if (p.PP == 1) { b0 = tm << (8 - p.trw_shift); y0 = 0; x0 = 0; }
+    else {
+        b0 = tm / p.PP;
+        const int pr = tm - b0 * p.PP, py = pr / p.PX, px = pr - py * p.PX;
+        y0 = py << (p.trw_shift - p.tw_shift); x0 = px << p.tw_shift;
+    }
+    const int c_per = p.NC / p.splits, c_begin = blockIdx.y * c_per, c_end = c_begin + c_per;
+    const int nsteps = c_per * 9;
+
+    if (w >= 4) {
+        // =============================== loader waves ===============================
+        const int l = w - 4;
+        const int pch = lane & 7, lr = lane >> 3;
+        const int iy_base = (UP ? (y0 >> 1) : y0) - 1, ix_base = (UP ? (x0 >> 1) : x0) - 1;    // input pixel of halo (0, 0)
+        // halo piece of slot k (0..15): q = (k & 7) * 4 + l + (k >> 3) * 32 -- slice k & 7, second round for halos of more than 32 pieces
+        const char* hsrc[16];
+        const float inv_img = 1.0f / (float)p.HALO_IMG, inv_w = 1.0f / (float)p.HALO_W;
+        const char* zero = reinterpret_cast<const char*>(g_zero_region) + pch * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = (k & 7) * 4 + l + (k >> 3) * 32;
+            const int hr = 8 * q + lr;
+            const int hi = (int)(((float)hr + 0.5f) * inv_img), rem = hr - hi * p.HALO_IMG;
+            const int hy = (int)(((float)rem + 0.5f) * inv_w), hx = rem - hy * p.HALO_W;
+            const int b = b0 + hi, y = iy_base + hy, x = ix_base + hx;
+            const bool ok = (q < p.NQ) & (hr < p.NHALO) & (b < p.B) & (y >= 0) & (y < p.H) & (x >= 0) & (x < p.W);
+            const long pix = ((long)b * p.H + y) * p.W + x;
+            // source chunk of LDS slot pch: swizzled by the halo row index (hr & 7 == lr: 8 q is a multiple of 8) or, FAST, by the halo column
+            hsrc[k] = ok ? reinterpret_cast<const char*>(p.x + pix * p.Cin + (pch ^ (FAST ? (hx & 7) : lr)) * 8) : zero;
+        }
+        const f16* wsrc[WPL];
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const int q = l + 4 * j, r = 8 * (q < NBQ ? q : 0) + lr;
+            wsrc[j] = p.w + (size_t)(n_blk + r) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+        }
+        auto issue_w = [&](int c, int t, int buf) {
+            const size_t koff = (size_t)t * p.Cin + c * BK;
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) glds16(wsrc[j] + koff, lB + buf * B_BYTES + (l + 4 * j) * 1024);
+        };
+        // slice s (0..7) of chunk c: this wave's pieces q = 4 s + l and 4 s + l + 32; returns how many it issued
+        auto issue_h = [&](int c, auto s_tag, int buf) -> int {
+            constexpr int S = decltype(s_tag)::value;
+            const int q0 = S * 4 + l, q1 = q0 + 32;
+            int n = 0;
+            if (q0 < p.NQ) { glds16(hsrc[S] + (size_t)c * 128, lA + buf * A_BYTES + q0 * 1024); ++n; }
+            if (q1 < p.NQ) { glds16(hsrc[S + 8] + (size_t)c * 128, lA + buf * A_BYTES + q1 * 1024); ++n; }
+            return n;
+        };
+        // stage 0: the whole halo of the first chunk + the first tap's weights
+        issue_h(c_begin, std::integral_constant<int, 0>{}, 0); issue_h(c_begin, std::integral_constant<int, 1>{}, 0);
+        issue_h(c_begin, std::integral_constant<int, 2>{}, 0); issue_h(c_begin, std::integral_constant<int, 3>{}, 0);
+        issue_h(c_begin, std::integral_constant<int, 4>{}, 0); issue_h(c_begin, std::integral_constant<int, 5>{}, 0);
+        issue_h(c_begin, std::integral_constant<int, 6>{}, 0); issue_h(c_begin, std::integral_constant<int, 7>{}, 0);
+        issue_w(c_begin, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                           // K(-1): stage 0 has landed
+        int g = 0, wb1 = 1;                                                     // wb1 = (g + 1) % 3
+        // (timing experiments, debug bit 16384: cycles wave 4 spends waiting for its DMA / at the step barriers -> trace slots 9, 10)
+        const bool trl = TRACE && l == 0 && lane == 0 && blockIdx.x < CS_TRACE_SLOTS && blockIdx.y == 0;
+        unsigned long long tl_wait = 0, tl_bar = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int abn = (c + 1 - c_begin) & 1;
+            const bool halo_next = c + 1 < c_end;
+            auto step = [&](auto t_tag) {
+                constexpr int T = decltype(t_tag)::value;
+                const bool last = T == 8 && !halo_next;                          // the very last step: nothing to stage, but the compute waves' step is branch-free and has its barrier
+                // Stage g + 1 goes into buffer (g + 1) % 3, last read as stage g - 2.  Those reads were ISSUED before K(g - 2) and every compute
+                // wave has since waited for younger ones (LDS returns in order), so they are complete behind K(g - 1): the third buffer is what
+                // lets the compute waves pass their barrier without an lgkmcnt(0) (an exposed LDS latency per step with one computing wave per SIMD).
+                if (!last) issue_w(T == 8 ? c + 1 : c, T == 8 ? 0 : T + 1, wb1);
+                int nh = 0;
+                if constexpr (T < 8) { if (halo_next) nh = issue_h(c + 1, std::integral_constant<int, T>{}, abn); }
+                // the weights are needed behind the next barrier; the halo slice just issued is not (vmcnt counts in issue order; step (c, 8) issues
+                // no halo, so the whole halo of chunk c + 1 has landed when that step's barrier opens)
+                unsigned long long s0 = 0, s1 = 0;
+                if (TRACE) s0 = __builtin_readcyclecounter();
+                if (nh == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (nh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if (TRACE) s1 = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_barrier();                                    // K(g)
+                if (TRACE) { const unsigned long long s2 = __builtin_readcyclecounter(); tl_wait += s1 - s0; tl_bar += s2 - s1; }
+                ++g; wb1 = wb1 == NWB - 1 ? 0 : wb1 + 1;
+            };
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+        }
+        if (trl) { g_trace[blockIdx.x * CS_TRACE_W + 9] = tl_wait; g_trace[blockIdx.x * CS_TRACE_W + 10] = tl_bar; }
+        __builtin_amdgcn_s_barrier();                                           // E: the stage buffers become the epilogue patches
+        return;
+    }
+
+    // =============================== compute waves ===============================
+    // One computing wave per SIMD: nothing but this wave's own lookahead hides an LDS latency (~200 cycles with four waves reading and the DMA writing), so the
+    // step is branch-free, every LDS read is an inline-asm ds_read_b128 and every wait a hand-counted lgkmcnt.  (hipcc's own waits on this loop were lgkmcnt(0) at
+    // the loop head -- the back edge merges two histories -- and a 4, 3, 2, 1, 0 ladder behind the conditional reads of the last items: two exposed latencies per
+    // step, 2050 cycles per step against 1280 of MFMA issue; profiles/r03_conv_lw_trace.txt.)
+    //   item q = (k half ks, weight tile i), 4 MFMAs.  Reads issued in front of item q's MFMAs, in this order:
+    //     weight fragment q + LA of this stage (q + LA < NQ) or q + LA - NQ of the next one  -> ring slot (q + LA) % RS, the slot item q - 1 has just used
+    //     q < MT:            the k-half-1 activation fragment q of this step
+    //     q = QB, QB + 1:    two activation fragments (k half 0) of the next step
+    //   The barrier sits in front of item QB = NQ - LA: every weight fragment of this stage has been issued by then and the reads behind it go to the next stage.
+    //   The prologue issues exactly what a step's items QB .. NQ - 1 issue, so the counts hold from the first step on; the last step's "next" reads fetch stale
+    //   bytes of existing buffers and are never used.
+    const int wm = w;
+    int fi[MT], fy[MT], fx[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int o = wm * 64 + j * 16 + (lane & 15);
+        const int img = o >> p.trw_shift, rem = o & ((1 << p.trw_shift) - 1);
+        fy[j] = rem >> p.tw_shift; fx[j] = rem & ((1 << p.tw_shift) - 1); fi[j] = img * p.HALO_IMG;
+        if (!UP) fi[j] += fy[j] * p.HALO_W + fx[j];
+    }
+    const int gq = lane >> 4;
+    const int swz = (lane >> 1) & 7;
+    const unsigned lA_base = lds_addr(lA), lB_base = lds_addr(lB);
+    const unsigned wfrag0 = (lane & 15) * 128 + (gq ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + gq) ^ swz) * 16;
+    // byte offset (inside a halo buffer) of the k-half-0 fragment of output tile j under tap (dy, dx); the other k half is ^ 64
+    auto a_off = [&](int j, int dy, int dx) {
+        int hr;
+        if (UP) hr = fi[j] + (((fy[j] + dy - 1) >> 1) + 1) * p.HALO_W + ((fx[j] + dx - 1) >> 1) + 1;
+        else hr = fi[j] + dy * p.HALO_W + dx;
+        return (unsigned)(hr * 128 + ((gq ^ (hr & 7)) * 16));
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NQ = 2 * NT, RS = NT / 2, LA = RS - 1, QB = NQ - LA;
+    static_assert(NT % 2 == 0 && NQ % RS == 0 && LA >= 2 && MT == 4 && QB + 1 < NQ && QB > NT + MT, "ring / fragment placement");
+    f16x8 fa[2][MT], fw[RS];
+    unsigned aoff[MT], anext[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) aoff[j] = a_off(j, 0, 0);
+
+    unsigned long long tc_t0 = 0, tc_r0 = 0;
+    if constexpr (FAST) {
+        // per-tile address registers: VA[dx][ks] = halo row of (output row 4 w, tap row 0) at column fx + dx, k half ks, in the CURRENT chunk's halo buffer
+        // (moved to the other buffer once per chunk: 7 v_add per 720 MFMAs); VN = VA[0][0] in the other buffer; WB[wb][ks] = weight tile 0 of buffer wb
+        constexpr int AB_F = 41 * 1024, ROWB = 18 * 128;
+        const int fxl = lane & 15;
+        const unsigned rowb = lA_base + (unsigned)((4 * wm) * 18 + fxl) * 128;
+        unsigned VA[3][2], VN, WB[NWB][2];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const unsigned sw = (unsigned)((gq ^ ((fxl + d) & 7)) << 4);
+            VA[d][0] = rowb + d * 128 + sw; VA[d][1] = rowb + d * 128 + (sw ^ 64u);
+        }
+        VN = VA[0][0] + AB_F;
+#pragma unroll
+        for (int b3 = 0; b3 < NWB; ++b3) { WB[b3][0] = lB_base + b3 * B_BYTES + wfrag0; WB[b3][1] = lB_base + b3 * B_BYTES + wfrag1; }
+        __builtin_amdgcn_s_barrier();                                           // K(-1): stage 0 has landed
+        // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (tap (0, 0), halo buffer 0, weight buffer 0)
+        lds_read<0>(fw[0], WB[0][0]); lds_read<0 * ROWB>(fa[0][0], VA[0][0]); lds_read<1 * ROWB>(fa[0][1], VA[0][0]);
+        lds_read<2048>(fw[1], WB[0][0]); lds_read<2 * ROWB>(fa[0][2], VA[0][0]); lds_read<3 * ROWB>(fa[0][3], VA[0][0]);
+        lds_read<2 * 2048>(fw[2], WB[0][0]); lds_read<3 * 2048>(fw[3], WB[0][0]);
+        static_assert(LA == 4, "prologue reads");
+        if (TRACE) { tc_t0 = __builtin_readcyclecounter(); tc_r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        int delta = AB_F;
+        for (int c = c_begin; c < c_end; ++c) {
+            static_for<9>([&](auto tc) {                                        // tap T of this chunk; the next step is tap T + 1 or tap 0 of the next chunk (other halo buffer)
+                constexpr int T = decltype(tc)::value;
+                constexpr int DY = T / 3, DX = T % 3, TN = T == 8 ? 0 : T + 1, DYN = TN / 3, DXN = TN % 3;
+                constexpr int WBC = T % 3, WBN = TN % 3;
+                static_for<NQ>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
+                    if constexpr (q == QB) __builtin_amdgcn_s_barrier();       // K(g): stage g + 1 has landed
+                    {
+                        constexpr int r = q + LA;
+                        if constexpr (r < NT) lds_read<r * 2048>(fw[r % RS], WB[WBC][0]);
+                        else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], WB[WBC][1]);
+                        else lds_read<(r - NQ) * 2048>(fw[r % RS], WB[WBN][0]);
+                    }
+                    if constexpr (q < MT) lds_read<(DY + q) * ROWB>(fa[1][q], VA[DX][1]);
+                    if constexpr (q == QB || q == QB + 1) {
+                        constexpr int j0 = (q - QB) * 2;
+                        if constexpr (T == 8) {
+                            lds_read<j0 * ROWB>(fa[0][j0], VN); lds_read<(j0 + 1) * ROWB>(fa[0][j0 + 1], VN);
+                        } else {
+                            lds_read<(DYN + j0) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<(DYN + j0 + 1) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) mfma_inplace(acc[i][j], fw[q % RS], fa[ks][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            // the next chunk lives in the other halo buffer
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { VA[d][0] += delta; VA[d][1] += delta; }
+            VN -= delta; delta = -delta;
+        }
+    } else {
+    __builtin_amdgcn_s_barrier();                                               // K(-1): stage 0 has landed
+    // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0
+    {
+        const unsigned w0 = lB_base + wfrag0, ha0 = lA_base;
+        lds_read<0>(fw[0], w0); lds_read<0>(fa[0][0], ha0 + aoff[0]); lds_read<0>(fa[0][1], ha0 + aoff[1]);
+        lds_read<2048>(fw[1], w0); lds_read<0>(fa[0][2], ha0 + aoff[2]); lds_read<0>(fa[0][3], ha0 + aoff[3]);
+#pragma unroll
+        for (int r = 2; r < LA; ++r) {
+            if (r == 2) lds_read<2 * 2048>(fw[2 % RS], w0);
+            if (r == 3) lds_read<3 * 2048>(fw[3 % RS], w0);
+        }
+        static_assert(LA <= 4, "prologue reads");
+    }
+
+    if (TRACE) { tc_t0 = __builtin_readcyclecounter(); tc_r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    int ab = 0, t = 0, dy = 0, dx = 0, wb = 0;                                   // wb = g % 3
+    for (int g = 0; g < nsteps; ++g) {
+        // next step's tap / halo buffer
+        int tn = t + 1, dxn = dx + 1, dyn = dy, abn = ab;
+        if (dxn == 3) { dxn = 0; ++dyn; }
+        if (tn == 9) { tn = 0; dxn = 0; dyn = 0; abn ^= 1; }
+        const int wbn = wb == NWB - 1 ? 0 : wb + 1;
+        const unsigned ha1 = lA_base + ab * A_BYTES, han = lA_base + abn * A_BYTES;
+        const unsigned wc0 = lB_base + wb * B_BYTES + wfrag0, wc1 = lB_base + wb * B_BYTES + wfrag1, wn0 = lB_base + wbn * B_BYTES + wfrag0;
+        static_for<NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
+            if constexpr (q == QB) __builtin_amdgcn_s_barrier();               // K(g): stage g + 1 has landed (no lgkmcnt(0): the loader's comment on the third buffer)
+            // ---- reads -----------------------------------------------------------------------------------------------
+            {
+                constexpr int r = q + LA;
+                if constexpr (r < NT) lds_read<r * 2048>(fw[r % RS], wc0);
+                else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], wc1);
+                else lds_read<(r - NQ) * 2048>(fw[r % RS], wn0);
+            }
+            if constexpr (q < MT) lds_read<0>(fa[1][q], ha1 + (aoff[q] ^ 64u));
+            if constexpr (q == QB || q == QB + 1) {
+                lds_read<0>(fa[0][(q - QB) * 2], han + anext[(q - QB) * 2]);
+                lds_read<0>(fa[0][(q - QB) * 2 + 1], han + anext[(q - QB) * 2 + 1]);
+            }
+            // ---- wait for what this item multiplies --------------------------------------------------------------------
+            lds_wait<lw_wait_count(q, NQ, LA, MT, QB)>(fw[q % RS]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                mfma_inplace(acc[i][j], fw[q % RS], fa[ks][j]);
+            if constexpr (q < MT) anext[q] = a_off(q, dyn, dxn);                 // (address arithmetic of the next step, one tile per item)
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int j = 0; j < MT; ++j) aoff[j] = anext[j];
+        t = tn; dx = dxn; dy = dyn; ab = abn; wb = wbn;
+    }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");          // (the last step's look-ahead reads; the last MFMAs' results: hipcc pads nothing behind an asm MFMA)
+    if (TRACE && w == 0 && lane == 0 && blockIdx.x < CS_TRACE_SLOTS && blockIdx.y == 0) {
+        g_trace[blockIdx.x * CS_TRACE_W + 6] = __builtin_readcyclecounter() - tc_t0;
+        g_trace[blockIdx.x * CS_TRACE_W + 8] = __builtin_amdgcn_s_memrealtime() - tc_r0;
+        g_trace[blockIdx.x * CS_TRACE_W + 5] = (unsigned long long)nsteps;
+    }
+    __builtin_amdgcn_s_barrier();                                               // E
+    const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
+    if (p.splits == 1) {
+        igemm_epilogue<false, NT, MT, NT, PatchRows, 2>(p.e, acc, rows, n_blk, lane, smem + w * 11264);
+    } else {
+        float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = rows(j * 16 + (lane & 15));
+            if (m < 0) continue;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + i * 16 + gq * 4) = acc[i][j];
+        }
+    }
+}
+
 // out = sum_s partial[s] + bias + temb + res  (8 channels per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const float* __restrict__ partial, int splits) {
     const int NV = p.N >> 3;
@@ -551,7 +921,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
 // layers were bound by L2->LDS traffic (the activation panel was re-staged N/160 times), not MFMA.
 // Two LDS stages (144 KB), one workgroup per CU, 9 DMA issues per wave per 80 MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <bool GEGLU, int BNX, int RING = 0>
+template <bool GEGLU, int BNX>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     // BNX = 320: wave tile 64 x 160 (every SD1.5 width >= 320 with enough rows); BNX = 160: wave tile 64 x 80 for the 1280-wide layers
     // at 16 x 16 (M = 8192: 32 x 8 = 256 tiles = one per CU, where 256 x 320 tiles would leave half the chip idle)
@@ -654,12 +1024,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     trace_stamp(p.debug, blockIdx.x, 1);
 
     const int KTX = (p.debug & 2) ? 0 : p.KT;
-    // (debug bit 16384: where a k step's time goes, in shader-clock cycles summed over the k loop: DMA issue / MFMAs + fragment reads /
-    //  wait for the DMA / barrier; waves 0 and 4 of each workgroup, slots [6..9] and [10..11] of the trace record hold wave 0's sums and stamps)
-    const bool tr = (p.debug & 16384) && lane == 0 && w == 0 && blockIdx.x < CS_TRACE_SLOTS;
-    unsigned long long tsum[4] = {0, 0, 0, 0}, tc0 = 0;
-    if (tr) tc0 = __builtin_readcyclecounter();
-    if constexpr (RING >= 2) {
+    {
         // PIPELINED form (the FLUX GEMM's structure, csrc/gemm2.hip, on this tile): the per-step barrier sits at three quarters of the step.
         // Before it a wave has ALL of the stage's fragments in registers (the last NT/2 weight fragments are read ahead into a five-slot
         // ring), so after it (i) the buffer just released is re-filled in place with stage kt + 2 while (ii) the remaining MFMAs of step kt
@@ -731,75 +1096,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
             }
         }
         __syncthreads();                            // the stage buffers become the epilogue patches
-    } else
-    for (int kt = 0; kt < KTX; ++kt) {
-        const int buf = kt & 1;
-        unsigned long long ta_ = 0, tb_ = 0, tc_ = 0, td_ = 0;
-        if (p.debug & 16384) ta_ = __builtin_readcyclecounter();
-        const bool do_stage = kt + 1 < p.KT && !(p.debug & 32768);                                     // (timing experiments: no staging / the same k step every time)
-        const int kt_stage = (p.debug & 131072) ? 0 : kt + 1;
-        if (do_stage && !RING) stage(kt_stage, buf ^ 1);
-        const char* ta = smem + buf * STAGE + (wm * 64) * 128;
-        const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 128;
-        if (p.debug & 16384) { __builtin_amdgcn_sched_barrier(0); tb_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-        if constexpr (RING == 1) {
-            // fragment reads run a RING of two weight fragments ahead of the MFMAs that consume them, and the second half-step's
-            // activation fragments are read under the first half's last MFMAs: every wait is a counted lgkmcnt(N > 0).  (The compiler's
-            // own order is read two fragments -> lgkmcnt(0) -> eight MFMAs, ten exposed LDS latencies per k step.)
-            // The next stage's DMA pieces go BETWEEN the items, one per SP items, activations first: 72 KB per step through the CU's 64 B/clk
-            // vector-memory path is ~1150 cycles, and issued as one burst at the top of the step every wave of the CU sat in it while the
-            // matrix pipe idled (stamps: 0.57 us of a 2.3 us step, profiles/r02_gemm_timeline.txt).
-            constexpr int NQ = 2 * NT;                                   // items: (half-step ks, weight tile i)
-            constexpr int NP = 4 + BPW, SP = (NQ >= 2 * NP) ? 2 : 1;
-            auto wr = [&](int q) { const int ks = q / NT, i = q - ks * NT; return *reinterpret_cast<const f16x8*>(tb + i * 2048 + (ks ? frag_off1 : frag_off0)); };
-            f16x8 fa[2][MT], fw[3];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) fa[0][j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + frag_off0);
-            fw[0] = wr(0); fw[1] = wr(1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int ks = q / NT, i = q - ks * NT;
-                if (q + 2 < NQ) fw[(q + 2) % 3] = wr(q + 2);
-                if (ks == 0 && i >= NT - MT) fa[1][i - (NT - MT)] = *reinterpret_cast<const f16x8*>(ta + (i - (NT - MT)) * 2048 + frag_off1);
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[q % 3], fa[ks][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q % SP == 0 && q / SP < NP) {
-                    if (do_stage) stage_piece(kt_stage, buf ^ 1, q / SP);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        } else
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fo = ks ? frag_off1 : frag_off0;
-            f16x8 fa[MT];
-#pragma unroll
-            for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 2048 + fo);
-#pragma unroll
-            for (int half = 0; half < NT / NH; ++half) {
-                f16x8 fw[NH];
-#pragma unroll
-                for (int i = 0; i < NH; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + (half * NH + i) * 2048 + fo);
-#pragma unroll
-                for (int i = 0; i < NH; ++i)
-#pragma unroll
-                    for (int j = 0; j < MT; ++j)
-                        acc[half * NH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[half * NH + i][j], 0, 0, 0);
-            }
-        }
-        if (p.debug & 16384) { __builtin_amdgcn_sched_barrier(0); tc_ = __builtin_readcyclecounter(); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.debug & 16384) td_ = __builtin_readcyclecounter();
-        __syncthreads();
-        if (tr) { const unsigned long long te_ = __builtin_readcyclecounter(); tsum[0] += tb_ - ta_; tsum[1] += tc_ - tb_; tsum[2] += td_ - tc_; tsum[3] += te_ - td_; }
-    }
-    if (tr) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) g_trace[blockIdx.x * CS_TRACE_W + 6 + k] = tsum[k];
-        g_trace[blockIdx.x * CS_TRACE_W + 10] = tc0; g_trace[blockIdx.x * CS_TRACE_W + 11] = __builtin_readcyclecounter();
     }
     trace_stamp(p.debug, blockIdx.x, 2);
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
@@ -807,132 +1103,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, (BNX == 320 ? 2 : 1)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     trace_stamp(p.debug, blockIdx.x, 3);
     if (p.debug & 16384) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p.debug, blockIdx.x, 4); }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same 256 x 320 tile in the halo conv kernel's LOOP STRUCTURE (round 2): k steps of 32 (one MFMA k-step), THREE LDS stages
-// of [256 + 320 rows][64 B] = 36 KB, waves 4-7 staggered by one step behind waves 0-3 with static priority and their LDS-DMA
-// issues placed among their MFMAs.  gemm_big_kernel's k64 steps need 112 fragment registers for a whole step, which the staggered
-// group would have to hold across the barrier next to 160 accumulators; at k32 it is 56.  Why the structure: profiles/r02_conv_bound.txt
-// (lock-step waves lose an LDS latency after every barrier; priority makes the stagger's overlap real).
-// 64-byte LDS rows, 16-byte chunk index XOR (row >> 1) & 3 (conflict-free ds_read_b128, as the conv kernel's k32 weight tile);
-// one DMA instruction = 16 rows.  Hazard rule as in the conv kernel: slab s is read during iteration s by both groups (group B's
-// reads may still be in flight when the barrier ending s opens), so its buffer is re-staged no earlier than iteration s + 2.
-// ------------------------------------------------------------------------------------------------
-template <bool GEGLU>
-__global__ __launch_bounds__(512, 2) void gemm_stag_kernel(IgemmParams p) {
-    constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4, KS = 32;
-    constexpr int A_BYTES = BMX * KS * 2, B_BYTES = BNX * KS * 2, STAGE = A_BYTES + B_BYTES;     // 16 KB + 20 KB
-    constexpr int APQ = BMX / 16, BPQ = BNX / 16;                 // DMA pieces per stage: 16 + 20
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
-    const int m_blk = tm * BMX, n_blk = tn * BNX;
-
-    // ---- staging: wave w issues A pieces {w, w + 8} and W pieces {w, w + 8, w + 16 (< 20)} -----------------
-    const int pch = lane & 3;
-    int a_row[2], a_chunk[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 16 * (w + 8 * j) + (lane >> 2);
-        const int m = m_blk + r;
-        a_chunk[j] = (pch ^ ((r >> 1) & 3)) * 8;
-        a_row[j] = (m < p.M) ? m : -1;
-    }
-    const f16* b_src[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int q = w + 8 * j;
-        const int r = 16 * (q < BPQ ? q : 0) + (lane >> 2);
-        b_src[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 3)) * 8;
-    }
-    const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
-    const int KT32 = p.KT * 2;
-    auto stage = [&](int kt, int buf) {
-        const int cc = kt * KS;
-        const f16* src; int cs, coff;
-        if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
-        char* la = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool ok = a_row[j] >= 0;
-            const uintptr_t real = (uintptr_t)(src + ((long)a_row[j] * cs + coff + a_chunk[j]));
-            const uintptr_t msk = (uintptr_t)0 - (uintptr_t)ok;
-            glds16((const void*)((real & msk) | ((uintptr_t)zero & ~msk)), la + (w + 8 * j) * 1024);
-        }
-        char* lb = smem + buf * STAGE + A_BYTES;
-        glds16(b_src[0] + (size_t)kt * KS, lb + w * 1024);
-        glds16(b_src[1] + (size_t)kt * KS, lb + (w + 8) * 1024);
-        if (w + 16 < BPQ) glds16(b_src[2] + (size_t)kt * KS, lb + (w + 16) * 1024);
-    };
-
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int g = lane >> 4;
-    const int frag_off = (lane & 15) * 64 + ((g ^ ((lane >> 1) & 3)) * 16);
-    f16x8 fa[MT], fw[NT];
-    auto read_frags = [&](int buf) {
-        const char* ta = smem + buf * STAGE + (wm * 64) * 64;
-        const char* tb = smem + buf * STAGE + A_BYTES + (wn * (BNX / 2)) * 64;
-#pragma unroll
-        for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const f16x8*>(ta + j * 1024 + frag_off);
-#pragma unroll
-        for (int i = 0; i < NT; ++i) fw[i] = *reinterpret_cast<const f16x8*>(tb + i * 1024 + frag_off);
-    };
-    auto multiply_part = [&](auto i0_tag, auto i1_tag) {
-        constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
-#pragma unroll
-        for (int i = I0; i < I1; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-    };
-
-    const bool groupB = w >= 4;
-    if (groupB) __builtin_amdgcn_s_setprio(2);
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int buf = 0;
-#pragma unroll 1
-    for (int kt = 0; kt < KT32; ++kt) {
-        const int nbuf = buf == 2 ? 0 : buf + 1;
-        const bool more = kt + 1 < KT32;
-        if (groupB) {
-            // multiply step kt - 1 (fragments read before the previous barrier), this wave's DMA issues in between
-            constexpr int C1 = NT / 2;
-            if (kt > 0) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, C1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) stage(kt + 1, nbuf);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt > 0) multiply_part(std::integral_constant<int, C1>{}, std::integral_constant<int, NT>{});
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            if (more) stage(kt + 1, nbuf);
-        }
-        read_frags(buf);
-        if (!groupB) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        buf = nbuf;
-    }
-    if (groupB) multiply_part(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{});     // drain: group B's last step
-    __syncthreads();                               // group B's last reads are consumed; the stage buffers become the epilogue patches
-    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
-    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
 template <int BN, bool CONV3, bool GEGLU>
@@ -1102,10 +1272,9 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 int g_tune_debug = 0;
 int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
 int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
-int g_tune_gemm_ring = 2;      // gemm_big_kernel k loop: 2 pipelined (barrier at 3/4 of the step, in-place refill; default), 1 fragment ring + spread DMA, 0 the compiler's order
-int g_tune_gemm_stag = 0;      // 1: 256 x 320 linear / 1x1 layers through gemm_stag_kernel instead of gemm_big_kernel<.,320>
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
+int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
 
 double igemm_flops(const IgemmArgs& a) {
@@ -1177,6 +1346,9 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP;
         if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
         else if (a.N % 256 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 256) >= 192 || g_tune_halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
+        // round 3: loader-wave kernel (256 pixels x 160 channels per workgroup) wherever the channel count allows it
+        const bool lw = g_tune_conv_lw != 0 && a.N % 160 == 0;
+        if (lw) { hbn = 160; wide = false; }
         const int tiles_n = a.N / hbn;
         const int NC = cin / BK;
         int splits = 1;
@@ -1199,7 +1371,28 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * (wide ? 64 : 128));
             const dim3 grid(h.e.nblk, splits);
             int rc;
-            if (wide && hbn == 320) rc = a.upsample ? launch_halo<true, 320, 2>(h, grid, l, s) : launch_halo<false, 320, 2>(h, grid, l, s);
+            if (lw) {
+                constexpr size_t llw_max = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);      // = 160 KiB exactly: the whole LDS of a CU
+                const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * (160 * 128);
+                // FAST: plain conv on 16 x 16 patches (every UNet level down to 16 x 16, the VAE): immediate-offset LDS addressing
+                const bool fast = !a.upsample && TW == 16 && TH == 16 && h.HALO_W == 18 && h.NQ == 41 && g_tune_conv_lw != 2;
+                typedef void (*lw_fn)(HaloParams);
+                static const lw_fn variants[5] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
+                                                  conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>};
+                static bool configured_lw = false;
+                if (!configured_lw) {
+                    for (lw_fn f : variants)
+                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)llw_max));
+                    configured_lw = true;
+                }
+                auto launch = [&](lw_fn kfn) -> int { hipLaunchKernelGGL(kfn, grid, dim3(512), llw, s, h); return CS_OK; };
+                const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations
+                if (trace) rc = launch(variants[fast ? 3 : 4]);
+                else if (a.upsample) rc = launch(variants[2]);
+                else rc = launch(variants[fast ? 0 : 1]);
+                if (rc != CS_OK) return rc;
+                rc = CS_OK;
+            } else if (wide && hbn == 320) rc = a.upsample ? launch_halo<true, 320, 2>(h, grid, l, s) : launch_halo<false, 320, 2>(h, grid, l, s);
             else if (wide) rc = a.upsample ? launch_halo<true, 256, 2>(h, grid, l, s) : launch_halo<false, 256, 2>(h, grid, l, s);
             else if (hbn == 160) rc = a.upsample ? launch_halo<true, 160, 1>(h, grid, l, s) : launch_halo<false, 160, 1>(h, grid, l, s);
             else rc = a.upsample ? launch_halo<true, 128, 1>(h, grid, l, s) : launch_halo<false, 128, 1>(h, grid, l, s);
@@ -1228,43 +1421,6 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            if (g_tune_gemm_stag) {                      // round-2 loop structure (k32 steps, three stages, staggered wave groups)
-                constexpr size_t lds3 = 3 * (256 * 32 * 2 + 320 * 32 * 2);
-                static bool configured3 = false;
-                if (!configured3) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stag_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-                    configured3 = true;
-                }
-                if (a.geglu) hipLaunchKernelGGL((gemm_stag_kernel<true>), dim3(p.nblk), dim3(512), lds3, s, p);
-                else hipLaunchKernelGGL((gemm_stag_kernel<false>), dim3(p.nblk), dim3(512), lds3, s, p);
-                CS_CHECK_LAUNCH();
-                return CS_OK;
-            }
-            if (g_tune_gemm_ring) {
-                static bool configured_r = false;
-                if (!configured_r) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    configured_r = true;
-                }
-                if (g_tune_gemm_ring >= 2) {
-                    static bool configured_2 = false;
-                    if (!configured_2) {
-                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        configured_2 = true;
-                    }
-                    if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320, 2>), dim3(p.nblk), dim3(512), lds, s, p);
-                    else hipLaunchKernelGGL((gemm_big_kernel<false, 320, 2>), dim3(p.nblk), dim3(512), lds, s, p);
-                    CS_CHECK_LAUNCH();
-                    return CS_OK;
-                }
-                if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
-                else hipLaunchKernelGGL((gemm_big_kernel<false, 320, true>), dim3(p.nblk), dim3(512), lds, s, p);
-                CS_CHECK_LAUNCH();
-                return CS_OK;
-            }
             if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             else hipLaunchKernelGGL((gemm_big_kernel<false, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();
@@ -1281,26 +1437,6 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             if (!configured) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
-            }
-            if (g_tune_gemm_ring) {
-                static bool configured_r = false;
-                if (!configured_r) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    configured_r = true;
-                }
-                if (g_tune_gemm_ring >= 2) {
-                    static bool configured_2 = false;
-                    if (!configured_2) {
-                        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        configured_2 = true;
-                    }
-                    hipLaunchKernelGGL((gemm_big_kernel<false, 160, 2>), dim3(p.nblk), dim3(512), lds, s, p);
-                    CS_CHECK_LAUNCH();
-                    return CS_OK;
-                }
-                hipLaunchKernelGGL((gemm_big_kernel<false, 160, true>), dim3(p.nblk), dim3(512), lds, s, p);
-                CS_CHECK_LAUNCH();
-                return CS_OK;
             }
             hipLaunchKernelGGL((gemm_big_kernel<false, 160>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();

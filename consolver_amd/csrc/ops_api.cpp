@@ -4,8 +4,8 @@
 #include <cstring>
 
 extern int g_tune_halo;
+extern int g_tune_conv_lw;
 extern int g_tune_debug;
-extern int g_tune_gemm_ring;
 extern int g_tune_gemm_gm;
 extern int g_tune_gn_fuse;
 int debug_trace_read(void* dst, size_t bytes);
@@ -13,7 +13,6 @@ extern int g_tune_cfg_share;
 extern int g_tune_xattn_fused;
 extern int g_tune_conv_sched;
 extern int g_tune_attn_prio;
-extern int g_tune_gemm_stag;
 extern int g_tune_gemm2_prio;
 extern int g_tune_biggemm;
 extern int g_tune_attn_qt40;
@@ -23,15 +22,14 @@ extern "C" {
 int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
+    if (!strcmp(key, "conv_lw")) { g_tune_conv_lw = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
     if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
-    if (!strcmp(key, "gemm_ring")) { if (value < 0 || value > 2) CS_FAIL(CS_E_ARG, "gemm_ring: 0, 1 or 2"); g_tune_gemm_ring = value; return CS_OK; }
     if (!strcmp(key, "gemm_gm")) { g_tune_gemm_gm = value; return CS_OK; }
     if (!strcmp(key, "gn_fuse")) { g_tune_gn_fuse = value ? 1 : 0; return CS_OK; }
     if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
     if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
-    if (!strcmp(key, "gemm_stag")) { g_tune_gemm_stag = value; return CS_OK; }
     if (!strcmp(key, "attn_prio")) { g_tune_attn_prio = value; return CS_OK; }
     if (!strcmp(key, "conv_sched")) { if (value < -1 || value > 2) CS_FAIL(CS_E_ARG, "conv_sched must be -1 (auto), 0, 1 or 2"); g_tune_conv_sched = value; return CS_OK; }
     if (!strcmp(key, "attn_qt40")) { if (value != 2 && value != 4) CS_FAIL(CS_E_ARG, "attn_qt40 must be 2 or 4"); g_tune_attn_qt40 = value; return CS_OK; }

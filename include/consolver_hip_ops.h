@@ -124,10 +124,9 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
  *                cs_op_conv2d_gn, 0 always a separate statistics pass;
- *   "gemm_ring": k loop of the 256-row GEMM kernel: 2 (default) pipelined (barrier at 3/4 of the step, in-place refill of the stage buffer),
- *                1 fragment-read ring + DMA pieces spread between the MFMAs, 0 the compiler's order;
- *   "gemm_gm":   its tile order: -1 (default) bands of 4 tile rows when there are >= 12 tile columns, 0 / 1 row-major, n bands of n;
- *   "gemm_stag": 1 the staggered k32 three-stage variant of that kernel (measured experiment, default 0);
+ *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 run on the loader-wave kernel (conv3_lw_kernel: waves 0-3 multiply,
+ *                waves 4-7 stage), 0 the 8-wave halo kernels;
+ *   "gemm_gm":   tile order of the 256-row GEMM kernel: -1 (default) bands of 4 tile rows when there are >= 12 tile columns, 0 / 1 row-major, n bands of n;
  *   "attn_prio" / "gemm2_prio": static wave priority experiments (attn_prio -1 = auto: head dim 128 only);
  *   "debug":     timing experiments only (results are wrong or the run is slowed): 1 skip the GEMM epilogue, 2 skip its k loop,
  *                4096 static priority in the GEMM kernel, 8192 + (n << 16) late start of every other CU by n x s_sleep(127),

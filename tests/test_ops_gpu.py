@@ -85,11 +85,11 @@ def test_conv3x3_halo_kernel(case):
     x, w, b = rnd(B, H, W, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, W, N, seed=5)
     ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
-    ops.set_tuning("conv_halo", 2)
+    ops.set_tuning("conv_halo", 2); ops.set_tuning("conv_lw", 0)
     try:
         out = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
     finally:
-        ops.set_tuning("conv_halo", 1)
+        ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
     generic = None
     ops.set_tuning("conv_halo", 0)
     try:
@@ -105,11 +105,11 @@ def test_conv3x3_halo_kernel(case):
 def test_conv3x3_halo_kernel_fused_upsample(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
-    ops.set_tuning("conv_halo", 2)
+    ops.set_tuning("conv_halo", 2); ops.set_tuning("conv_lw", 0)
     try:
         out = ops.conv2d(x, ops.pack_conv_weight(w), b, upsample=True)
     finally:
-        ops.set_tuning("conv_halo", 1)
+        ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
     assert out.shape == (B, 2 * H, 2 * H, N)
     assert rel_l2(nchw(out), ref) < 1e-3
 
@@ -129,11 +129,11 @@ def test_conv3x3_halo_kernel_wide_tiles(case):
     ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
     outs = {}
     for mode in (3, 4):                     # 3: force the wide tiles, 4: forbid them (k64 tiles of 160 / 128 columns)
-        ops.set_tuning("conv_halo", mode)
+        ops.set_tuning("conv_halo", mode); ops.set_tuning("conv_lw", 0)
         try:
             outs[mode] = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
         finally:
-            ops.set_tuning("conv_halo", 1)
+            ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
     assert rel_l2(nchw(outs[3]), ref) < 1e-3
     assert float((nchw(outs[3]) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
     assert rel_l2(outs[3].float(), outs[4].float()) < 5e-4      # same math, different k order
@@ -143,12 +143,68 @@ def test_conv3x3_halo_kernel_wide_tiles(case):
 def test_conv3x3_halo_kernel_wide_tiles_fused_upsample(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
-    ops.set_tuning("conv_halo", 3)
+    ops.set_tuning("conv_halo", 3); ops.set_tuning("conv_lw", 0)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, upsample=True)
+    finally:
+        ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+
+
+LW_CASES = [  # B, H, W, cin, N (N % 160 == 0): the loader-wave kernel (conv3_lw_kernel) forced on every tile geometry -- 16 x 16 patches, whole
+    # 8-wide images four per tile with a ragged last tile, non-square images, one / several column tiles, one / many channel chunks
+    (2, 64, 64, 64, 320), (3, 32, 32, 128, 160), (2, 16, 16, 64, 320), (5, 8, 8, 64, 160), (1, 8, 8, 128, 320), (1, 64, 64, 320, 640),
+    (2, 16, 32, 64, 160), (3, 16, 8, 64, 160), (1, 48, 80, 64, 480), (1, 32, 32, 640, 640), (2, 16, 16, 1280, 1280), (7, 8, 8, 192, 960)]
+
+
+@pytest.mark.parametrize("case", LW_CASES)
+def test_conv3x3_loader_wave_kernel(case):
+    B, H, W, cin, N = case
+    x, w, b = rnd(B, H, W, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, W, N, seed=5)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
+    outs = {}
+    for lw in (1, 0):
+        ops.set_tuning("conv_halo", 2); ops.set_tuning("conv_lw", lw)
+        try:
+            outs[lw] = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res, splitk=False)     # (no split over the chunks: bit-comparable)
+            if lw:
+                again = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res, splitk=False)
+        finally:
+            ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
+    assert rel_l2(nchw(outs[1]), ref) < 1e-3
+    assert float((nchw(outs[1]) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+    assert torch.equal(outs[1], outs[0])        # same k order (chunk-major, tap-minor, two k halves) and same epilogue as the 8-wave halo kernel
+    assert torch.equal(outs[1], again)
+
+
+@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320), (1, 32, 320, 640)])
+def test_conv3x3_loader_wave_kernel_fused_upsample(B, H, cin, N):
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    ops.set_tuning("conv_halo", 2)
     try:
         out = ops.conv2d(x, ops.pack_conv_weight(w), b, upsample=True)
     finally:
         ops.set_tuning("conv_halo", 1)
+    assert out.shape == (B, 2 * H, 2 * H, N)
     assert rel_l2(nchw(out), ref) < 1e-3
+    assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160)])
+def test_conv3x3_loader_wave_kernel_split_k(B, H, cin, N):
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
+    ops.set_tuning("conv_halo", 2)
+    try:
+        out = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
+        out2 = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res.clone())
+    finally:
+        ops.set_tuning("conv_halo", 1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+    assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160)])
@@ -157,13 +213,13 @@ def test_conv3x3_halo_kernel_split_k(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
     ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1) + temb.float()[:, :, None, None] + nchw(res)
-    ops.set_tuning("conv_halo", 2)
+    ops.set_tuning("conv_halo", 2); ops.set_tuning("conv_lw", 0)
     try:
         out = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res)
         res2 = res.clone()
         out2 = ops.conv2d(x, ops.pack_conv_weight(w), b, temb=temb, res=res2)   # deterministic (no atomics)
     finally:
-        ops.set_tuning("conv_halo", 1)
+        ops.set_tuning("conv_halo", 1); ops.set_tuning("conv_lw", 1)
     assert rel_l2(nchw(out), ref) < 1e-3
     assert torch.equal(out, out2)
 

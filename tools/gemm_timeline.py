@@ -47,7 +47,7 @@ for tag, M, K, N, res, geglu in shapes:
         print("   k loop split, us per workgroup (counter %.0f MHz): DMA issue %.2f | MFMAs + fragment reads %.2f | wait for the DMA %.2f | barrier %.2f ; steps %d"
               % (mhz, parts[0], parts[1], parts[2], parts[3], K // 64))
     else:
-        print("   k loop split: n/a (the in-loop cycle stamps exist in the gemm_ring = 0 / 1 loops only: CS_TUNE=gemm_ring=1)")
+        print("   k loop split: n/a (the in-loop cycle stamps belonged to the round-2 non-pipelined loops, removed in round 3)")
     gaps, firsts = [], []
     for c in np.unique(cu):
         idx = np.where(cu == c)[0]
