@@ -26,6 +26,7 @@
 
 extern int g_tune_halo;
 extern int g_tune_conv_lw;
+extern int g_tune_gemm_w8;
 extern int g_tune_debug;
 extern int g_tune_biggemm;
 
@@ -554,6 +555,8 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(static_ca
 // conv3_lw_kernel: number of LDS reads issued AFTER the youngest read item q multiplies, counted up to and including item q's own reads (LDS returns in
 // order, so s_waitcnt lgkmcnt(that) is exactly "my operands have landed").  Reads in front of item p's MFMAs, in order: one weight fragment (for item p + LA),
 // then (p < MT) one k-half-1 activation fragment, then (p = QB, QB + 1) two next-step activation fragments.
+// FAST addressing of conv3_lw_kernel: halo row (relative to the wave's first one) read by output row j of the wave under tap row dy
+constexpr int lw_rowi(bool up, int j, int dy) { return up ? (j + dy + 1) / 2 : dy + j; }        // (((j + dy - 1) >> 1) + 1 == (j + dy + 1) / 2 for j + dy >= 0)
 constexpr int lw_reads_of(int p, int MT, int QB) { return 1 + (p < MT ? 1 : 0) + ((p == QB || p == QB + 1) ? 2 : 0); }
 constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
     // the weight fragment of item q was the FIRST read of item q - LA (mod NQ)
@@ -587,14 +590,16 @@ constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
 //     (output row j + tap row dy) * 18 * 128 + parity * 41 KiB < 64 Ki fits the 16-bit offset field of ds_read.
 template <bool UP, int BN, bool TRACE = false, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
-    static_assert(!(FAST && UP), "the FAST addressing is for the plain 3x3 conv");
+    // (FAST with the fused nearest-x2 upsample: the 16 x 16 output patch reads an 8 x 8 input patch, HALO_W = 10, 100 halo rows, 13 pieces; output column fx
+    //  under tap column dx reads halo column ((fx + dx - 1) >> 1) + 1 -- again three per-lane values -- and output row 4 w + j under tap row dy reads halo row
+    //  2 w + ((j + dy - 1) >> 1) + 1: the (j, dy) part is a compile-time immediate)
     constexpr int NT = BN / 16, MT = 4;
     constexpr int B_BYTES = BN * 128, NWB = 3;
     constexpr int NBQ = BN / 8;                              // weight DMA pieces per stage (8 rows of 128 B each)
     static_assert(NBQ % 4 == 0, "every loader wave issues the same number of weight pieces");
     constexpr int WPL = NBQ / 4;                             // ... per loader wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int A_BYTES = FAST ? 41 * 1024 : p.NQ * 1024;          // halo buffer: NQ pieces of 8 rows (<= HALO_ROWS_MAX * 128)
+    const int A_BYTES = FAST ? (UP ? 13 : 41) * 1024 : p.NQ * 1024;          // halo buffer: NQ pieces of 8 rows (<= HALO_ROWS_MAX * 128)
     char* const lA = smem;                    // [2][A_BYTES]
     char* const lB = smem + 2 * A_BYTES;      // [NWB][B_BYTES]: stage g lives in buffer g % 3
 
@@ -753,22 +758,23 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     if constexpr (FAST) {
         // per-tile address registers: VA[dx][ks] = halo row of (output row 4 w, tap row 0) at column fx + dx, k half ks, in the CURRENT chunk's halo buffer
         // (moved to the other buffer once per chunk: 7 v_add per 720 MFMAs); VN = VA[0][0] in the other buffer; WB[wb][ks] = weight tile 0 of buffer wb
-        constexpr int AB_F = 41 * 1024, ROWB = 18 * 128;
+        constexpr int HW_F = UP ? 10 : 18, AB_F = (UP ? 13 : 41) * 1024, ROWB = HW_F * 128;
         const int fxl = lane & 15;
-        const unsigned rowb = lA_base + (unsigned)((4 * wm) * 18 + fxl) * 128;
+        const unsigned rowb = lA_base + (unsigned)((UP ? 2 : 4) * wm * HW_F) * 128;
         unsigned VA[3][2], VN, WB[NWB][2];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const unsigned sw = (unsigned)((gq ^ ((fxl + d) & 7)) << 4);
-            VA[d][0] = rowb + d * 128 + sw; VA[d][1] = rowb + d * 128 + (sw ^ 64u);
+            const int hcol = UP ? ((fxl + d - 1) >> 1) + 1 : fxl + d;                     // halo column read by this lane under tap column d
+            const unsigned sw = (unsigned)((gq ^ (hcol & 7)) << 4);
+            VA[d][0] = rowb + hcol * 128 + sw; VA[d][1] = rowb + hcol * 128 + (sw ^ 64u);
         }
         VN = VA[0][0] + AB_F;
 #pragma unroll
         for (int b3 = 0; b3 < NWB; ++b3) { WB[b3][0] = lB_base + b3 * B_BYTES + wfrag0; WB[b3][1] = lB_base + b3 * B_BYTES + wfrag1; }
         __builtin_amdgcn_s_barrier();                                           // K(-1): stage 0 has landed
         // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (tap (0, 0), halo buffer 0, weight buffer 0)
-        lds_read<0>(fw[0], WB[0][0]); lds_read<0 * ROWB>(fa[0][0], VA[0][0]); lds_read<1 * ROWB>(fa[0][1], VA[0][0]);
-        lds_read<2048>(fw[1], WB[0][0]); lds_read<2 * ROWB>(fa[0][2], VA[0][0]); lds_read<3 * ROWB>(fa[0][3], VA[0][0]);
+        lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowi(UP, 0, 0) * ROWB>(fa[0][0], VA[0][0]); lds_read<lw_rowi(UP, 1, 0) * ROWB>(fa[0][1], VA[0][0]);
+        lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowi(UP, 2, 0) * ROWB>(fa[0][2], VA[0][0]); lds_read<lw_rowi(UP, 3, 0) * ROWB>(fa[0][3], VA[0][0]);
         lds_read<2 * 2048>(fw[2], WB[0][0]); lds_read<3 * 2048>(fw[3], WB[0][0]);
         static_assert(LA == 4, "prologue reads");
         if (TRACE) { tc_t0 = __builtin_readcyclecounter(); tc_r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -787,13 +793,13 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
                         else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], WB[WBC][1]);
                         else lds_read<(r - NQ) * 2048>(fw[r % RS], WB[WBN][0]);
                     }
-                    if constexpr (q < MT) lds_read<(DY + q) * ROWB>(fa[1][q], VA[DX][1]);
+                    if constexpr (q < MT) lds_read<lw_rowi(UP, q, DY) * ROWB>(fa[1][q], VA[DX][1]);
                     if constexpr (q == QB || q == QB + 1) {
                         constexpr int j0 = (q - QB) * 2;
                         if constexpr (T == 8) {
-                            lds_read<j0 * ROWB>(fa[0][j0], VN); lds_read<(j0 + 1) * ROWB>(fa[0][j0 + 1], VN);
+                            lds_read<lw_rowi(UP, j0, 0) * ROWB>(fa[0][j0], VN); lds_read<lw_rowi(UP, j0 + 1, 0) * ROWB>(fa[0][j0 + 1], VN);
                         } else {
-                            lds_read<(DYN + j0) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<(DYN + j0 + 1) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
+                            lds_read<lw_rowi(UP, j0, DYN) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<lw_rowi(UP, j0 + 1, DYN) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
@@ -883,6 +889,145 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
                 *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + i * 16 + gq * 4) = acc[i][j];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 256 x 320 x 64 GEMM tile (8 waves, all multiplying, wave tile 64 x 160, two 72 KB stages) with the k loop written like conv3_lw_kernel's
+// (round 3).  gemm_big_kernel's loop carried ~180 vector-ALU instructions per wave and step -- the zero-page select and the 64-bit address of its
+// nine LDS-DMA pieces -- plus hipcc's own waits (lgkmcnt(0) at the loop head).  Here:
+//   * LDS-DMA as buffer_load ... lds: per-piece 32-bit row offsets computed once per tile, the k offset in an SGPR (soffset): no vector ALU;
+//     rows past M are clamped to the last row (their products are never stored) instead of being redirected to a zero page;
+//   * every fragment read is an inline-asm ds_read_b128 at (per-tile register + immediate), every wait a hand-counted lgkmcnt, MFMAs in place;
+//   * piece schedule: behind barrier K(g) (item 16 of step g) buffer g & 1 is free (every wave has waited lgkmcnt(0) in front of the barrier):
+//     pieces 0..3 of stage g + 2 go out with items 16..19, pieces 4..8 with items 0..4 of step g + 1; vmcnt(0) in front of K(g + 1).
+// Activations / weights must be addressable with 32-bit byte offsets (M * K * 2 < 4 GiB), else the caller falls back to gemm_big_kernel.
+// Measured against it and removed (round 3, same-box A/Bs under profiles/): the loader-wave form on a 256 x 160 tile (r03_ab_gemm_lw.txt: bit-identical,
+// +20..40 % time on the K <= 2560 shapes -- twice the L2 -> LDS bytes per FLOP and that path is the bound) and the 256 x 320 tile on four 512-register waves
+// with the accumulators in AGPRs (r03_ab_gemm_w4.txt: bit-identical, +10..30 % -- half the waves for a store-bound epilogue, no k-loop gain).
+// ------------------------------------------------------------------------------------------------
+template <bool GEGLU>
+__global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
+    constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4;
+    constexpr int A_BYTES = BMX * 128, B_BYTES = BNX * 128, STAGE = A_BYTES + B_BYTES;      // 32 KB + 40 KB
+    constexpr int NPC = 9;                                       // DMA pieces per wave and stage: 4 of the activations + 5 of the weights
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int tm, tn;
+    if (p.gm > 1) {
+        const int tiles_m = p.nblk / p.tiles_n;
+        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
+        const int gsz = min(p.gm, tiles_m - band * p.gm);
+        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
+    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+    const int m_blk = tm * BMX, n_blk = tn * BNX;
+    const int KT = p.KT;
+
+    // ---- staging: wave w owns activation pieces 4 w .. 4 w + 3 (rows 32 w ..) and weight pieces w, w + 8, .. w + 32 ----------------------------
+    const int pch = lane & 7, lr = lane >> 3;
+    unsigned aoff0[4], aoff1[4], woff[5];                        // byte offsets from a0 / a1 / w (row * row length + swizzled chunk)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (w * 4 + j) + lr;
+        const unsigned m = (unsigned)min(m_blk + r, p.M - 1);
+        const unsigned ch = (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
+        aoff0[j] = m * (unsigned)(p.c0 * 2) + ch; aoff1[j] = m * (unsigned)(p.c1 * 2) + ch;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int r = 8 * (w + 8 * j) + lr;
+        woff[j] = (unsigned)(n_blk + r) * (unsigned)(p.Ktot * 2) + (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
+    }
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c1 ? p.a1 : p.a0), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xffffffff, 0x00020000);
+    // piece n (0..8) of stage kt into stage buffer `buf`
+    auto piece = [&](auto n_tag, int kt, int buf) {
+        constexpr int n = decltype(n_tag)::value;
+        const int cc = kt * BK;
+        if constexpr (n < 4) {
+            lptr_t dst = (lptr_t)(smem + buf * STAGE + (w * 4 + n) * 1024);
+            if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, dst, 16, aoff0[n], cc * 2, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, dst, 16, aoff1[n], (cc - p.c0) * 2, 0, 0);
+        } else {
+            lptr_t dst = (lptr_t)(smem + buf * STAGE + A_BYTES + (w + 8 * (n - 4)) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, woff[n - 4], cc * 2, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing: per-tile registers + immediates ----------------------------------------------------------------------------------
+    const int gq = lane >> 4, swz = (lane >> 1) & 7;
+    const unsigned sbase = lds_addr(smem);
+    const unsigned wfrag0 = (lane & 15) * 128 + (gq ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + gq) ^ swz) * 16;
+    unsigned SA[2][2], SW[2][2];
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+        SA[b2][0] = sbase + b2 * STAGE + wm * 8192 + wfrag0; SA[b2][1] = sbase + b2 * STAGE + wm * 8192 + wfrag1;
+        SW[b2][0] = sbase + b2 * STAGE + A_BYTES + wn * (BNX / 2) * 128 + wfrag0; SW[b2][1] = sbase + b2 * STAGE + A_BYTES + wn * (BNX / 2) * 128 + wfrag1;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NQ = 2 * NT, RS = NT / 2, LA = RS - 1, QB = NQ - LA;
+    static_assert(LA == 4 && MT == 4 && NPC == 9, "read / piece schedule");
+    f16x8 fa[2][MT], fw[RS];
+
+    // prologue: stage 0, then what items 16..19 of a step issue (pieces 0..3 of the next stage, the next step's first fragments)
+    static_for<NPC>([&](auto nc) { piece(nc, 0, 0); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (KT > 1) static_for<4>([&](auto nc) { piece(nc, 1, 1); });
+    lds_read<0>(fw[0], SW[0][0]); lds_read<0>(fa[0][0], SA[0][0]); lds_read<2048>(fa[0][1], SA[0][0]);
+    lds_read<2048>(fw[1], SW[0][0]); lds_read<2 * 2048>(fa[0][2], SA[0][0]); lds_read<3 * 2048>(fa[0][3], SA[0][0]);
+    lds_read<2 * 2048>(fw[2], SW[0][0]); lds_read<3 * 2048>(fw[3], SW[0][0]);
+
+    int kt = 0;
+    auto step = [&](auto b_tag) {                                               // stage kt in buffer B
+        constexpr int B = decltype(b_tag)::value, BO = B ^ 1;
+        static_for<NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
+            if constexpr (q == QB) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // stage kt + 1 (this wave's pieces) has landed; this wave's reads of stage kt are done
+                __builtin_amdgcn_s_barrier();                                    // K(kt)
+            }
+            {
+                constexpr int r = q + LA;
+                if constexpr (r < NT) lds_read<r * 2048>(fw[r % RS], SW[B][0]);
+                else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], SW[B][1]);
+                else lds_read<(r - NQ) * 2048>(fw[r % RS], SW[BO][0]);
+            }
+            if constexpr (q < MT) lds_read<q * 2048>(fa[1][q], SA[B][1]);
+            if constexpr (q == QB || q == QB + 1) {
+                constexpr int j0 = (q - QB) * 2;
+                lds_read<j0 * 2048>(fa[0][j0], SA[BO][0]); lds_read<(j0 + 1) * 2048>(fa[0][j0 + 1], SA[BO][0]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) mfma_inplace(acc[i][j], fw[q % RS], fa[ks][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            // staging: pieces 4..8 of stage kt + 1 (buffer BO) with items 0..4, pieces 0..3 of stage kt + 2 (buffer B, free behind K(kt)) with items 16..19
+            if constexpr (q < 5) { if (kt + 1 < KT) piece(std::integral_constant<int, 4 + q>{}, kt + 1, BO); }
+            if constexpr (q >= QB) { if (kt + 2 < KT) piece(std::integral_constant<int, q - QB>{}, kt + 2, B); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    for (;;) {
+        step(std::integral_constant<int, 0>{}); if (++kt == KT) break;
+        step(std::integral_constant<int, 1>{}); if (++kt == KT) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                               // the stage buffers become the epilogue patches
+    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
 // out = sum_s partial[s] + bias + temb + res  (8 channels per thread)
@@ -1274,6 +1419,7 @@ int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output
 int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
+int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
 int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
 
@@ -1375,10 +1521,10 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 constexpr size_t llw_max = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);      // = 160 KiB exactly: the whole LDS of a CU
                 const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * (160 * 128);
                 // FAST: plain conv on 16 x 16 patches (every UNet level down to 16 x 16, the VAE): immediate-offset LDS addressing
-                const bool fast = !a.upsample && TW == 16 && TH == 16 && h.HALO_W == 18 && h.NQ == 41 && g_tune_conv_lw != 2;
+                const bool fast = TW == 16 && TH == 16 && g_tune_conv_lw != 2 && (a.upsample ? (h.HALO_W == 10 && h.NQ == 13) : (h.HALO_W == 18 && h.NQ == 41));
                 typedef void (*lw_fn)(HaloParams);
-                static const lw_fn variants[5] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
-                                                  conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>};
+                static const lw_fn variants[6] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
+                                                  conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>, conv3_lw_kernel<true, 160, false, true>};
                 static bool configured_lw = false;
                 if (!configured_lw) {
                     for (lw_fn f : variants)
@@ -1386,9 +1532,9 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                     configured_lw = true;
                 }
                 auto launch = [&](lw_fn kfn) -> int { hipLaunchKernelGGL(kfn, grid, dim3(512), llw, s, h); return CS_OK; };
-                const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations
+                const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations (plain conv only)
                 if (trace) rc = launch(variants[fast ? 3 : 4]);
-                else if (a.upsample) rc = launch(variants[2]);
+                else if (a.upsample) rc = launch(variants[fast ? 5 : 2]);
                 else rc = launch(variants[fast ? 0 : 1]);
                 if (rc != CS_OK) return rc;
                 rc = CS_OK;
@@ -1420,6 +1566,20 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<true, 320>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
+            }
+            // round 3: the hand-scheduled k loop (gemm_w8_kernel) whenever 32-bit byte offsets reach every operand row
+            const bool off32 = (double)p.M * (a.c0 > a.c1 ? a.c0 : a.c1) * 2 < 4.0e9 && (double)a.N * p.Ktot * 2 < 4.0e9;
+            if (g_tune_gemm_w8 && off32 && !g_tune_debug) {
+                static bool configured_w8 = false;
+                if (!configured_w8) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    configured_w8 = true;
+                }
+                if (a.geglu) hipLaunchKernelGGL((gemm_w8_kernel<true>), dim3(p.nblk), dim3(512), lds, s, p);
+                else hipLaunchKernelGGL((gemm_w8_kernel<false>), dim3(p.nblk), dim3(512), lds, s, p);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
             }
             if (a.geglu) hipLaunchKernelGGL((gemm_big_kernel<true, 320>), dim3(p.nblk), dim3(512), lds, s, p);
             else hipLaunchKernelGGL((gemm_big_kernel<false, 320>), dim3(p.nblk), dim3(512), lds, s, p);

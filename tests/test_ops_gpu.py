@@ -266,6 +266,45 @@ def test_linear_big_tile_kernel(M, K, N, geglu):
     assert rel_l2(out.float(), ref) < 1.5e-3
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(256, 64, 320, False), (1000, 320, 960, False), (300, 128, 640, True), (513, 64, 2560, True), (8192, 1280, 1280, False),
+                                         (4097, 640, 1920, False), (2048, 2560, 640, False), (1, 192, 320, False), (8192, 1280, 2560, True)])
+def test_linear_hand_scheduled_256x320_kernel(M, K, N, geglu):
+    """gemm_w8_kernel (the 8-wave 256 x 320 tile with buffer-load LDS-DMA, hand-counted LDS reads, in-place MFMAs) against the reference and, bit for bit,
+    against gemm_big_kernel (same k order, same epilogue): one / odd / even k-step counts, ragged M (clamped rows), GEGLU, residual."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.2)
+    outs = {}
+    for w8 in (1, 0):
+        ops.set_tuning("gemm_w8", w8); ops.set_tuning("gemm_big", 2)
+        try:
+            if geglu:
+                wp, bp = ops.geglu_pack(w, b)
+                outs[w8] = ops.linear(x, wp.to(DEV), bp.to(DEV), geglu=True)
+                val, gate = F.linear(x.float(), w.float(), b.float()).chunk(2, dim=-1)
+                ref = val * F.gelu(gate)
+            else:
+                r = rnd(M, N, seed=4)
+                outs[w8] = ops.linear(x, w, b, res=r)
+                ref = F.linear(x.float(), w.float(), b.float()) + r.float()
+        finally:
+            ops.set_tuning("gemm_w8", 1); ops.set_tuning("gemm_big", 1)
+    assert rel_l2(outs[1].float(), ref) < 1.5e-3
+    assert torch.equal(outs[1], outs[0])
+
+
+def test_conv1x1_over_concat_hand_scheduled_kernel():
+    B, H, c0, c1, N = 2, 16, 640, 320, 640
+    x0, x1 = rnd(B, H, H, c0, seed=1), rnd(B, H, H, c1, seed=2)
+    w, b = rnd(N, c0 + c1, 1, 1, seed=3, scale=(c0 + c1) ** -0.5), rnd(N, seed=4, scale=0.1)
+    ref = F.conv2d(nchw(torch.cat([x0, x1], -1)), w.float(), b.float())
+    for w8 in (1, 0):
+        ops.set_tuning("gemm_big", 2); ops.set_tuning("gemm_w8", w8)
+        try:
+            out = ops.conv2d(x0, ops.pack_conv_weight(w), b, x1=x1, taps=1)
+        finally:
+            ops.set_tuning("gemm_big", 1); ops.set_tuning("gemm_w8", 1)
+        assert rel_l2(nchw(out), ref) < 1e-3
+
+
 @pytest.mark.parametrize("M,K,N", [(256, 64, 160), (1000, 320, 480), (8192, 1280, 1280), (513, 128, 1280)])
 def test_linear_big_tile_kernel_160(M, K, N):
     """256x160 variant of the 8-wave kernel (the 1280-wide layers at 16x16), forced on small and ragged shapes"""
