@@ -168,16 +168,16 @@ def extra_rollout(unet, vae, dev, B=80, n=8, epochs=4, iters=2):
              (torch.randn(1, 4, 64, 64, generator=g) * 0.18).half().to(dev).repeat(B, 1, 1, 1))
     ms, out = _timed_ms(lambda: ppo.train_iteration(tr, None, sch, unet, vae, batch, None, cfg=3.0, num_inference_steps=n, ppo_epochs=epochs,
                                                     prompt_embeds=pe, negative_prompt_embeds=ne), iters)
-    fl = unet.flops(2 * B) * n + vae.flops(8) * (2 * B / 8)
-    tf = fl / (ms * 1e-3) / 1e12
+    fl_ref = unet.flops(2 * B) * n + vae.flops(8) * (2 * B / 8)
     # executed: the B rows are copies of one sample (repeat_random_sample, data_processing.py:65-83): steps 0 and 1 of the rollout run the
-    # denoiser for one row, the teacher latent is decoded once
+    # denoiser for one row, the teacher latent is decoded once (~25 % of the reference loop's FLOPs are not run at all)
     fl_exec = unet.flops_executed(B, 2) * (n - 2) + unet.flops_executed(1, 2) * 2 + vae.flops(8) * (B / 8) + vae.flops(1)
+    tf = fl_exec / (ms * 1e-3) / 1e12
     return {"workload": f"configs[4] on 1 GPU: PPO rollout B={B}, {n} steps, CFG 3, 2x{B} VAE decodes, image_psnr reward, {epochs} PPO epochs",
             "ms_per_iteration": ms, "trajectories_per_s": B / (ms * 1e-3), "tflops": tf, "frac_of_mfma_peak": tf / PEAK_F16_TFLOPS,
-            "tflops_executed": fl_exec / (ms * 1e-3) / 1e12, "frac_of_mfma_peak_executed": fl_exec / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS,
-            "note": "tflops = algorithmic FLOPs of the reference's loop (B full trajectories, 2B decodes) / time; _executed = what the "
-                    "identical-input sharing actually runs",
+            "tflops_reference_equivalent": fl_ref / (ms * 1e-3) / 1e12,
+            "note": "tflops / frac_of_mfma_peak count the FLOPs the hardware EXECUTED (identical-input sharing: steps 0-1 for one row, one teacher decode); "
+                    "tflops_reference_equivalent = the reference loop's algorithmic FLOPs (B full trajectories, 2B decodes) / the same time",
             "loss_finite": bool(torch.isfinite(torch.as_tensor(float(out["loss"]))))}
 
 
@@ -252,10 +252,15 @@ def dry_run(args):
         all_b = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(all_b, torch.tensor([lo, hi], dtype=torch.int64))
         bounds = [b.tolist() for b in all_b]
+    # what main() runs OUTSIDE the timed region on this launch: the cpu_baseline leg and the sub-record extras are N = 1 only (same conditions as in
+    # main()), so an 8-GPU timed region and its barriers see nothing but the sampling loop
+    side_work = {"cpu_baseline": world == 1 and not args.no_cpu_baseline, "extras": world == 1 and bool(args.extras),
+                 "ceilings": world == 1 and bool(args.ceilings), "kernel_profile_pass": rank == 0 and bool(args.profile_kernels)}
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
                           "images": B * world * args.steps, "max_elapsed_s": elapsed, "shards": bounds,
-                          "local_rank_env": os.environ.get("LOCAL_RANK"), "cuda_initialised": torch.cuda.is_initialized()}))
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "cuda_initialised": torch.cuda.is_initialized(),
+                          "side_work_after_timed_region": side_work}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -403,13 +408,16 @@ def main():
                 traffic, traffic_src = json.load(open(f))["traffic_bytes_per_forward"], os.path.relpath(f, ROOT)
             except Exception:
                 pass
+    # flops_per_launch is the ALGORITHMIC count of the reference graph (32 x 803.27 GFLOP): `achieved` / `frac` are quoted on it as the
+    # contract asks.  The executor evaluates the layers in front of the first cross attention once for both CFG halves (same latents and
+    # timestep: bit-identical results, tests/test_unet_gpu.py), so ~2.5 % fewer FLOPs are actually executed: `achieved_executed` / `frac_executed`
+    # are what the matrix pipes did.
+    flops_exec = unet.flops_executed(B, 2) if args.guidance > 1 else flops_fwd
+    achieved_exec = flops_exec / (fwd_ms * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F16_TFLOPS,
+                "achieved_executed": achieved_exec, "frac_executed": achieved_exec / PEAK_F16_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
-                "launch_ms": fwd_ms, "flops_per_launch": flops_fwd,
-                # flops_per_launch is the ALGORITHMIC count of the reference graph (32 x 803.27 GFLOP).  The executor evaluates
-                # the layers in front of the first cross attention once for both CFG halves (same latents and timestep: bit-identical
-                # results, tests/test_unet_gpu.py), so slightly fewer FLOPs are actually executed:
-                "flops_executed_per_launch": unet.flops_executed(B, 2) if args.guidance > 1 else flops_fwd}
+                "launch_ms": fwd_ms, "flops_per_launch": flops_fwd, "flops_executed_per_launch": flops_exec}
 
     kernels = None
     if args.profile_kernels and rank == 0:

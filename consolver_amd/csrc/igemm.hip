@@ -118,14 +118,19 @@ struct LinearRows {
 
 // RSPLIT > 1 trades column groups for row groups: the patch holds 64 / RSPLIT rows x ALL the wave's columns, so a pass stores
 // 320-byte (not 160-byte) row segments: whole 128-byte lines instead of halves of them.
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
+// F32 (round 3, layers with a time-embedding or residual add): the patch holds acc + bias in FP32 and the adds happen in fp32 on the way out, so the
+// output is rounded to fp16 ONCE (torch's fp16 graph -- and this epilogue until round 2 -- rounds the conv output and then the sum); half as many rows
+// per pass.  Every residual-adding layer of the UNet paid that extra 2^-11 on the residual stream.
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32>
+__device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
+    static_assert(!(F32 && GEGLU), "the GEGLU layers add nothing after the product");
     constexpr int RT = MT / RSPLIT;                           // 16-row tiles per pass
     constexpr int COLS = GEGLU ? GROUP * 8 : GROUP * 16;      // output columns per pass
-    constexpr int ROWB = (COLS + 8) * 2;                      // padded LDS row (bytes, multiple of 16)
-    constexpr int CH = COLS / 8;                              // 16-byte chunks per row
+    constexpr int ROWB = F32 ? COLS * 4 + 16 : (COLS + 8) * 2;   // padded LDS row (bytes, multiple of 16)
+    static_assert(RT * 16 * ROWB <= 11264, "the wave's patch");
+    constexpr int CH = COLS / 8;                              // 8-column chunks per row (16 bytes of output each)
     const int g4 = (lane >> 4) * 4, i16 = lane & 15;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
     // GroupNorm statistics of the output (p.gn_stats): the final fp16 values of a pass are written back into the patch, and lanes
@@ -137,7 +142,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     for (int grp = 0; grp < NT / GROUP; ++grp)
 #pragma unroll
     for (int rh = 0; rh < RSPLIT; ++rh) {
-        // ---- phase 1: registers -> LDS patch [RT * 16 rows][COLS] fp16 -----------------------------------
+        // ---- phase 1: registers -> LDS patch [RT * 16 rows][COLS] fp16 (F32: fp32) --------------------------
 #pragma unroll
         for (int ii = 0; ii < GROUP; ii += (GEGLU ? 2 : 1)) {
             const int i = grp * GROUP + ii;
@@ -156,18 +161,23 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
             for (int jj = 0; jj < RT; ++jj) {
                 const int j = rh * RT + jj;
-                f16x4 o;
-                if (GEGLU) {
-                    const f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
-                    const f32x2 g01 = gelu_erf2(f32x2{gt[0] + bg[0], gt[1] + bg[1]}), g23 = gelu_erf2(f32x2{gt[2] + bg[2], gt[3] + bg[3]});
-                    o[0] = (f16)((acc[i][j][0] + bv[0]) * g01[0]); o[1] = (f16)((acc[i][j][1] + bv[1]) * g01[1]);
-                    o[2] = (f16)((acc[i][j][2] + bv[2]) * g23[0]); o[3] = (f16)((acc[i][j][3] + bv[3]) * g23[1]);
+                if constexpr (F32) {
+                    const f32x4 o = {acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    *reinterpret_cast<f32x4*>(wave_lds + (jj * 16 + i16) * ROWB + (ii * 16 + g4) * 4) = o;
                 } else {
+                    f16x4 o;
+                    if (GEGLU) {
+                        const f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
+                        const f32x2 g01 = gelu_erf2(f32x2{gt[0] + bg[0], gt[1] + bg[1]}), g23 = gelu_erf2(f32x2{gt[2] + bg[2], gt[3] + bg[3]});
+                        o[0] = (f16)((acc[i][j][0] + bv[0]) * g01[0]); o[1] = (f16)((acc[i][j][1] + bv[1]) * g01[1]);
+                        o[2] = (f16)((acc[i][j][2] + bv[2]) * g23[0]); o[3] = (f16)((acc[i][j][3] + bv[3]) * g23[1]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] + bv[r]);
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] + bv[r]);
+                    }
+                    const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
+                    *reinterpret_cast<f16x4*>(wave_lds + (jj * 16 + i16) * ROWB + col * 2) = o;
                 }
-                const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
-                *reinterpret_cast<f16x4*>(wave_lds + (jj * 16 + i16) * ROWB + col * 2) = o;
             }
         }
         // ---- phase 2: LDS patch -> global, 16 bytes per lane, + temb + residual ------------------------------
@@ -178,13 +188,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
             const int idx = lane + 64 * k;
             const int row = idx / CH, ch = idx - row * CH;
             const int m = rows(rh * RT * 16 + row);
-            const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
-            if (m >= 0) {
-                const size_t off = (size_t)m * Nout + n0 + ch * 8;
-                if (p.temb || p.res) {
-                    float f[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) f[r] = (float)v[r];
+            if constexpr (F32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32), v1 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32 + 16);
+                f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m >= 0) {
+                    const size_t off = (size_t)m * Nout + n0 + ch * 8;
+                    float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     if (p.temb) {
                         const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n0 + ch * 8);
 #pragma unroll
@@ -195,16 +204,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
                         for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
                     }
-                    f16x8 o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
-                    if (stats) *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = o;
-                } else {
-                    *reinterpret_cast<f16x8*>(p.out + off) = v;
                 }
-            } else if (stats) {
-                *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                // (the fp16 values of chunk ch go where the fp32 values of chunks ch / 2 were: every lane has read its fp32 slot by now -- LDS operations of a
+                //  wave execute in order -- and later iterations read other rows)
+                if (stats) *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = o;
+            } else {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
+                if (m >= 0) {
+                    const size_t off = (size_t)m * Nout + n0 + ch * 8;
+                    *reinterpret_cast<f16x8*>(p.out + off) = v;
+                } else if (stats) {
+                    *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
         }
         if (stats && lane < COLS / 4) {
@@ -224,6 +238,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
         if (slot >= 0)
             *reinterpret_cast<f32x4*>(p.gn_stats + ((size_t)slot * (p.N >> 1) + (n_base >> 1) + lane * 2) * 2) = f32x4{st_sum[0], st_sq[0], st_sum[1], st_sq[1]};
     }
+}
+
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
+    if constexpr (!GEGLU) {
+        if (p.temb || p.res) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
+    }
+    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false>(p, acc, rows, n_base, lane, wave_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1026,7 +1048,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");
     __builtin_amdgcn_s_barrier();                                               // the stage buffers become the epilogue patches
-    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
@@ -1244,7 +1266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     }
     trace_stamp(p.debug, blockIdx.x, 2);
     if (p.debug & 1) { if (acc[0][0][0] == 123.456f) p.out[0] = (f16)1; return; }
-    if (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, (BNX == 320 ? 2 : 1)>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     trace_stamp(p.debug, blockIdx.x, 3);
     if (p.debug & 16384) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p.debug, blockIdx.x, 4); }

@@ -274,6 +274,9 @@ struct Run {
     const f16* ctx = nullptr; f16* kv = nullptr; const f16* tproj = nullptr; int tstride = 0;
     float* gn_ws = nullptr;
     float* sk_ws = nullptr; size_t sk_bytes = 0;
+    // execution variant, snapshotted from the process-wide knobs ONCE per forward (cs_set_tuning from another thread cannot change a forward in
+    // flight; the workspace query passes its variants here instead of writing the globals)
+    int v_gn_fuse = 1, v_xattn_fused = 1, v_cfg_share = 1;
 
     f16* alloc(size_t halfs) {
         void* p = u->arena.alloc(halfs * sizeof(f16));
@@ -292,7 +295,7 @@ struct Run {
         if (it != stat_of.end()) { u->arena.free(it->second.stats); stat_of.erase(it); }
         u->arena.free(const_cast<void*>(p));
     }
-    bool stats_fusable(int HW, int C) const { return g_tune_gn_fuse != 0 && HW % 64 == 0 && C % 2 == 0; }
+    bool stats_fusable(int HW, int C) const { return v_gn_fuse != 0 && HW % 64 == 0 && C % 2 == 0; }
     // partial-sum buffer for a [Bt][HW][C] tensor about to be produced (Bt samples); registered under `out` by the caller
     float* alloc_stats(int Bt, int HW, int C) { return (float*)alloc((size_t)Bt * (HW / 64) * C * 2); }      // C/2 pairs x 2 floats = C floats = 2C halfs
 
@@ -357,7 +360,7 @@ struct Run {
     }
 
     // fused LN2 -> to_q -> cross attention -> to_out + residual (xattn.hip); h_in may equal h_out
-    bool xattn_fusable(const Xformer& X, int HW) const { return g_tune_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
+    bool xattn_fusable(const Xformer& X, int HW) const { return v_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
     void xattn_fused(const Xformer& X, const f16* h_in, f16* h_out, const f16* kvl, int HW) {
         XattnArgs a{};
         a.h = h_in; a.out = h_out; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
@@ -503,8 +506,11 @@ f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, 
     return g;
 }
 
+struct Variant { int gn_fuse, xattn_fused, cfg_share; };
+static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share}; }
+
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
-                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s) {
+                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant()) {
     const CsUNetConfig& c = u->cfg;
     const int B = n_lat * dup;
     const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B) + sk_ws_bytes(u, B);
@@ -512,6 +518,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->arena.reset(ws + kvb + gnb, dry ? 0 : ws_bytes - kvb - gnb, dry);
     u->dry_flops = 0;
     Run R{u, s, dry, B};
+    R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
     const int c0 = c.block_out_channels[0], td = 4 * c0, L = c.ctx_len;
@@ -542,7 +549,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     int ch = c0;
     skips.push_back({h, ch});
     // CFG dual batch with one timestep: the first resnet and the first transformer block up to its cross attention are shared
-    const bool share = (dup == 2 && nt == 1 && c.down_has_attn[0] && g_tune_cfg_share != 0 && !u->down_res[0].empty());
+    const bool share = (dup == 2 && nt == 1 && c.down_has_attn[0] && R.v_cfg_share != 0 && !u->down_res[0].empty());
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->down_res[i].size(); ++j) {
             f16* r;
@@ -701,20 +708,15 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
     // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
     size_t peak = 0;
-    const int knob_share = g_tune_cfg_share, knob_fused = g_tune_xattn_fused, knob_gn = g_tune_gn_fuse;
     for (int variant = 0; variant < 4; ++variant) {
-        const int fused = variant & 1;
-        g_tune_xattn_fused = fused; g_tune_gn_fuse = variant >> 1;
-        run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr);
+        const Variant v{variant >> 1, variant & 1, 1};
+        run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
         peak = std::max(peak, u->arena.peak);
         if (batch % 2 == 0) {
-            g_tune_cfg_share = 1;
-            run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+            run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
             peak = std::max(peak, u->arena.peak);
-            g_tune_cfg_share = knob_share;
         }
     }
-    g_tune_xattn_fused = knob_fused; g_tune_gn_fuse = knob_gn;
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;
 }
 

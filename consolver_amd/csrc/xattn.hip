@@ -19,7 +19,7 @@
 //   phase 3' K fragments of the NEXT head are loaded while the current head computes;
 //   phase 4  out = XT Wo^T as phase 1, + bias -> fp16 -> LDS patch -> + residual (h re-read, L2-hot) -> fp16 -> 640-byte row stores.
 //
-// LDS: XT 80 KB + two weight stages 80 KB = 160 KB exactly (one workgroup per CU); the V tile reuses the stages, the epilogue patch XT.
+// LDS: XT 80 KB + two weight stages 80 KB = 160 KB exactly (one workgroup per CU); the V tile reuses the stages, the epilogue patch XT and the first 2 KB of stage 0.
 // The arithmetic class (fp16 storage points, fp32 accumulation) is the unfused path's; the softmax here subtracts the true row maximum
 // (the unfused kernel's max-free steady state is for thousands of keys).
 #include "ops.h"
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
     // ---------------- phase 4: out = O Wo^T + bias + h ------------------------------------------------------------------------------------
     if (!(p.debug & 2)) gemm_320<false>(p.wo, smem, w, lane, wm, wn, acc);     // ends with a barrier: XT becomes the epilogue patch
     {
-        char* const patch = smem;                    // [128 rows][PROW]
+        char* const patch = smem;                    // [128 rows][PROW] = 83,968 B: all of XT and the first 2 KB of weight stage 0 (free: gemm_320 ends with a barrier)
+        static_assert(TM * PROW <= XT_BYTES + WST, "the epilogue patch may reach into weight stage 0 but not beyond it");
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int n = wn * 80 + i * 16 + 4 * g;

@@ -139,11 +139,11 @@ class HipFluxTransformer2DModel:
     def _rope_dev(self, txt_ids, img_ids):
         # same id objects as the previous call (the edit loop passes them unchanged every step): no D2H copy, no sync
         last = getattr(self, "_rope_last", None)
-        if last is not None and last[0] is txt_ids and last[1] is img_ids and not (
-                torch.is_tensor(img_ids) and img_ids._version != last[2]):
+        ver = lambda t: t._version if torch.is_tensor(t) else 0                     # (in-place edits of either id tensor invalidate the cache)
+        if last is not None and last[0] is txt_ids and last[1] is img_ids and last[2] == (ver(txt_ids), ver(img_ids)):
             return last[3]
         out = self._rope_from_values(txt_ids, img_ids)
-        self._rope_last = (txt_ids, img_ids, img_ids._version if torch.is_tensor(img_ids) else 0, out)
+        self._rope_last = (txt_ids, img_ids, (ver(txt_ids), ver(img_ids)), out)
         return out
 
     def _rope_from_values(self, txt_ids, img_ids):

@@ -222,10 +222,9 @@ def train_iteration(trainer, text_encoder, noise_scheduler, unet, vae, batch, to
     import random
     from .ppo_data import repeat_random_sample
     rng = rng or random
-    text, noise, tch = repeat_random_sample(batch)
+    text, noise, tch, i = repeat_random_sample(batch, return_index=True)
     B = noise.shape[0]
     if prompt_embeds is not None and prompt_embeds.shape[0] == B:       # cached embeddings follow the item that was picked
-        i = repeat_random_sample.last_index
         prompt_embeds = prompt_embeds[i:i + 1].expand(B, -1, -1).contiguous()
         if negative_prompt_embeds is not None:
             negative_prompt_embeds = negative_prompt_embeds[i:i + 1].expand(B, -1, -1).contiguous()

@@ -66,11 +66,13 @@ def collate_teacher_pairs(samples):
     return list(text), torch.stack(noise), torch.stack(latent)
 
 
-def repeat_random_sample(batch):
+def repeat_random_sample(batch, index=None, return_index=False):
     """data_processing.py:65-83: one random sample of the batch repeated batch-size times (the trainer rolls out B
-    trajectories of the SAME prompt/noise so that the advantage normalisation compares policies, not prompts)."""
+    trajectories of the SAME prompt/noise so that the advantage normalisation compares policies, not prompts).
+    ``index``: use this item instead of drawing one; ``return_index=True``: also return the item that was used, for callers that
+    hold per-item side data (cached prompt embeddings) -- no hidden state is kept between calls."""
     text, noise, tch = batch
     B = noise.shape[0]
-    i = random.randint(0, B - 1)
-    repeat_random_sample.last_index = i          # callers holding per-item side data (cached prompt embeddings) pick the same item
-    return [text[i]] * B, noise[i:i + 1].repeat(B, *[1] * (noise.dim() - 1)), tch[i:i + 1].repeat(B, *[1] * (tch.dim() - 1))
+    i = random.randint(0, B - 1) if index is None else int(index)
+    out = ([text[i]] * B, noise[i:i + 1].repeat(B, *[1] * (noise.dim() - 1)), tch[i:i + 1].repeat(B, *[1] * (tch.dim() - 1)))
+    return out + (i,) if return_index else out

@@ -52,6 +52,13 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
     try:
         shared_steps = 0
         if identical_inputs and native and batch_size > 1:
+            # the caller's statement is checked once per rollout (one small device->host read): a batch that is NOT B copies of one sample
+            # would otherwise get steps 0-1 computed from row 0 and broadcast, silently
+            same = bool(torch.equal(noise[:1].expand_as(noise), noise)) and bool(torch.equal(prompt_embeds[:1].expand(batch_size, -1, -1), prompt_embeds[:batch_size]))
+            if do_cfg:
+                same = same and bool(torch.equal(prompt_embeds[batch_size:batch_size + 1].expand(batch_size, -1, -1), prompt_embeds[batch_size:]))
+            if not same:
+                raise ValueError("identical_inputs=True, but the rows of noise / prompt embeddings are not copies of one sample")
             shared_steps = 2 if scheduler.config.scaler_dim == 0 else 1
             pe1 = (torch.cat([prompt_embeds[:1], prompt_embeds[batch_size:batch_size + 1]]) if do_cfg else prompt_embeds[:1]).contiguous()
         for i, t in enumerate(scheduler.timesteps):

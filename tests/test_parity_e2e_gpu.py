@@ -14,6 +14,8 @@ HIP path cannot be closer to "the reference" than that arithmetic class is to it
 
 The torch-fp16 graph is a comparator, not an oracle: nothing is checked against it except the error budget.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -153,7 +155,7 @@ def test_forward_error_budget_and_class_attribution():
     print(f"  worst HIP / torch-fp16 ratio = {worst_ratio:.3f}")
     for r in rows:
         assert r["hip_executor"] <= 1.25 * r["torch_fp16"], r
-        assert r["hip_executor"] < 2.2e-3, r                      # absolute bound: measured 1.57e-3 .. 1.66e-3, + 30 %
+        assert r["hip_executor"] < 2.05e-3, r                     # absolute bound: measured 1.49e-3 .. 1.56e-3 (round 3: one rounding per residual layer), + 30 %
 
 
 def _scheduler(seed=11):
@@ -175,12 +177,15 @@ def _oracle_sched(w):
     return s
 
 
-@pytest.mark.timeout(3000)
-def test_eight_step_trajectory_full_unet_vs_oracle():
-    """(a): configs[1]'s 8 steps (trailing grid 999..124, CFG 3, order 4) on the full UNet at B = 2."""
+# B = 16 is configs[1]'s own batch: ~10 minutes of fp32 CPU oracle on the GPU box, so it runs on request (CS_PARITY_B16=1; its output is kept
+# under profiles/) and the default suite keeps B = 2 -- the per-sample arithmetic does not depend on the batch.
+@pytest.mark.timeout(6000)
+@pytest.mark.parametrize("B", [2] + ([16] if os.environ.get("CS_PARITY_B16") == "1" else []))
+def test_eight_step_trajectory_full_unet_vs_oracle(B):
+    """(a): configs[1]'s 8 steps (trailing grid 999..124, CFG 3, order 4) on the full UNet."""
     u, sd = build_full()
     sch, w = _scheduler()
-    B, n, g = 2, 8, 3.0
+    n, g = 8, 3.0
     idx = np.random.default_rng(6).integers(0, 11, size=(n, B, 3))
     pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
     noise = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(43)).half()
@@ -225,7 +230,7 @@ def test_eight_step_trajectory_full_unet_vs_oracle():
         x16 = so.round_f16(s_16.step(ec, t, x16, idx[i], cond_dtype="f16")["prev_sample"])
         rows.append(dict(step=i, t=t, fwd_hip=rel_l2(e_hip, e_or), fwd_t16=rel_l2(e_16, e_or),
                          drift_hip=rel_l2(hip_traj[i], xo), drift_t16=rel_l2(x16, xo)))
-    print("\n8-step trajectory, full SD1.5 UNet, B=2, CFG 3 (relative L2 vs the fp32 oracle):")
+    print(f"\n8-step trajectory, full SD1.5 UNet, B={B}, CFG 3 (relative L2 vs the fp32 oracle):")
     for r in rows:
         print("  step {step} t={t:3d}  forward: hip {fwd_hip:.3e} torch-fp16 {fwd_t16:.3e}   "
               "latents: hip {drift_hip:.3e} torch-fp16 {drift_t16:.3e}".format(**r))
@@ -235,7 +240,7 @@ def test_eight_step_trajectory_full_unet_vs_oracle():
         assert r["fwd_hip"] <= 1.25 * r["fwd_t16"], r
     # end-to-end: no worse than the fp16 arithmetic class of the reference pipeline (+25 %), and an absolute bound
     assert final_hip <= 1.25 * final_t16 + 2e-4, (final_hip, final_t16)
-    assert final_hip < 1.9e-3, final_hip                          # measured 1.45e-3 (torch-fp16 class: 1.95e-3), + 30 %
+    assert final_hip < 1.82e-3, final_hip                         # measured 1.40e-3 at B = 2 (torch-fp16 class: 1.94e-3), + 30 %
 
 
 def test_two_rollouts_with_different_prompts_do_not_share_kv():
