@@ -27,6 +27,7 @@
 extern int g_tune_halo;
 extern int g_tune_conv_lw;
 extern int g_tune_gemm_w8;
+extern int g_tune_gemm_lw;
 extern int g_tune_debug;
 extern int g_tune_biggemm;
 
@@ -914,6 +915,148 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Linear / 1x1 layers whose 256 x 320 tiling cannot fill the chip (the 1280-wide layers at 16 x 16: M = 8192 -> 128 tiles), in the loader-wave form of
+// conv3_lw_kernel (round 3): tile 256 rows x 160 columns, waves 0-3 multiply (wave tile 64 x 160: 80 MFMAs, 28 hand-counted LDS reads, no vector ALU per
+// step), waves 4-7 stage [256 + 160 rows][64 k] = 52 KB per step into one of THREE stage buffers (156 of the CU's 160 KB), two steps ahead.
+// With ONE tile per CU and the operands in L2 / Infinity Cache this form is latency-free; as a general GEMM it loses to the 256 x 320 tile (twice the
+// L2 -> LDS bytes per FLOP: profiles/r03_ab_gemm_lw.txt), so launch_igemm_impl uses it only where gemm_big_kernel<false, 160> used to run.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
+    constexpr int BMX = 256, BN = 160, NT = BN / 16, MT = 4, NWB = 3;
+    constexpr int A_BYTES = BMX * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int APL = BMX / 8 / 4, WPL = BN / 8 / 4;        // DMA pieces (8 rows x 128 B) per loader wave and stage: 8 + 5
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int tm, tn;
+    if (p.gm > 1) {
+        const int tiles_m = p.nblk / p.tiles_n;
+        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
+        const int gsz = min(p.gm, tiles_m - band * p.gm);
+        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
+    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+    const int m_blk = tm * BMX, n_blk = tn * BN;
+    const int KT = p.KT;
+
+    if (w >= 4) {
+        // =============================== loader waves ===============================
+        const int l = w - 4;
+        const int pch = lane & 7, lr = lane >> 3;
+        // rows past M are clamped to the last row: their products are computed and never stored
+        const f16* asrc0[APL]; const f16* asrc1[APL]; const f16* wsrc[WPL];
+#pragma unroll
+        for (int j = 0; j < APL; ++j) {
+            const int r = 8 * (l + 4 * j) + lr;
+            const long m = min(m_blk + r, p.M - 1);
+            const int ch = (pch ^ ((r >> 1) & 7)) * 8;
+            asrc0[j] = p.a0 + m * p.c0 + ch;
+            asrc1[j] = p.c1 ? p.a1 + m * p.c1 + ch : asrc0[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) {
+            const int r = 8 * (l + 4 * j) + lr;
+            wsrc[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 7)) * 8;
+        }
+        auto issue = [&](int kt, int buf) {
+            char* st = smem + buf * STAGE;
+            const int cc = kt * BK;
+            if (cc < p.c0) {
+#pragma unroll
+                for (int j = 0; j < APL; ++j) glds16(asrc0[j] + cc, st + (l + 4 * j) * 1024);
+            } else {
+#pragma unroll
+                for (int j = 0; j < APL; ++j) glds16(asrc1[j] + (cc - p.c0), st + (l + 4 * j) * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) glds16(wsrc[j] + cc, st + A_BYTES + (l + 4 * j) * 1024);
+        };
+        // two stages ahead (an activation tile may come from the Infinity Cache: ~1 us under load, more than one step).  Stage g + 2 goes out behind
+        // K(g - 1) into buffer (g + 2) % 3 = (g - 1) % 3 -- the compute waves wait lgkmcnt(0) in front of their barrier here, so those reads are complete --
+        // and K(g) needs stage g + 1: everything but the 13 pieces just issued.
+        issue(0, 0);
+        if (KT > 1) issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                           // K(-1): stages 0 and 1 have landed
+        int wb2 = 2;
+        static_assert(APL + WPL == 13, "counted wait below");
+        for (int g = 0; g < KT; ++g) {
+            if (g + 2 < KT) { issue(g + 2, wb2); asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // K(g)
+            wb2 = wb2 == NWB - 1 ? 0 : wb2 + 1;
+        }
+        __builtin_amdgcn_s_barrier();                                           // E: the stage buffers become the epilogue patches
+        return;
+    }
+
+    // =============================== compute waves ===============================
+    const int wm = w;
+    const int gq = lane >> 4, swz = (lane >> 1) & 7;
+    const unsigned sbase = lds_addr(smem);
+    const unsigned wfrag0 = (lane & 15) * 128 + (gq ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + gq) ^ swz) * 16;
+    unsigned SA[NWB][2], SW[NWB][2];                            // fragment bases: rows 64 wm .. of stage buffer b / weight tile 0 of stage buffer b; k half 0 / 1
+#pragma unroll
+    for (int b3 = 0; b3 < NWB; ++b3) {
+        SA[b3][0] = sbase + b3 * STAGE + wm * 8192 + wfrag0; SA[b3][1] = sbase + b3 * STAGE + wm * 8192 + wfrag1;
+        SW[b3][0] = sbase + b3 * STAGE + A_BYTES + wfrag0; SW[b3][1] = sbase + b3 * STAGE + A_BYTES + wfrag1;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NQ = 2 * NT, RS = NT / 2, LA = RS - 1, QB = NQ - LA;
+    static_assert(LA == 4 && MT == 4, "read schedule of conv3_lw_kernel (lw_wait_count)");
+    f16x8 fa[2][MT], fw[RS];
+
+    __builtin_amdgcn_s_barrier();                                               // K(-1)
+    // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0
+    lds_read<0>(fw[0], SW[0][0]); lds_read<0>(fa[0][0], SA[0][0]); lds_read<2048>(fa[0][1], SA[0][0]);
+    lds_read<2048>(fw[1], SW[0][0]); lds_read<2 * 2048>(fa[0][2], SA[0][0]); lds_read<3 * 2048>(fa[0][3], SA[0][0]);
+    lds_read<2 * 2048>(fw[2], SW[0][0]); lds_read<3 * 2048>(fw[3], SW[0][0]);
+    auto step = [&](auto b_tag) {                                               // stage in buffer B, the next one in (B + 1) % 3
+        constexpr int B = decltype(b_tag)::value, BNX = (B + 1) % NWB;
+        static_for<NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
+            if constexpr (q == QB) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's reads of stage g are complete: its buffer is refilled right behind the barrier
+                __builtin_amdgcn_s_barrier();                                    // K(g): stage g + 1 has landed
+            }
+            {
+                constexpr int r = q + LA;
+                if constexpr (r < NT) lds_read<r * 2048>(fw[r % RS], SW[B][0]);
+                else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], SW[B][1]);
+                else lds_read<(r - NQ) * 2048>(fw[r % RS], SW[BNX][0]);
+            }
+            if constexpr (q < MT) lds_read<q * 2048>(fa[1][q], SA[B][1]);
+            if constexpr (q == QB || q == QB + 1) {
+                constexpr int j0 = (q - QB) * 2;
+                lds_read<j0 * 2048>(fa[0][j0], SA[BNX][0]); lds_read<(j0 + 1) * 2048>(fa[0][j0 + 1], SA[BNX][0]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) mfma_inplace(acc[i][j], fw[q % RS], fa[ks][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    for (int kt = 0;;) {
+        step(std::integral_constant<int, 0>{}); if (++kt == KT) break;
+        step(std::integral_constant<int, 1>{}); if (++kt == KT) break;
+        step(std::integral_constant<int, 2>{}); if (++kt == KT) break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");          // (the last step's look-ahead reads; the last MFMAs' results)
+    __builtin_amdgcn_s_barrier();                                               // E
+    igemm_epilogue<false, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 256 x 320 x 64 GEMM tile (8 waves, all multiplying, wave tile 64 x 160, two 72 KB stages) with the k loop written like conv3_lw_kernel's
 // (round 3).  gemm_big_kernel's loop carried ~180 vector-ALU instructions per wave and step -- the zero-page select and the 64-bit address of its
 // nine LDS-DMA pieces -- plus hipcc's own waits (lgkmcnt(0) at the loop head).  Here:
@@ -923,8 +1066,8 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 //   * piece schedule: behind barrier K(g) (item 16 of step g) buffer g & 1 is free (every wave has waited lgkmcnt(0) in front of the barrier):
 //     pieces 0..3 of stage g + 2 go out with items 16..19, pieces 4..8 with items 0..4 of step g + 1; vmcnt(0) in front of K(g + 1).
 // Activations / weights must be addressable with 32-bit byte offsets (M * K * 2 < 4 GiB), else the caller falls back to gemm_big_kernel.
-// Measured against it and removed (round 3, same-box A/Bs under profiles/): the loader-wave form on a 256 x 160 tile (r03_ab_gemm_lw.txt: bit-identical,
-// +20..40 % time on the K <= 2560 shapes -- twice the L2 -> LDS bytes per FLOP and that path is the bound) and the 256 x 320 tile on four 512-register waves
+// Measured against it (round 3, same-box A/Bs under profiles/): the loader-wave form on a 256 x 160 tile as a GENERAL GEMM (r03_ab_gemm_lw.txt: bit-identical,
+// +20..40 % time on the multi-round K <= 2560 shapes -- twice the L2 -> LDS bytes per FLOP and that path is the bound; kept for the one-round shapes only) and the 256 x 320 tile on four 512-register waves
 // with the accumulators in AGPRs (r03_ab_gemm_w4.txt: bit-identical, +10..30 % -- half the waves for a store-bound epilogue, no k-loop gain).
 // ------------------------------------------------------------------------------------------------
 template <bool GEGLU>
@@ -1441,6 +1584,7 @@ int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output
 int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
 int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
+int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few 256 x 320 tiles) through gemm_lw_kernel (loader waves), 0: gemm_big_kernel<false, 160>
 int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
 int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
@@ -1619,6 +1763,17 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             if (!configured) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
+            }
+            if (g_tune_gemm_lw && !g_tune_debug) {                    // round 3: the loader-wave form (three 52 KB stages)
+                constexpr size_t lds_lw = 3 * (256 * BK * 2 + 160 * BK * 2);
+                static bool configured_lw = false;
+                if (!configured_lw) {
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lw));
+                    configured_lw = true;
+                }
+                hipLaunchKernelGGL(gemm_lw_kernel, dim3(p.nblk), dim3(512), lds_lw, s, p);
+                CS_CHECK_LAUNCH();
+                return CS_OK;
             }
             hipLaunchKernelGGL((gemm_big_kernel<false, 160>), dim3(p.nblk), dim3(512), lds, s, p);
             CS_CHECK_LAUNCH();

@@ -305,17 +305,20 @@ def test_conv1x1_over_concat_hand_scheduled_kernel():
         assert rel_l2(nchw(out), ref) < 1e-3
 
 
-@pytest.mark.parametrize("M,K,N", [(256, 64, 160), (1000, 320, 480), (8192, 1280, 1280), (513, 128, 1280)])
+@pytest.mark.parametrize("M,K,N", [(256, 64, 160), (1000, 320, 480), (8192, 1280, 1280), (513, 128, 1280), (1, 192, 160), (4097, 640, 640), (700, 1024, 480)])
 def test_linear_big_tile_kernel_160(M, K, N):
     """256x160 variant of the 8-wave kernel (the 1280-wide layers at 16x16), forced on small and ragged shapes"""
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.2), rnd(M, N, seed=4)
-    ops.set_tuning("gemm_big", 3)
-    try:
-        out = ops.linear(x, w, b, res=r)
-    finally:
-        ops.set_tuning("gemm_big", 1)
     ref = F.linear(x.float(), w.float(), b.float()) + r.float()
-    assert rel_l2(out.float(), ref) < 1.5e-3
+    outs = {}
+    for lw in (1, 0):                          # 1: gemm_lw_kernel (waves 0-3 multiply, 4-7 stage, three stage buffers), 0: the 8-wave 256 x 160 kernel
+        ops.set_tuning("gemm_big", 3); ops.set_tuning("gemm_lw", lw)
+        try:
+            outs[lw] = ops.linear(x, w, b, res=r)
+        finally:
+            ops.set_tuning("gemm_big", 1); ops.set_tuning("gemm_lw", 1)
+        assert rel_l2(outs[lw].float(), ref) < 1.5e-3
+    assert torch.equal(outs[1], outs[0])        # same k order, same epilogue
 
 
 @pytest.mark.parametrize("M,C", [(128, 64), (300, 320), (64, 1280)])

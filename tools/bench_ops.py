@@ -50,6 +50,7 @@ if which in ("all", "gemm"):
     lin(32768, 640, 1920, tag="qkv L1"); lin(32768, 640, 5120, geglu=True, tag="ff1 L1"); lin(32768, 2560, 640, res=True, tag="ff2 L1")
     lin(8192, 1280, 3840, tag="qkv L2"); lin(8192, 1280, 10240, geglu=True, tag="ff1 L2"); lin(8192, 5120, 1280, res=True, tag="ff2 L2")
     lin(2464, 768, 640, tag="cross kv")
+    lin(8192, 1280, 1280, res=True, tag="out/proj L2"); lin(32768, 640, 640, res=True, tag="out/proj L1"); lin(2048, 1280, 1280, res=True, tag="out/proj L3")
 if which in ("all", "conv"):
     conv(64, 320, 320, tag="L0"); conv(64, 640, 320, tag="L0 up"); conv(64, 960, 320, tag="L0 up")
     conv(32, 640, 640, tag="L1"); conv(32, 1280, 640, tag="L1 up"); conv(32, 1920, 640, tag="L1 up")

@@ -16,7 +16,7 @@ agg = collections.OrderedDict()
 for r in fw:
     name = r["Kernel_Name"]
     import re
-    mm = re.search(r"(conv3_halo_kernel<[^>]*>|gemm_big_kernel<[^>]*>|igemm_kernel<[^>]*>|splitk_reduce_kernel)", name)
+    mm = re.search(r"(conv3_lw_kernel<[^>]*>|conv3_halo_kernel<[^>]*>|gemm_w8_kernel<[^>]*>|gemm_big_kernel<[^>]*>|igemm_kernel<[^>]*>|splitk_reduce_kernel)", name)
     short = mm.group(1) if mm else re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", name)[:36]
     key = (short, r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""), r.get("Workgroup_Size_X", ""))
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
