@@ -125,12 +125,16 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
  *                cs_op_conv2d_gn, 0 always a separate statistics pass;
  *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 run on the loader-wave kernel (conv3_lw_kernel: waves 0-3 multiply,
- *                waves 4-7 stage), 0 the 8-wave halo kernels;
+ *                waves 4-7 stage), 2 the same without its immediate-offset (FAST) addressing, 0 the 8-wave halo kernels;
+ *   "gemm_w8":   1 (default) the 256x320 GEMM runs its hand-scheduled k loop (gemm_w8_kernel; needs 32-bit operand offsets), 0 the
+ *                compiler-scheduled gemm_big_kernel (bit-identical results);
+ *   "gemm_lw":   1 (default) layers served by the 256x160 GEMM tile run the loader-wave kernel (gemm_lw_kernel), 0 gemm_big_kernel<.,160>;
  *   "gemm_gm":   tile order of the 256-row GEMM kernel: -1 (default) bands of 4 tile rows when there are >= 12 tile columns, 0 / 1 row-major, n bands of n;
  *   "attn_prio" / "gemm2_prio": static wave priority experiments (attn_prio -1 = auto: head dim 128 only);
  *   "debug":     timing experiments only (results are wrong or the run is slowed): 1 skip the GEMM epilogue, 2 skip its k loop,
  *                4096 static priority in the GEMM kernel, 8192 + (n << 16) late start of every other CU by n x s_sleep(127),
- *                16384 per-workgroup stamps (cs_debug_trace_read), 32768 no staging inside the k loop, 65536 activations from the
+ *                16384 per-workgroup stamps (cs_debug_trace_read; gemm_big_kernel and the TRACE instantiation of
+ *                conv3_lw_kernel, tools/conv_lw_trace.py), 32768 no staging inside the k loop, 65536 activations from the
  *                zero page, 131072 the same k step staged every time; the halo conv kernel has its own bits (csrc/igemm.hip) */
 int cs_set_tuning(const char* key, int value);
 /* Timing experiments only: with cs_set_tuning("debug", 16384) every workgroup of the 256-row GEMM kernel records wall-clock stamps
