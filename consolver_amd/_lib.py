@@ -175,6 +175,7 @@ SYMBOLS = {
     "cs_op_group_norm_pre": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_debug_trace_read": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "cs_debug_attn_trace_read": (C.c_int, [C.c_void_p, C.c_size_t]),
     "cs_op_layer_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 

@@ -22,7 +22,9 @@
 #include <type_traits>
 
 int g_tune_attn_qt40 = 4;
-int g_tune_attn_prio = -1;     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
+int g_tune_attn_prio = -1;
+extern int g_tune_debug;
+int g_tune_attn_lw = 1;        // 1: head dim 40 self-attention (Nq % 256 == 0, Nk % 64 == 0) runs attn40_lw_kernel (loader waves + hand-placed stream), 0: attn_kernel     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
 
 namespace {
 
@@ -477,6 +479,386 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int row
     *reinterpret_cast<u32x4*>(p.out + (size_t)(b * p.Nq + qrow) * p.out_stride + h * DH + d) = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Head dim 40 self-attention with DEDICATED LOADER WAVES and a hand-placed instruction stream (round 3).
+// attn_kernel<f16, 40, 4> spends ~2000 SIMD cycles per 64-key tile and wave (45 % matrix-pipe busy): two waves per SIMD each run scores -> softmax -> P V
+// one after the other, the compiler waits out LDS latencies inside both MFMA phases, and all four waves meet at a barrier per tile.  The tile's work
+// is 56 MFMAs (896 matrix-pipe cycles) and ~1300 cycles of vector issue (MFMA 8, v_exp_f32 8, everything else 4: MI355X_MICROARCH.md), so what a SIMD can
+// do is bounded by the issue port, and only a stream that never stalls gets near it.  This kernel is conv3_lw_kernel's answer applied to attention:
+//   * 8 waves, one workgroup per CU: waves 0-3 (one per SIMD, 64 queries each) compute and never touch global memory inside the loop, waves 4-7 stage K / V
+//     tiles by LDS-DMA into a ring of NS stages (row stride 96 B for both: conflict-free ds_read_b128 and transposing reads; K's pad chunk is a copy of
+//     real data and meets zero Q columns, V's pad chunk is (1, 0, ..) -- the ones column that makes the P V product produce the softmax denominator);
+//   * the compute stream is software-pipelined over UNITS of 32 keys: slot n issues the 16 score MFMAs of unit n, the 32 exponentials + 16 conversions of
+//     unit n - 1 and the 12 P V MFMAs of unit n - 2 interleaved (three mutually independent strands, so nothing in a slot waits for anything in it), every
+//     operand fragment is read one slot ahead with immediate offsets and a hand-counted lgkmcnt; one barrier per 64-key tile, none of the waves waits at it
+//     for LDS;
+//   * the reference maximum of the softmax is the first tile's column maximum (as in attn_kernel's FAST path); a wave whose denominators come out non-finite
+//     redoes its 64 rows alone with a plain maxima-tracking loop straight from global memory (never seen on real inputs; tests force it).
+// Bit-identical to attn_kernel<f16, 40, 4> (same MFMA chains, same exponent arguments, same rounding, same accumulation order).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned g_attn_ones_chunk[4] = {0x00003c00u, 0u, 0u, 0u};     // fp16 (1, 0, 0, 0, 0, 0, 0, 0)
+
+typedef const __attribute__((address_space(1))) void* a40_gptr;
+typedef __attribute__((address_space(3))) void* a40_lptr;
+__device__ __forceinline__ void glds16a(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((a40_gptr)src, (a40_lptr)lds_wave_base, 16, 0, 0); }
+template <int OFF>
+__device__ __forceinline__ void a40_read_k(f16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF>
+__device__ __forceinline__ void a40_read_vt(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int N>
+__device__ __forceinline__ void a40_wait(f16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int N>
+__device__ __forceinline__ void a40_wait2(u32x2& a, u32x2& b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+__device__ __forceinline__ void a40_mfma(f32x4& c, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void a40_mfma_c(f32x4& d, const f16x8& a, const f16x8& b, const f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void a40_mfma_z(f32x4& d, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b)); }
+// (macros: a vector element cannot bind to a reference)
+#define a40_exp(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define a40_cvt(d, a, b) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+template <int N, class F, int... I>
+__device__ __forceinline__ void a40_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void a40_for(F&& f) { a40_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+// timing experiments only (cs_set_tuning("debug", 16384) selects the TRACE instantiation; cs_debug_attn_trace_read): per workgroup
+// [0] shader cycles of compute wave 0 over the steady loop, [1] 100 MHz ticks over the same, [2] tiles in it, [3] loader wave 4's cycles in vmcnt waits, [4] at barriers
+#define A40_TRACE_SLOTS 4096
+#define A40_TRACE_W 12
+__device__ unsigned long long g_a40_trace[A40_TRACE_SLOTS * A40_TRACE_W];
+
+// DBG (TRACE builds only, results wrong): 1 steady loop without the exponentials / conversions, 2 without the MFMAs
+template <int NS, bool TRACE = false, int DBG = 0, int PAD = 0>
+__global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
+    unsigned long long te0 = 0;
+    if (TRACE) te0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int DH = 40, RS = 96, KB = 64 * RS, ST = 2 * KB;                  // stage = K tile (6 KB) | V tile (6 KB)
+    static_assert(NS >= 5 && NS <= 12, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    int lin;
+    {
+        const int n = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = n >> 3, r = n & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int qblk = lin % p.nqb, hb = lin / p.nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int ntiles = p.Nk >> 6;
+    const f16* kbase = p.k + (size_t)b * p.Nk * p.k_stride + h * DH;
+    const f16* vbase = p.v + (size_t)b * p.Nk * p.v_stride + h * DH;
+
+    // (no LDS initialisation: every byte of a stage is written by its twelve DMA pieces -- the pad chunk of a K row is a copy of real data, the pad chunk of a V row
+    //  is the ones chunk -- and fragments are only multiplied out of stages that have landed)
+    if (w >= 4) {
+        // =============================== loader waves: pieces l, l + 4, l + 8 of the 12 KiB stage ===============================
+        const int l = w - 4;
+        const char* src[3]; size_t step[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = l + 4 * j, kv = q >= 6 ? 1 : 0, pq = q - 6 * kv;
+            const int off = pq * 1024 + lane * 16, row = off / RS, ch = (off - row * RS) >> 4;
+            if (!kv) { src[j] = reinterpret_cast<const char*>(kbase + (size_t)row * p.k_stride + (ch == 5 ? 0 : ch) * 8); step[j] = (size_t)64 * p.k_stride * 2; }
+            else if (ch < 5) { src[j] = reinterpret_cast<const char*>(vbase + (size_t)row * p.v_stride + ch * 8); step[j] = (size_t)64 * p.v_stride * 2; }
+            else { src[j] = reinterpret_cast<const char*>(g_attn_ones_chunk); step[j] = 0; }
+        }
+        auto issue = [&](int tile, int stage) {
+            const int t = tile < ntiles ? tile : ntiles - 1;                   // past the end: the last tile again, into a free stage (keeps the counts uniform)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) glds16a(src[j] + (size_t)t * step[j], smem + stage * ST + (l + 4 * j) * 1024);
+        };
+        for (int t = 0; t <= NS - 3; ++t) issue(t, t);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (NS - 4)) : "memory");     // tiles 0 and 1 have landed
+        __builtin_amdgcn_s_barrier();                                            // B(-1)
+        int st = NS - 2;
+        unsigned long long tl_wait = 0, tl_bar = 0;
+        for (int j = 0; j < ntiles; ++j) {
+            issue(j - 2 + NS, st);                                               // into the stage of tile j - 2, released at B(j - 1)
+            st = st + 1 == NS ? 0 : st + 1;
+            unsigned long long s0 = 0, s1 = 0;
+            if (TRACE) s0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (NS - 4)) : "memory"); // tile j + 2 has landed (first read behind B(j))
+            if (TRACE) s1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();                                        // B(j)
+            if (TRACE) { const unsigned long long s2 = __builtin_readcyclecounter(); tl_wait += s1 - s0; tl_bar += s2 - s1; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TRACE && l == 0 && lane == 0 && blockIdx.x < A40_TRACE_SLOTS) { g_a40_trace[blockIdx.x * A40_TRACE_W + 3] = tl_wait; g_a40_trace[blockIdx.x * A40_TRACE_W + 4] = tl_bar; }
+        return;
+    }
+
+    // =============================== compute waves ===============================
+    const int q0 = qblk * 256 + w * 64;
+    f16x8 qf[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int qrow = q0 + t * 16 + i16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int d = ks * 32 + 8 * g;
+            u32x4 v = {0, 0, 0, 0};
+            if (d < DH) {
+                v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2<f16>(El<f16>::tof((u16)(v[e] & 0xffff)) * p.c, El<f16>::tof((u16)(v[e] >> 16)) * p.c);
+            }
+            qf[t][ks] = as_frag<f16>(v);
+        }
+    }
+    f32x4 o_acc[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o_acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sc[2][2][4];                  // [unit parity][key tile of the unit][query tile]
+    u32x4 pfw[2][4];                    // [unit parity][query tile]: P fragment (B operand) as four packed words
+    f32x4 negm[4];
+    float m_run[4];
+    f16x8 kf[4];                        // K fragments of the NEXT unit: (kt', ks) = (0,0) (0,1) (1,0) (1,1)
+    u32x2 vlo[3], vhi[3];               // V^T fragments (a = 0..2) of the unit whose P V product runs in the next slot
+    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned kl = sbase + i16 * RS + g * 16;
+    const unsigned vl = sbase + KB + (4 * g + (i16 >> 2)) * RS + (i16 & 3) * 8;
+
+    // One slot.  PAR = parity of unit n; reads: K fragments of unit n + 1 (half 1 - PAR of its tile, address ka), V^T fragments of unit n - 1 (half 1 - PAR, va).
+    // MFMA groups in order: S(kt'0, ks0) | P V a0 | S(kt'0, ks1) | P V a1 | S(kt'1, ks0) | P V a2 | S(kt'1, ks1); behind group j the fragment it used is re-read
+    // for the next slot, so in front of a group (10 - its own events) reads are younger than its operand: lgkmcnt 9 (K, one event) / 8 (V^T, two events).
+    // E strand: items k = (t, kt') of 4 exponentials + 2 conversions, the conversions one item behind their exponentials, spread evenly behind the 28 MFMAs.
+    auto slot = [&](auto par_tag, auto s_tag, auto e_tag, auto p_tag, unsigned ka, unsigned va) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr int DO_S = decltype(s_tag)::value;          // 0 none, 1 accumulate from -m_ref, 2 from zero (first tile: raw scores)
+        constexpr bool DO_E = decltype(e_tag)::value, DO_P = decltype(p_tag)::value;
+        constexpr int H2 = 1 - PAR;                          // half (of its tile) of units n + 1 and n - 1
+        auto e_instr = [&](auto q_tag) {
+            constexpr int Q = decltype(q_tag)::value;
+            if constexpr (DO_E) {
+                constexpr int SP = 1 - PAR;                  // scores of unit n - 1, P fragment of unit n - 1
+                if constexpr (Q < 4) a40_exp(sc[SP][0][0][Q]);
+                else {
+                    constexpr int QQ = Q - 4, K = 1 + QQ / 6, R = QQ % 6;
+                    if constexpr (K <= 7) {
+                        if constexpr (R < 4) a40_exp(sc[SP][K % 2][K / 2][R]);
+                        else { constexpr int KP = K - 1, C = R - 4; a40_cvt(pfw[SP][KP / 2][2 * (KP % 2) + C], sc[SP][KP % 2][KP / 2][2 * C], sc[SP][KP % 2][KP / 2][2 * C + 1]); }
+                    } else { constexpr int C = QQ - 42; a40_cvt(pfw[SP][3][2 + C], sc[SP][1][3][2 * C], sc[SP][1][3][2 * C + 1]); }
+                }
+            }
+        };
+        auto filler = [&](auto m_tag) {                       // E instructions behind MFMA m of the slot
+            constexpr int M = decltype(m_tag)::value;
+            constexpr int LO = 48 * M / 28, HI = 48 * (M + 1) / 28;
+            a40_for<HI - LO>([&](auto i_tag) { e_instr(std::integral_constant<int, LO + decltype(i_tag)::value>{}); });
+        };
+        auto s_group = [&](auto j_tag) {                      // j = kt' * 2 + ks
+            constexpr int J = decltype(j_tag)::value, KT = J / 2, KS = J % 2, G = 2 * J;
+            a40_wait<9>(kf[J]);
+            a40_for<4>([&](auto t_tag) {
+                constexpr int T = decltype(t_tag)::value;
+                if constexpr (DO_S == 1) { if constexpr (KS == 0) a40_mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]); else a40_mfma(sc[PAR][KT][T], kf[J], qf[T][1]); }
+                if constexpr (DO_S == 2) { if constexpr (KS == 0) a40_mfma_z(sc[PAR][KT][T], kf[J], qf[T][0]); else a40_mfma(sc[PAR][KT][T], kf[J], qf[T][1]); }
+                filler(std::integral_constant<int, G * 4 + T>{});
+            });
+            a40_read_k<(2 * H2 + KT) * 16 * RS + KS * 64>(kf[J], ka);
+        };
+        auto p_group = [&](auto a_tag) {
+            constexpr int A = decltype(a_tag)::value, G = 2 * A + 1;
+            a40_wait2<8>(vlo[A], vhi[A]);
+            if constexpr (DO_P) {
+                const f16x8 vf = as_frag<f16>(u32x4{vlo[A][0], vlo[A][1], vhi[A][0], vhi[A][1]});
+                a40_for<4>([&](auto t_tag) {
+                    constexpr int T = decltype(t_tag)::value;
+                    a40_mfma(o_acc[A][T], vf, as_frag<f16>(pfw[PAR][T]));
+                    filler(std::integral_constant<int, G * 4 + T>{});
+                });
+            } else {
+                a40_for<4>([&](auto t_tag) { filler(std::integral_constant<int, G * 4 + decltype(t_tag)::value>{}); });
+            }
+            a40_read_vt<32 * H2 * RS + A * 32>(vlo[A], va);
+            a40_read_vt<32 * H2 * RS + A * 32 + 16 * RS>(vhi[A], va);
+        };
+        s_group(std::integral_constant<int, 0>{}); p_group(std::integral_constant<int, 0>{});
+        s_group(std::integral_constant<int, 1>{}); p_group(std::integral_constant<int, 1>{});
+        s_group(std::integral_constant<int, 2>{}); p_group(std::integral_constant<int, 2>{});
+        s_group(std::integral_constant<int, 3>{});
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using BT = std::true_type; using BF = std::false_type;
+
+    // stage byte offsets of tiles i - 1, i, i + 1
+    int so_prev = 0, so_cur = 0, so_next = ST;
+    __builtin_amdgcn_s_barrier();                                                // B(-1): tiles 0 and 1 are in LDS
+    unsigned long long te1 = 0;
+    if (TRACE) te1 = __builtin_amdgcn_s_memrealtime();
+    // ---- tile 0: raw scores of both halves, the reference maximum, the exponentials of unit 0 --------------------------------------------
+    // (the priming slot only issues the reads of a slot, so that every counted wait below sees the steady-state history; its waits are trivially true)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kf[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { vlo[a] = u32x2{0, 0}; vhi[a] = u32x2{0, 0}; }
+    slot(I1{}, I0{}, BF{}, BF{}, kl, vl);                                         // reads K(unit 0)
+    slot(I0{}, I2{}, BF{}, BF{}, kl, vl);                                         // S(0) raw; reads K(unit 1)
+    slot(I1{}, I2{}, BF{}, BF{}, kl + so_next, vl);                               // S(1) raw; reads K(unit 2) of tile 1, V^T(unit 0)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                            // the MFMA results are read by compiler-scheduled code next (it cannot see the producers)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float mx = sc[0][0][t][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[u][kt][t][r]);
+        mx = xor32_max(xor16_max(mx));
+        m_run[t] = mx;
+        negm[t] = f32x4{-mx, -mx, -mx, -mx};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[u][kt][t][r] -= mx;
+    }
+    asm volatile("s_nop 7" ::: "memory");
+    {   // E(0) alone (in the steady state it runs inside slot 1)
+        a40_for<48>([&](auto q_tag) {
+            constexpr int Q = decltype(q_tag)::value;
+            if constexpr (Q < 4) a40_exp(sc[0][0][0][Q]);
+            else {
+                constexpr int QQ = Q - 4, K = 1 + QQ / 6, R = QQ % 6;
+                if constexpr (K <= 7) {
+                    if constexpr (R < 4) a40_exp(sc[0][K % 2][K / 2][R]);
+                    else { constexpr int KP = K - 1, C = R - 4; a40_cvt(pfw[0][KP / 2][2 * (KP % 2) + C], sc[0][KP % 2][KP / 2][2 * C], sc[0][KP % 2][KP / 2][2 * C + 1]); }
+                } else { constexpr int C = QQ - 42; a40_cvt(pfw[0][3][2 + C], sc[0][1][3][2 * C], sc[0][1][3][2 * C + 1]); }
+            }
+        });
+    }
+    __builtin_amdgcn_s_barrier();                                                // B(0)
+    unsigned long long tc0 = 0, tr0 = 0;
+    if (TRACE) { tc0 = __builtin_readcyclecounter(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long te3 = 0;
+    // ---- tiles 1 .. ntiles - 1 ----------------------------------------------------------------------------------------------------------
+    // Placement of the hand-written loop in the instruction stream: without this anchor the product instantiation ran 1.06-1.09 ms where the TRACE instantiation of the
+    // same source ran 0.92 (loop head at 60 vs 12 mod 64 bytes); behind a 64-byte alignment every padding 0..15 words measured 0.84-0.87 ms
+    // (profiles/r03_attn_pad_sweep.txt; MI355X_MICROARCH.md "code-placement sensitivity of hand-written streams").
+    asm volatile(".p2align 6\n\t.rept %0\n\ts_nop 0\n\t.endr" :: "n"(PAD));
+    for (int i = 1; i < ntiles; ++i) {
+        so_prev = so_cur; so_cur = so_next; so_next = so_next + ST == NS * ST ? 0 : so_next + ST;
+        using SE = std::integral_constant<bool, DBG != 1>; using SP = std::integral_constant<bool, DBG != 2>; using SS = std::integral_constant<int, DBG != 2 ? 1 : 0>;
+        slot(I0{}, SS{}, SE{}, SP{}, kl + so_cur, vl + so_prev);                  // unit 2i:     reads K(2i + 1) of tile i,     V^T(2i - 1) of tile i - 1
+        slot(I1{}, SS{}, SE{}, SP{}, kl + so_next, vl + so_cur);                  // unit 2i + 1: reads K(2i + 2) of tile i + 1, V^T(2i)     of tile i
+        __builtin_amdgcn_s_barrier();                                            // B(i): every read of tile i - 1 has been waited for
+    }
+    if (TRACE && w == 0 && lane == 0 && blockIdx.x < A40_TRACE_SLOTS) {
+        g_a40_trace[blockIdx.x * A40_TRACE_W + 0] = __builtin_readcyclecounter() - tc0;
+        g_a40_trace[blockIdx.x * A40_TRACE_W + 1] = __builtin_amdgcn_s_memrealtime() - tr0;
+        g_a40_trace[blockIdx.x * A40_TRACE_W + 2] = (unsigned long long)(ntiles - 1);
+    }
+    if (TRACE) te3 = __builtin_amdgcn_s_memrealtime();
+    // ---- drain: E(N - 1) | P V(N - 2), then P V(N - 1) -----------------------------------------------------------------------------------
+    slot(I0{}, I0{}, BT{}, BT{}, kl + so_cur, vl + so_cur);                       // reads V^T(N - 1) of the last tile
+    slot(I1{}, I0{}, BF{}, BT{}, kl + so_cur, vl + so_cur);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the slot's own trailing reads land before their registers are reused
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(kf[j]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(vlo[a]), "+v"(vhi[a]));
+
+    // ---- denominators; a wave with a non-finite one redoes its rows with running maxima, straight from global memory --------------------
+    float lsum[4];
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { lsum[t] = __shfl(o_acc[2][t][0], 32 + i16, 64); bad |= !(lsum[t] < INFINITY); }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o_acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m_run[t] = 0.f;
+        for (int tile = 0; tile < ntiles; ++tile) {
+            f32x4 s2[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f16* krow = kbase + (size_t)(tile * 64 + kt * 16 + i16) * p.k_stride;
+                const u32x4 k0 = *reinterpret_cast<const u32x4*>(krow + 8 * g);
+                u32x4 k1 = {0, 0, 0, 0};
+                if (g == 0) k1 = *reinterpret_cast<const u32x4*>(krow + 32);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float nm = tile == 0 ? 0.f : -m_run[t];
+                    s2[kt][t] = El<f16>::mfma(as_frag<f16>(k0), qf[t][0], f32x4{nm, nm, nm, nm});
+                    s2[kt][t] = El<f16>::mfma(as_frag<f16>(k1), qf[t][1], s2[kt][t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float mx = s2[0][t][0];
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s2[kt][t][r]);
+                mx = xor32_max(xor16_max(mx));
+                const float delta = tile == 0 ? mx : fmaxf(mx, 0.f);
+                m_run[t] = tile == 0 ? delta : m_run[t] + delta;
+                if (tile != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) o_acc[a][t] *= alpha;
+                }
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s2[kt][t][r] = __builtin_amdgcn_exp2f(s2[kt][t][r] - delta);
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int d = a * 16 + i16;
+                    union { u16 e[8]; u32x4 v; } vv;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = tile * 64 + 32 * t2 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+                        vv.e[j] = d < DH ? *reinterpret_cast<const u16*>(vbase + (size_t)key * p.v_stride + d) : (d == DH ? (u16)0x3c00 : (u16)0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const u32x4 f = {pack2<f16>(s2[2 * t2][t][0], s2[2 * t2][t][1]), pack2<f16>(s2[2 * t2][t][2], s2[2 * t2][t][3]),
+                                         pack2<f16>(s2[2 * t2 + 1][t][0], s2[2 * t2 + 1][t][1]), pack2<f16>(s2[2 * t2 + 1][t][2], s2[2 * t2 + 1][t][3])};
+                        o_acc[a][t] = El<f16>::mfma(as_frag<f16>(vv.v), as_frag<f16>(f), o_acc[a][t]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lsum[t] = __shfl(o_acc[2][t][0], 32 + i16, 64);
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float inv = 1.0f / lsum[t];
+        const int qrow = q0 + t * 16 + i16;
+        f16* orow = p.out + (size_t)(b * p.Nq + qrow) * p.out_stride + h * DH;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int d = a * 16 + 4 * g;
+            if (d + 4 <= DH) {
+                const u32x2 o = {pack2<f16>(o_acc[a][t][0] * inv, o_acc[a][t][1] * inv), pack2<f16>(o_acc[a][t][2] * inv, o_acc[a][t][3] * inv)};
+                *reinterpret_cast<u32x2*>(orow + d) = o;
+            }
+        }
+    }
+    if (TRACE && w == 0 && lane == 0 && blockIdx.x < A40_TRACE_SLOTS) {
+        // 100 MHz ticks: entry -> B(-1) | B(-1) -> B(0) | loop end -> exit; entry and exit stamps; hardware id (CU, SE, XCC)
+        unsigned long long* tr = g_a40_trace + blockIdx.x * A40_TRACE_W;
+        const unsigned long long te4 = __builtin_amdgcn_s_memrealtime();
+        tr[5] = te1 - te0; tr[6] = tr0 - te1; tr[7] = te4 - te3; tr[8] = te0; tr[9] = te4;
+        tr[10] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) | __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+    }
+}
+
 constexpr int ATTN_SLOTS = 512;      // 256 CUs x 2 resident workgroups (launch_bounds(256, 2), <= 72 KB of LDS each)
 
 template <typename T, int DH, int QT, bool CAUSAL = false, bool BIAS = false>
@@ -532,7 +914,34 @@ int launch_attn(AttnParams p, int B, hipStream_t s, void* split_ws = nullptr, si
     return CS_OK;
 }
 
+constexpr int A40_NS = 6;
+int launch_attn40_lw(AttnParams p, int B, hipStream_t s) {
+    constexpr size_t lds = (size_t)A40_NS * 12288;
+    const bool trace = (g_tune_debug & 16384) != 0;
+    auto kfn = trace ? ((g_tune_debug & 1) ? attn40_lw_kernel<A40_NS, true, 1> : (g_tune_debug & 2) ? attn40_lw_kernel<A40_NS, true, 2> : attn40_lw_kernel<A40_NS, true>)
+                     : attn40_lw_kernel<A40_NS, false>;
+    static bool configured = false;
+    if (!configured) {
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    p.nqb = p.Nq / 256; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
+    const long total = (long)p.nqb * p.H * B;
+    if (total > 0x7fffffffL) CS_FAIL(CS_E_SHAPE, "attention: too many workgroups");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)total), dim3(512), lds, s, p);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
 }  // namespace
+
+int debug_attn_trace_read(void* dst, size_t bytes) {
+    if (bytes > sizeof(unsigned long long) * A40_TRACE_SLOTS * A40_TRACE_W) bytes = sizeof(unsigned long long) * A40_TRACE_SLOTS * A40_TRACE_W;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_a40_trace), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? CS_OK : CS_E_HIP;
+}
 
 size_t attention_split_workspace_bytes(int B, int H, int Nq, int Nk, int dh) {
     if (dh != 128) return 0;
@@ -566,6 +975,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
         case 40: {
             const int qt = g_tune_attn_qt40;      // cs_set_tuning("attn_qt40", 2 | 4): query tiles per wave at head dim 40
             if (a.dtype == CS_BF16) CS_FAIL(CS_E_UNSUPPORTED, "attention: bf16 is built for head dim 128 only");
+            if (g_tune_attn_lw && qt == 4 && a.Nq % 256 == 0 && a.Nk % 64 == 0) return launch_attn40_lw(p, a.B, s);
             if (qt == 4) return launch_attn<f16, 40, 4>(p, a.B, s);
             return launch_attn<f16, 40, 2>(p, a.B, s);
         }

@@ -7,10 +7,12 @@ extern int g_tune_halo;
 extern int g_tune_conv_lw;
 extern int g_tune_gemm_w8;
 extern int g_tune_gemm_lw;
+extern int g_tune_attn_lw;
 extern int g_tune_debug;
 extern int g_tune_gemm_gm;
 extern int g_tune_gn_fuse;
 int debug_trace_read(void* dst, size_t bytes);
+int debug_attn_trace_read(void* dst, size_t bytes);
 extern int g_tune_cfg_share;
 extern int g_tune_xattn_fused;
 extern int g_tune_conv_sched;
@@ -25,6 +27,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_lw")) { g_tune_gemm_lw = value; return CS_OK; }
+    if (!strcmp(key, "attn_lw")) { g_tune_attn_lw = value; return CS_OK; }
     if (!strcmp(key, "gemm_w8")) { g_tune_gemm_w8 = value; return CS_OK; }
     if (!strcmp(key, "conv_lw")) { g_tune_conv_lw = value; return CS_OK; }
     if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
@@ -198,5 +201,6 @@ int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* o
 }
 
 int cs_debug_trace_read(void* dst_host, size_t bytes) { return debug_trace_read(dst_host, bytes); }
+int cs_debug_attn_trace_read(void* dst_host, size_t bytes) { return debug_attn_trace_read(dst_host, bytes); }
 
 }  // extern "C"

@@ -141,6 +141,9 @@ int cs_set_tuning(const char* key, int value);
  * (100 MHz) -- [slot][6] uint64: entry, first stage landed, k loop done, epilogue issued, stores drained, (XCC id << 32 | HW_ID) --
  * which this call copies to host memory (at most 8192 slots; tools/gemm_timeline.py). */
 int cs_debug_trace_read(void* dst_host, size_t bytes);
+/* the same for attn40_lw_kernel (head dim 40 self-attention): [slot][6] uint64: shader cycles of compute wave 0 over the steady loop, 100 MHz ticks
+ * over the same, tiles in it, loader wave 4's cycles in its DMA waits, at the tile barriers, unused (at most 4096 slots; tools/attn_lw_trace.py). */
+int cs_debug_attn_trace_read(void* dst_host, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -1,116 +1,170 @@
-// Probe (round 3, review item 7): the softmax exponentials of the head-dim-40 attention tile beside its MFMAs.  P is rounded to fp16 for the P V product
-// anyway, so is a PACKED fp16 exp2 (two values per issue slot) cheaper than v_exp_f32 per value?
-//   per 64-key tile and wave (64 queries): 56 x v_mfma_f32_16x16x32_f16 and 64 exponentials per lane, then 32 v_cvt_pk_f16_f32.
-//   variant 0: MFMAs only                                 (floor)
-//   variant 1: v_exp_f32 x 64 + v_cvt_pk_f16_f32 x 32      (what attn_kernel issues)
-//   variant 2: v_cvt_pk_f16_f32 x 32 first, then per PAIR: magic-number round (v_pk_add_f16 x 2), fraction (v_pk_add_f16), degree-3 polynomial
-//              (v_pk_fma_f16 x 3), exponent insertion (v_pk_lshlrev_b16 + v_pk_add_u16): 8 packed instructions per two values
-//   variant 3: v_exp_f16 x 64 on the converted halves (one value per instruction, fp16 transcendental) + the conversions
-// Two workgroups of four waves per CU (two waves per SIMD, like attn_kernel) and one (one wave per SIMD).
-// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probe/bin/exp_rate tools/probe/exp_rate.hip
+// Probe (round 3, review item 7 and the design question behind attn40_lw_kernel): what do the softmax exponentials of the head-dim-40 attention tile cost
+// beside its MFMAs, by WHERE they are issued?  One slot = the work of 32 keys x 64 queries of one wave: 28 x v_mfma_f32_16x16x32_f16 (16 score + 12 P V),
+// 32 x v_exp_f32 + 16 x v_cvt_pk_f16_f32, every instruction an asm volatile with real data flow (scores -> exp -> cvt -> B operand of the P V MFMAs of a later
+// slot, as in the kernel), no LDS traffic.  (The first version of this probe kept its exponent arguments loop-invariant and hipcc hoisted 60 of the 64
+// exponentials out of the loop: its numbers were withdrawn.)
+//   mode 0: MFMAs only                      mode 1: exponentials + conversions only
+//   mode 2: interleaved, one or two VALU instructions behind every MFMA (attn40_lw_kernel's first stream)
+//   mode 3: blocked: 28 MFMAs, then the 48 VALU instructions
+//   mode 4: blocked, waves 4-7 run the VALU block FIRST: SIMD partners in anti-phase (two waves per SIMD only)
+//   mode 5: packed-fp16 polynomial exp2 in the interleaved stream (8 packed instructions per two values; numerically unusable)
+// waves per SIMD: 1 (256-thread workgroup, one per CU) or 2 (512 threads); one s_barrier per two slots in every mode.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/probe/bin/exp_rate tools/probe/exp_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <utility>
 typedef _Float16 f16;
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef f16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int VAR>
-__global__ __launch_bounds__(256, 2) void exp_kernel(int tiles, float* sink, unsigned long long* cyc, float seed) {
+__device__ __forceinline__ void mfma_ip(f32x4& c, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void mfma_c(f32x4& d, const f16x8& a, const f16x8& b, const f32x4& c) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
+#define p_exp(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
+#define p_cvt(d, a, b) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+template <int N, class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+template <int MODE, int WPS>
+__global__ __launch_bounds__(WPS * 256) void slot_kernel(int slots2, float* sink, unsigned long long* cyc) {
     const int lane = threadIdx.x & 63;
-    f32x4 acc[14];
-    f16x8 a, b;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f16x8 qf[4][2], kf[4], vf[3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = (f16)(((lane * 7 + i * 13) % 31 - 15) * 0.03f); b[i] = (f16)(((lane * 11 + i * 5) % 29 - 14) * 0.02f); }
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int i = 0; i < 14; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s[64];
+        for (int t = 0; t < 4; ++t) { qf[t][0][i] = (f16)(((lane * 7 + i * 13 + t) % 31 - 15) * 0.02f); qf[t][1][i] = (f16)(((lane * 5 + i * 3 + t) % 29 - 14) * 0.02f); }
 #pragma unroll
-    for (int i = 0; i < 64; ++i) s[i] = -0.01f * (float)((lane + i * 3) % 97) * seed;
-    unsigned long long t0 = 0;
-    __syncthreads();
-    if (lane == 0) t0 = __builtin_readcyclecounter();
-    float keep = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        // score MFMAs (32), then the softmax work, then the P V MFMAs (24) -- the order of attn_kernel's tile
+        for (int j = 0; j < 4; ++j) kf[j][i] = (f16)(((lane * 11 + i * 5 + j) % 29 - 14) * 0.03f);
 #pragma unroll
-        for (int m = 0; m < 32; ++m) acc[m % 14] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[m % 14], 0, 0, 0);
-        if (VAR == 1) {
-            unsigned pk[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const float e0 = __builtin_amdgcn_exp2f(s[2 * i]), e1 = __builtin_amdgcn_exp2f(s[2 * i + 1]);
-                union { h2 h; unsigned u; } c; c.h = h2{(f16)e0, (f16)e1}; pk[i] = c.u;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { union { unsigned u[4]; f16x8 v; } c; c.u[0] = pk[4 * i]; c.u[1] = pk[4 * i + 1]; c.u[2] = pk[4 * i + 2]; c.u[3] = pk[4 * i + 3]; if (i == (t & 7)) b = c.v; }
-        } else if (VAR == 2) {
-            unsigned pk[32];
-            const h2 magic = {(f16)1536.f, (f16)1536.f}, c3 = {(f16)0.0555f, (f16)0.0555f}, c2 = {(f16)0.2402f, (f16)0.2402f}, c1 = {(f16)0.6931f, (f16)0.6931f},
-                     one = {(f16)1.f, (f16)1.f};
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const h2 x = {(f16)s[2 * i], (f16)s[2 * i + 1]};                 // v_cvt_pk_f16_f32 (rtz form in hardware; the probe only counts issue slots)
-                const h2 tt = x + magic;                                          // round to nearest integer in the low mantissa bits
-                const h2 n = tt - magic;
-                const h2 f = x - n;
-                h2 p = c3 * f + c2; p = p * f + c1; p = p * f + one;              // 2^f on [-0.5, 0.5], three v_pk_fma_f16
-                union { h2 h; unsigned u; } pu, tu; pu.h = p; tu.h = tt;
-                pk[i] = pu.u + ((tu.u << 10) & 0xfc00fc00u);                      // exponent insertion: v_pk_lshlrev_b16 + v_and + v_pk_add_u16 (and folded here)
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { union { unsigned u[4]; f16x8 v; } c; c.u[0] = pk[4 * i]; c.u[1] = pk[4 * i + 1]; c.u[2] = pk[4 * i + 2]; c.u[3] = pk[4 * i + 3]; if (i == (t & 7)) b = c.v; }
-        } else if (VAR == 3) {
-            unsigned pk[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const f16 e0 = __builtin_amdgcn_exp2f((float)(f16)s[2 * i]) > 0 ? (f16)0 : (f16)0;   // placeholder so that the variant compiles without a f16 exp builtin
-                (void)e0;
-                f16 h0 = (f16)s[2 * i], h1 = (f16)s[2 * i + 1];
-                asm volatile("v_exp_f16 %0, %0" : "+v"(h0));
-                asm volatile("v_exp_f16 %0, %0" : "+v"(h1));
-                union { h2 h; unsigned u; } c; c.h = h2{h0, h1}; pk[i] = c.u;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { union { unsigned u[4]; f16x8 v; } c; c.u[0] = pk[4 * i]; c.u[1] = pk[4 * i + 1]; c.u[2] = pk[4 * i + 2]; c.u[3] = pk[4 * i + 3]; if (i == (t & 7)) b = c.v; }
-        }
-#pragma unroll
-        for (int m = 0; m < 24; ++m) acc[m % 14] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[m % 14], 0, 0, 0);
-        // keep the scores data dependent on the loop so nothing is hoisted
-#pragma unroll
-        for (int i = 0; i < 64; i += 16) s[i] += acc[0][0] * 1e-30f;
+        for (int a = 0; a < 3; ++a) vf[a][i] = (f16)(((lane * 3 + i * 7 + a) % 23 - 11) * 0.03f);
     }
-    if (lane == 0 && (threadIdx.x >> 6) == 0) cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
+    f32x4 sc[2][2][4], o[3][4], negm[4];
+    u32x4 pfw[2][4];
 #pragma unroll
-    for (int i = 0; i < 14; ++i) keep += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (keep == 123.456f) sink[threadIdx.x] = keep;
+    for (int t = 0; t < 4; ++t) {
+        negm[t] = f32x4{-1.f, -1.f, -1.f, -1.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) o[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { sc[u][0][t] = f32x4{-1.f, -2.f, -3.f, -4.f}; sc[u][1][t] = f32x4{-1.5f, -2.5f, -3.5f, -0.5f}; pfw[u][t] = u32x4{0x3c003c00u, 0x38003800u, 0x34003400u, 0x30003000u}; }
+    }
+    // E instruction Q (0..47) of the slot whose scores are sc[SP] and whose P fragment is pfw[SP]: items (t, kt') of 4 exp + 2 cvt, conversions one item behind
+    auto e_instr = [&](auto sp_tag, auto q_tag) {
+        constexpr int SP = decltype(sp_tag)::value, Q = decltype(q_tag)::value;
+        (void)sc; (void)pfw;                                  // (named outside the discarded branches: clang decides a generic lambda's implicit captures there)
+        if constexpr (MODE == 5) {
+            // packed-fp16 polynomial: per item (4 values = 2 pairs): cvt x2, then per pair 8 packed instructions; issued as 6 "instructions" of this list = 18 / 6 = 3 each
+            constexpr int K = Q / 6, R = Q % 6;
+            if constexpr (R < 2) {
+                unsigned x; p_cvt(x, sc[SP][K % 2][K / 2][2 * R], sc[SP][K % 2][K / 2][2 * R + 1]);
+                unsigned tt, n, f, pp;
+                asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(tt) : "v"(x), "v"(0x66006600u));
+                asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(n) : "v"(tt), "v"(0x66006600u));
+                asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(f) : "v"(x), "v"(n));
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(pp) : "v"(f), "v"(0x2b1b2b1bu), "v"(0x33b033b0u));
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(pp) : "v"(pp), "v"(f), "v"(0x398c398cu));
+                asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(pp) : "v"(pp), "v"(f), "v"(0x3c003c00u));
+                asm volatile("v_pk_lshlrev_b16 %0, 10, %1" : "=v"(tt) : "v"(tt));
+                asm volatile("v_pk_add_u16 %0, %1, %2" : "=v"(pfw[SP][K / 2][2 * (K % 2) + R]) : "v"(pp), "v"(tt));
+            }
+        } else {
+            if constexpr (Q < 4) p_exp(sc[SP][0][0][Q]);
+            else {
+                constexpr int QQ = Q - 4, K = 1 + QQ / 6, R = QQ % 6;
+                if constexpr (K <= 7) {
+                    if constexpr (R < 4) p_exp(sc[SP][K % 2][K / 2][R]);
+                    else { constexpr int KP = K - 1, C = R - 4; p_cvt(pfw[SP][KP / 2][2 * (KP % 2) + C], sc[SP][KP % 2][KP / 2][2 * C], sc[SP][KP % 2][KP / 2][2 * C + 1]); }
+                } else { constexpr int C = QQ - 42; p_cvt(pfw[SP][3][2 + C], sc[SP][1][3][2 * C], sc[SP][1][3][2 * C + 1]); }
+            }
+        }
+    };
+    auto mfma_m = [&](auto par_tag, auto m_tag) {          // MFMA m (0..27) of a slot of parity PAR, in the kernel's group order S | PV | S | PV | S | PV | S
+        constexpr int PAR = decltype(par_tag)::value, M = decltype(m_tag)::value, G = M / 4, T = M % 4;
+        if constexpr (G % 2 == 0) {
+            constexpr int J = G / 2, KT = J / 2, KS = J % 2;
+            if constexpr (KS == 0) mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]); else mfma_ip(sc[PAR][KT][T], kf[J], qf[T][1]);
+        } else {
+            constexpr int A = G / 2;
+            union { u32x4 u; f16x8 f; } b; b.u = pfw[PAR][T];
+            mfma_ip(o[A][T], vf[A], b.f);
+        }
+    };
+    auto slot = [&](auto par_tag, auto vfirst_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool VFIRST = decltype(vfirst_tag)::value;
+        using SP = std::integral_constant<int, 1 - PAR>;
+        if constexpr (MODE == 0) sfor<28>([&](auto m) { mfma_m(par_tag, m); });
+        else if constexpr (MODE == 1) sfor<48>([&](auto q) { e_instr(SP{}, q); });
+        else if constexpr (MODE == 2 || MODE == 5) {
+            sfor<28>([&](auto m) {
+                constexpr int M = decltype(m)::value, LO = 48 * M / 28, HI = 48 * (M + 1) / 28;
+                mfma_m(par_tag, m);
+                sfor<HI - LO>([&](auto i) { e_instr(SP{}, std::integral_constant<int, LO + decltype(i)::value>{}); });
+            });
+        } else {
+            if constexpr (VFIRST) { sfor<48>([&](auto q) { e_instr(SP{}, q); }); sfor<28>([&](auto m) { mfma_m(par_tag, m); }); }
+            else { sfor<28>([&](auto m) { mfma_m(par_tag, m); }); sfor<48>([&](auto q) { e_instr(SP{}, q); }); }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    __syncthreads();
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (MODE == 4 && w >= 4) {
+        for (int s = 0; s < slots2; ++s) { slot(I0{}, std::true_type{}); slot(I1{}, std::true_type{}); __builtin_amdgcn_s_barrier(); }
+    } else {
+        for (int s = 0; s < slots2; ++s) { slot(I0{}, std::false_type{}); slot(I1{}, std::false_type{}); __builtin_amdgcn_s_barrier(); }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0 && w == 0) cyc[blockIdx.x] = t1 - t0;
+    float r = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) r += o[a][t][0] + o[a][t][1] + o[a][t][2] + o[a][t][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) r += sc[u][0][t][0] + sc[u][1][t][3] + (float)pfw[u][t][0];
+    }
+    if (r == 123.456f) sink[threadIdx.x] = r;
 }
 
-template <int VAR>
-static void run(float* sink, unsigned long long* cyc, int wgs, const char* tag) {
-    const int tiles = 4000;
-    hipLaunchKernelGGL(exp_kernel<VAR>, dim3(wgs), dim3(256), 0, 0, 100, sink, cyc, 1.0f);
+template <int MODE, int WPS>
+static void run(float* sink, unsigned long long* cyc, const char* tag) {
+    const int slots2 = 4000;
+    auto k = slot_kernel<MODE, WPS>;
+    hipLaunchKernelGGL(k, dim3(256), dim3(WPS * 256), 0, 0, 100, sink, cyc);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     (void)hipEventRecord(a);
-    hipLaunchKernelGGL(exp_kernel<VAR>, dim3(wgs), dim3(256), 0, 0, tiles, sink, cyc, 1.0f);
+    hipLaunchKernelGGL(k, dim3(256), dim3(WPS * 256), 0, 0, slots2, sink, cyc);
     (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b);
-    std::vector<unsigned long long> h(wgs);
-    (void)hipMemcpy(h.data(), cyc, wgs * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> h(256);
+    (void)hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
-    printf("%-64s %s : %7.1f cycles per tile and wave (56 MFMAs = 896) | %.3f ms\n", tag, wgs == 512 ? "two waves / SIMD" : "one wave / SIMD ", (double)h[wgs / 2] / tiles, ms);
+    const double per_tile = (double)h[128] / slots2;              // two slots = one 64-key tile of one wave
+    printf("%-72s %d wave(s) / SIMD : %7.1f cycles per 64-key tile and wave = %7.1f of SIMD time per wave-tile (56 MFMAs = 896) | clock %.2f GHz\n", tag, WPS, per_tile,
+           per_tile / WPS, (double)h[128] / (ms * 1e-3) / 1e9);
 }
 
 int main() {
     float* sink; unsigned long long* cyc;
-    (void)hipMalloc(&sink, 4096); (void)hipMalloc(&cyc, 512 * 8);
-    for (int wgs : {512, 256}) {
-        run<0>(sink, cyc, wgs, "0 MFMAs only");
-        run<1>(sink, cyc, wgs, "1 v_exp_f32 x 64 + v_cvt_pk_f16_f32 x 32 (attn_kernel)");
-        run<2>(sink, cyc, wgs, "2 packed-fp16 polynomial exp2 (8 packed ops per two values)");
-        run<3>(sink, cyc, wgs, "3 v_exp_f16 x 64 on converted halves");
-    }
+    (void)hipMalloc(&sink, 4096); (void)hipMalloc(&cyc, 256 * 8);
+    run<0, 1>(sink, cyc, "0 MFMAs only");
+    run<1, 1>(sink, cyc, "1 v_exp_f32 x 64 + v_cvt_pk_f16_f32 x 32 only");
+    run<2, 1>(sink, cyc, "2 interleaved (1-2 VALU behind every MFMA)");
+    run<3, 1>(sink, cyc, "3 blocked (28 MFMAs, then 48 VALU)");
+    run<5, 1>(sink, cyc, "5 interleaved, packed-fp16 polynomial exp2");
+    run<0, 2>(sink, cyc, "0 MFMAs only");
+    run<1, 2>(sink, cyc, "1 v_exp_f32 x 64 + v_cvt_pk_f16_f32 x 32 only");
+    run<2, 2>(sink, cyc, "2 interleaved");
+    run<3, 2>(sink, cyc, "3 blocked, both waves of a SIMD in the same order");
+    run<4, 2>(sink, cyc, "4 blocked, waves 4-7 VALU block first (anti-phase)");
+    run<5, 2>(sink, cyc, "5 interleaved, packed-fp16 polynomial exp2");
     return 0;
 }
