@@ -608,6 +608,9 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
             qf[t][ks] = as_frag<f16>(v);
         }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));     // (the conversions above complete in front of the asm MFMAs that read them)
+    asm volatile("s_nop 7" ::: "memory");
     f32x4 o_acc[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -700,7 +703,17 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     slot(I1{}, I0{}, BF{}, BF{}, kl, vl);                                         // reads K(unit 0)
     slot(I0{}, I2{}, BF{}, BF{}, kl, vl);                                         // S(0) raw; reads K(unit 1)
     slot(I1{}, I2{}, BF{}, BF{}, kl + so_next, vl);                               // S(1) raw; reads K(unit 2) of tile 1, V^T(unit 0)
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                            // the MFMA results are read by compiler-scheduled code next (it cannot see the producers)
+    // The MFMA results are read by compiler-scheduled code next.  hipcc does not know that the producers are MFMAs (no hazard padding) and is free to move the
+    // consumers up between the volatile asm statements (seen in one build: the column maxima were taken one instruction behind the MFMAs, the reference maximum
+    // came out different and the outputs differed in the last bit): the padding is followed by empty asm statements that re-define every score register, so
+    // that every consumer depends on something behind the padding in the (ordered) sequence of volatile statements.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(sc[u][kt][t]));
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float mx = sc[0][0][t][0];
@@ -764,6 +777,10 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(kf[j]));
 #pragma unroll
     for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(vlo[a]), "+v"(vhi[a]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(o_acc[a][t]));            // (as above: the accumulators' consumers stay behind the padding)
 
     // ---- denominators; a wave with a non-finite one redoes its rows with running maxima, straight from global memory --------------------
     float lsum[4];
