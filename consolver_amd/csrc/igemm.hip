@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     // the step instead of the middle, issues its fragment reads late, and both groups stand at the next barrier with B's reads still in
     // flight -- the pipe idles for an LDS latency every step (measured with the staging switched off: 238 us -> 194 us on the 64 x 64
     // 320 -> 320 layer once B wins the arbitration; pure MFMA issue of that loop: 177 us).  With priority B's MFMAs run first and
-    // uncontested, its reads overlap A's MFMAs, and vice versa.  (cs_set_tuning("conv_sched", 0) restores the old schedule.)
+    // uncontested, its reads overlap A's MFMAs, and vice versa.
     // What bounds this loop was measured with throw-away builds that skip parts of it (profiles/r02_conv_bound.txt): pure MFMA issue
     // 177 us, + per-step barrier 184, + fragment reads 221, + staging 259 (round-1 schedule); no barrier at all 180.
     if (SCHED >= 1 && groupB) __builtin_amdgcn_s_setprio(2);
@@ -892,6 +892,10 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");          // (the last step's look-ahead reads; the last MFMAs' results: hipcc pads nothing behind an asm MFMA)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     if (TRACE && w == 0 && lane == 0 && blockIdx.x < CS_TRACE_SLOTS && blockIdx.y == 0) {
         g_trace[blockIdx.x * CS_TRACE_W + 6] = __builtin_readcyclecounter() - tc_t0;
         g_trace[blockIdx.x * CS_TRACE_W + 8] = __builtin_amdgcn_s_memrealtime() - tc_r0;
@@ -1052,6 +1056,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
         step(std::integral_constant<int, 2>{}); if (++kt == KT) break;
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");          // (the last step's look-ahead reads; the last MFMAs' results)
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // E
     igemm_epilogue<false, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264);
 }
@@ -1190,6 +1198,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
         step(std::integral_constant<int, 1>{}); if (++kt == KT) break;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // the stage buffers become the epilogue patches
     if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
@@ -1582,7 +1594,6 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 int g_tune_debug = 0;
 int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
 int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
-int g_tune_conv_sched = -1;    // halo conv schedule: -1 auto, 0 round-1 lock-step groups, 1 + priority for the staggered group, 2 + its DMA issues among its MFMAs
 int g_tune_halo = 1;
 int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few 256 x 320 tiles) through gemm_lw_kernel (loader waves), 0: gemm_big_kernel<false, 160>
 int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
@@ -1594,7 +1605,7 @@ double igemm_flops(const IgemmArgs& a) {
     return 2.0 * M * a.N * (double)a.taps * (a.c0 + a.c1);
 }
 
-// one halo-conv instantiation per (upsample, tile width, k halves, schedule); the schedule comes from cs_set_tuning("conv_sched")
+// one halo-conv instantiation per (upsample, tile width, k halves)
 template <bool UP, int BN, int KH, int SCHED>
 static int launch_halo_sched(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) {
     static bool configured = false;
@@ -1607,12 +1618,10 @@ static int launch_halo_sched(const HaloParams& h, dim3 grid, size_t lds, hipStre
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
+// the k32-step kernels (KH = 2: BN 320 / 256) run schedule 2 (priority + interleaved DMA for the staggered group: -6 ... -11 %, profiles/r02_ab_conv_sched.txt), the
+// k64-step kernels (BN 160 / 128) the lock-step schedule 0 (schedule 2 cost them 3 %); the other combinations were measured in round 2 and are not compiled any more
 template <bool UP, int BN, int KH>
-static int launch_halo(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) {
-    if (h.sched <= 0) return launch_halo_sched<UP, BN, KH, 0>(h, grid, lds, s);
-    if (h.sched == 1) return launch_halo_sched<UP, BN, KH, 1>(h, grid, lds, s);
-    return launch_halo_sched<UP, BN, KH, 2>(h, grid, lds, s);
-}
+static int launch_halo(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) { return launch_halo_sched<UP, BN, KH, KH == 2 ? 2 : 0>(h, grid, lds, s); }
 
 static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done) {
     const int cin = a.c0 + a.c1;
@@ -1679,7 +1688,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             h.PX = PX; h.PP = PP;
             // schedule: the k32-step kernels (BN 320 / 256) gain 6-11 % from priority + interleaved DMA (A/B on one box, tools/ab_convsched.sh);
             // the k64-step kernels (BN 160 / 128: 16 x 16 and 8 x 8 images) measured 0.207 -> 0.213 ms with it and keep the lock-step schedule
-            h.splits = splits; h.partial = a.splitk_ws; h.sched = g_tune_conv_sched < 0 ? (wide ? 2 : 0) : g_tune_conv_sched;
+            h.splits = splits; h.partial = a.splitk_ws; h.sched = wide ? 2 : 0;
             const size_t l = 2 * (HALO_ROWS_MAX * 128) + 3 * ((size_t)hbn * (wide ? 64 : 128));
             const dim3 grid(h.e.nblk, splits);
             int rc;

@@ -15,7 +15,6 @@ int debug_trace_read(void* dst, size_t bytes);
 int debug_attn_trace_read(void* dst, size_t bytes);
 extern int g_tune_cfg_share;
 extern int g_tune_xattn_fused;
-extern int g_tune_conv_sched;
 extern int g_tune_attn_prio;
 extern int g_tune_gemm2_prio;
 extern int g_tune_biggemm;
@@ -38,7 +37,6 @@ int cs_set_tuning(const char* key, int value) {
     if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
     if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
     if (!strcmp(key, "attn_prio")) { g_tune_attn_prio = value; return CS_OK; }
-    if (!strcmp(key, "conv_sched")) { if (value < -1 || value > 2) CS_FAIL(CS_E_ARG, "conv_sched must be -1 (auto), 0, 1 or 2"); g_tune_conv_sched = value; return CS_OK; }
     if (!strcmp(key, "attn_qt40")) { if (value != 2 && value != 4) CS_FAIL(CS_E_ARG, "attn_qt40 must be 2 or 4"); g_tune_attn_qt40 = value; return CS_OK; }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
 }

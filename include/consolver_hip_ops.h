@@ -118,8 +118,6 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "conv_halo": 0 never, 1 auto (default), 2 whenever the shape allows, 3 also force the 256x320 / 256x256 k32 tiles, 4 never use those;
  *   "gemm_big":  0 off, 1 auto (default), 2 force the 256x320 GEMM, 3 force the 256x160 GEMM;
  *   "attn_qt40": query tiles per wave at head dim 40 (2 | 4, default 4);
- *   "conv_sched": halo 3x3 conv wave schedule: -1 auto (default: 2 for the 320 / 256-wide k32 kernels, 0 otherwise), 0 lock-step groups,
- *                1 + static priority for the staggered wave group, 2 + that group's LDS-DMA issues spread among its MFMAs;
  *   "xattn_fused": 1 (default): the cross-attention sub-block at C = 320 runs as one kernel (cs_op_xattn_block) inside cs_unet_forward;
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
