@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     }
 
     // =============================== compute waves ===============================
+    if (p.prio) __builtin_amdgcn_s_setprio(1);                 // (cs_set_tuning("attn_prio", 1): static priority over the loader partner; measured)
     const int q0 = qblk * 256 + w * 64;
     f16x8 qf[4][2];
 #pragma unroll
@@ -944,6 +945,11 @@ int launch_attn40_lw(AttnParams p, int B, hipStream_t s) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
+    }
+    p.nqb = p.Nq / 256; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
+        hipLaunchKernelGGL(k9, dim3((unsigned)((long)p.nqb * p.H * B)), dim3(512), 9 * 12288, s, p);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
     }
     p.nqb = p.Nq / 256; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
     const long total = (long)p.nqb * p.H * B;

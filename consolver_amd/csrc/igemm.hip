@@ -732,6 +732,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     }
 
     // =============================== compute waves ===============================
+    if (p.e.debug & 4096) __builtin_amdgcn_s_setprio(1);       // (timing experiment: static priority for the multiplying wave of each SIMD over its loader partner)
     // One computing wave per SIMD: nothing but this wave's own lookahead hides an LDS latency (~200 cycles with four waves reading and the DMA writing), so the
     // step is branch-free, every LDS read is an inline-asm ds_read_b128 and every wait a hand-counted lgkmcnt.  (hipcc's own waits on this loop were lgkmcnt(0) at
     // the loop head -- the back edge merges two histories -- and a 4, 3, 2, 1, 0 ladder behind the conditional reads of the last items: two exposed latencies per
