@@ -947,11 +947,6 @@ int launch_attn40_lw(AttnParams p, int B, hipStream_t s) {
         configured = true;
     }
     p.nqb = p.Nq / 256; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
-        hipLaunchKernelGGL(k9, dim3((unsigned)((long)p.nqb * p.H * B)), dim3(512), 9 * 12288, s, p);
-        CS_CHECK_LAUNCH();
-        return CS_OK;
-    }
-    p.nqb = p.Nq / 256; p.lin0 = 0; p.splits = 1; p.tiles_per_split = 0; p.part_rows = 0; p.part_o = nullptr; p.part_ml = nullptr;
     const long total = (long)p.nqb * p.H * B;
     if (total > 0x7fffffffL) CS_FAIL(CS_E_SHAPE, "attention: too many workgroups");
     hipLaunchKernelGGL(kfn, dim3((unsigned)total), dim3(512), lds, s, p);

@@ -613,6 +613,8 @@ constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
 //     (output row j + tap row dy) * 18 * 128 + parity * 41 KiB < 64 Ki fits the 16-bit offset field of ds_read.
 template <bool UP, int BN, bool TRACE = false, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
+    unsigned long long tw_entry = 0;
+    if (TRACE) tw_entry = __builtin_amdgcn_s_memrealtime();
     // (FAST with the fused nearest-x2 upsample: the 16 x 16 output patch reads an 8 x 8 input patch, HALO_W = 10, 100 halo rows, 13 pieces; output column fx
     //  under tap column dx reads halo column ((fx + dx - 1) >> 1) + 1 -- again three per-lane values -- and output row 4 w + j under tap row dy reads halo row
     //  2 w + ((j + dy - 1) >> 1) + 1: the (j, dy) part is a compile-time immediate)
@@ -901,6 +903,10 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         g_trace[blockIdx.x * CS_TRACE_W + 6] = __builtin_readcyclecounter() - tc_t0;
         g_trace[blockIdx.x * CS_TRACE_W + 8] = __builtin_amdgcn_s_memrealtime() - tc_r0;
         g_trace[blockIdx.x * CS_TRACE_W + 5] = (unsigned long long)nsteps;
+        g_trace[blockIdx.x * CS_TRACE_W + 0] = tw_entry;                                        // 100 MHz stamps: entry | k loop start | k loop end (exit: slot 3, below)
+        g_trace[blockIdx.x * CS_TRACE_W + 1] = tc_r0;
+        g_trace[blockIdx.x * CS_TRACE_W + 2] = __builtin_amdgcn_s_memrealtime();
+        g_trace[blockIdx.x * CS_TRACE_W + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) | __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
     }
     __builtin_amdgcn_s_barrier();                                               // E
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
@@ -916,6 +922,10 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
             for (int i = 0; i < NT; ++i)
                 *reinterpret_cast<f32x4*>(dst + (size_t)m * p.e.N + n_blk + i * 16 + gq * 4) = acc[i][j];
         }
+    }
+    if (TRACE && w == 0 && lane == 0 && blockIdx.x < CS_TRACE_SLOTS && blockIdx.y == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        // (the stores have left the CU)
+        g_trace[blockIdx.x * CS_TRACE_W + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

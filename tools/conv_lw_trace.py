@@ -41,3 +41,18 @@ for tag, H, cin, cout, up in [("L0 320->320", 64, 320, 320, False), ("L0 960->32
     print(f"== {tag}: {ms:.3f} ms ({2.0 * B * Ho * Ho * 9 * cin * cout / ms / 1e12:.0f} TFLOP/s), {len(t)} workgroups x {int(med(steps))} steps | per step, compute wave 0: "
           f"{med(cyc / steps):7.1f} cycles (MFMA floor 1280), barrier {med(bar / steps):6.1f}, lgkmcnt(0) {med(lgkm / steps):6.1f} | clock {med(cyc / ticks) * 0.1:.2f} GHz | "
           f"k loop {med(ticks) / 100:.1f} us per tile | loader wave 4: DMA wait {med(lwait / steps):6.1f}, barrier {med(lbar / steps):7.1f} cycles per step")
+    # the workgroup's phases (100 MHz stamps) and the CU's turnaround to its next workgroup
+    raw = buf[:nwg][ok]
+    ent, ks, ke, ex = (raw[:, i].astype(np.float64) for i in range(4))
+    print(f"      phases, us: entry -> k loop {med(ks - ent) / 100:.2f} | k loop {med(ke - ks) / 100:.2f} | epilogue until the stores have left {med(ex - ke) / 100:.2f} | workgroup {med(ex - ent) / 100:.2f} | "
+          f"launch: first entry -> last exit {(ex.max() - ent.min()) / 100:.1f} us")
+    cu = {}
+    for r in raw:
+        cu.setdefault((((int(r[4]) >> 32) & 0xF) << 8) | ((int(r[4]) >> 8) & 0xFF), []).append((int(r[0]), int(r[3])))
+    gaps, per = [], []
+    for lst in cu.values():
+        lst.sort(); per.append(len(lst))
+        gaps += [(lst[i + 1][0] - lst[i][1]) / 100 for i in range(len(lst) - 1)]
+    if gaps:
+        print(f"      {len(cu)} CUs, workgroups per CU min / mean / max {min(per)} / {np.mean(per):.1f} / {max(per)}; exit -> next entry on the same CU: median {np.median(gaps):.2f} us, mean {np.mean(gaps):.2f} us; "
+              f"entry of a CU's first workgroup: spread {(max(l[0][0] for l in cu.values()) - ent.min()) / 100:.1f} us; exit of its last: spread {(ex.max() - min(l[-1][1] for l in cu.values())) / 100:.1f} us")
