@@ -53,6 +53,11 @@ for tag, H, cin, cout, up in [("L0 320->320", 64, 320, 320, False), ("L0 960->32
     for lst in cu.values():
         lst.sort(); per.append(len(lst))
         gaps += [(lst[i + 1][0] - lst[i][1]) / 100 for i in range(len(lst) - 1)]
+    xcc = (raw[:, 4].astype(np.uint64) >> np.uint64(32)).astype(np.int64) & 0xF
+    dur = (ex - ent) / 100
+    kl = (ke - ks) / 100
+    print("      per XCD: mean workgroup us " + " ".join(f"{dur[xcc == x].mean():.1f}" for x in range(8)) + " | mean k loop us " + " ".join(f"{kl[xcc == x].mean():.1f}" for x in range(8))
+          + " | last exit us " + " ".join(f"{(ex[xcc == x].max() - ent.min()) / 100:.0f}" for x in range(8)))
     if gaps:
         print(f"      {len(cu)} CUs, workgroups per CU min / mean / max {min(per)} / {np.mean(per):.1f} / {max(per)}; exit -> next entry on the same CU: median {np.median(gaps):.2f} us, mean {np.mean(gaps):.2f} us; "
               f"entry of a CU's first workgroup: spread {(max(l[0][0] for l in cu.values()) - ent.min()) / 100:.1f} us; exit of its last: spread {(ex.max() - min(l[-1][1] for l in cu.values())) / 100:.1f} us")
