@@ -801,8 +801,9 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (tap (0, 0), halo buffer 0, weight buffer 0)
         lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowi(UP, 0, 0) * ROWB>(fa[0][0], VA[0][0]); lds_read<lw_rowi(UP, 1, 0) * ROWB>(fa[0][1], VA[0][0]);
         lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowi(UP, 2, 0) * ROWB>(fa[0][2], VA[0][0]); lds_read<lw_rowi(UP, 3, 0) * ROWB>(fa[0][3], VA[0][0]);
-        lds_read<2 * 2048>(fw[2], WB[0][0]); lds_read<3 * 2048>(fw[3], WB[0][0]);
-        static_assert(LA == 4, "prologue reads");
+        lds_read<2 * 2048>(fw[2], WB[0][0]);
+        if constexpr (LA == 4) lds_read<3 * 2048>(fw[3], WB[0][0]);
+        static_assert(LA == 3 || LA == 4, "prologue reads");
         if (TRACE) { tc_t0 = __builtin_readcyclecounter(); tc_r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         int delta = AB_F;
         for (int c = c_begin; c < c_end; ++c) {
@@ -1608,7 +1609,7 @@ int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 
 int g_tune_halo = 1;
 int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few 256 x 320 tiles) through gemm_lw_kernel (loader waves), 0: gemm_big_kernel<false, 160>
 int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
-int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 0: the 8-wave halo kernels
+int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 or N % 128 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 3: N % 160 == 0 only, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
 
 double igemm_flops(const IgemmArgs& a) {
@@ -1679,8 +1680,10 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
         else if (a.N % 256 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 256) >= 192 || g_tune_halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
         // round 3: loader-wave kernel (256 pixels x 160 channels per workgroup) wherever the channel count allows it
-        const bool lw = g_tune_conv_lw != 0 && a.N % 160 == 0;
-        if (lw) { hbn = 160; wide = false; }
+        const bool lw160 = g_tune_conv_lw != 0 && a.N % 160 == 0;
+        const bool lw128 = g_tune_conv_lw != 0 && g_tune_conv_lw != 3 && !lw160 && a.N % 128 == 0;        // the VAE's widths 128 / 256 / 512 (conv_lw = 3: BN 160 only)
+        const bool lw = lw160 || lw128;
+        if (lw) { hbn = lw160 ? 160 : 128; wide = false; }
         const int tiles_n = a.N / hbn;
         const int NC = cin / BK;
         int splits = 1;
@@ -1705,12 +1708,13 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             int rc;
             if (lw) {
                 constexpr size_t llw_max = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);      // = 160 KiB exactly: the whole LDS of a CU
-                const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * (160 * 128);
+                const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)hbn * 128);
                 // FAST: plain conv on 16 x 16 patches (every UNet level down to 16 x 16, the VAE): immediate-offset LDS addressing
                 const bool fast = TW == 16 && TH == 16 && g_tune_conv_lw != 2 && (a.upsample ? (h.HALO_W == 10 && h.NQ == 13) : (h.HALO_W == 18 && h.NQ == 41));
                 typedef void (*lw_fn)(HaloParams);
-                static const lw_fn variants[6] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
-                                                  conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>, conv3_lw_kernel<true, 160, false, true>};
+                static const lw_fn variants[10] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
+                                                   conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>, conv3_lw_kernel<true, 160, false, true>,
+                                                   conv3_lw_kernel<false, 128, false, true>, conv3_lw_kernel<false, 128>, conv3_lw_kernel<true, 128>, conv3_lw_kernel<true, 128, false, true>};
                 static bool configured_lw = false;
                 if (!configured_lw) {
                     for (lw_fn f : variants)
@@ -1719,7 +1723,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 }
                 auto launch = [&](lw_fn kfn) -> int { hipLaunchKernelGGL(kfn, grid, dim3(512), llw, s, h); return CS_OK; };
                 const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations (plain conv only)
-                if (trace) rc = launch(variants[fast ? 3 : 4]);
+                if (hbn == 128) rc = launch(variants[a.upsample ? (fast ? 9 : 8) : (fast ? 6 : 7)]);
+                else if (trace) rc = launch(variants[fast ? 3 : 4]);
                 else if (a.upsample) rc = launch(variants[fast ? 5 : 2]);
                 else rc = launch(variants[fast ? 0 : 1]);
                 if (rc != CS_OK) return rc;

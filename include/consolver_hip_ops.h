@@ -122,8 +122,9 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
  *                cs_op_conv2d_gn, 0 always a separate statistics pass;
- *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 run on the loader-wave kernel (conv3_lw_kernel: waves 0-3 multiply,
- *                waves 4-7 stage), 2 the same without its immediate-offset (FAST) addressing, 0 the 8-wave halo kernels;
+ *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 (BN 160: the UNet) or N % 128 == 0 (BN 128: the VAE) run on the loader-wave kernel
+ *                (conv3_lw_kernel: waves 0-3 multiply, waves 4-7 stage), 2 the same without its immediate-offset (FAST) addressing, 3 BN 160 only, 0 the 8-wave
+ *                halo kernels;
  *   "gemm_w8":   1 (default) the 256x320 GEMM runs its hand-scheduled k loop (gemm_w8_kernel; needs 32-bit operand offsets), 0 the
  *                compiler-scheduled gemm_big_kernel (bit-identical results);
  *   "gemm_lw":   1 (default) layers served by the 256x160 GEMM tile run the loader-wave kernel (gemm_lw_kernel), 0 gemm_big_kernel<.,160>;

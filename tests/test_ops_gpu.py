@@ -151,10 +151,12 @@ def test_conv3x3_halo_kernel_wide_tiles_fused_upsample(B, H, cin, N):
     assert rel_l2(nchw(out), ref) < 1e-3
 
 
-LW_CASES = [  # B, H, W, cin, N (N % 160 == 0): the loader-wave kernel (conv3_lw_kernel) forced on every tile geometry -- 16 x 16 patches, whole
+LW_CASES = [  # B, H, W, cin, N (N % 160 == 0, or N % 128 == 0 below): the loader-wave kernel (conv3_lw_kernel) forced on every tile geometry -- 16 x 16 patches, whole
     # 8-wide images four per tile with a ragged last tile, non-square images, one / several column tiles, one / many channel chunks
     (2, 64, 64, 64, 320), (3, 32, 32, 128, 160), (2, 16, 16, 64, 320), (5, 8, 8, 64, 160), (1, 8, 8, 128, 320), (1, 64, 64, 320, 640),
-    (2, 16, 32, 64, 160), (3, 16, 8, 64, 160), (1, 48, 80, 64, 480), (1, 32, 32, 640, 640), (2, 16, 16, 1280, 1280), (7, 8, 8, 192, 960)]
+    (2, 16, 32, 64, 160), (3, 16, 8, 64, 160), (1, 48, 80, 64, 480), (1, 32, 32, 640, 640), (2, 16, 16, 1280, 1280), (7, 8, 8, 192, 960),
+    # N % 128 == 0 (BN 128: the VAE's widths)
+    (2, 64, 64, 64, 128), (1, 32, 32, 256, 256), (1, 64, 64, 128, 512), (5, 8, 8, 64, 256), (1, 48, 80, 64, 384), (2, 16, 16, 512, 512)]
 
 
 @pytest.mark.parametrize("case", LW_CASES)
@@ -178,7 +180,7 @@ def test_conv3x3_loader_wave_kernel(case):
     assert torch.equal(outs[1], again)
 
 
-@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320), (1, 32, 320, 640)])
+@pytest.mark.parametrize("B,H,cin,N", [(2, 32, 64, 320), (1, 16, 128, 160), (3, 8, 64, 320), (1, 32, 320, 640), (1, 32, 128, 256), (2, 16, 64, 128), (1, 64, 256, 512)])
 def test_conv3x3_loader_wave_kernel_fused_upsample(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     ref = F.conv2d(F.interpolate(nchw(x), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
@@ -192,7 +194,7 @@ def test_conv3x3_loader_wave_kernel_fused_upsample(B, H, cin, N):
     assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160)])
+@pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160), (2, 16, 512, 256), (4, 8, 256, 128)])
 def test_conv3x3_loader_wave_kernel_split_k(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
     temb, res = rnd(B, N, seed=4, scale=0.5), rnd(B, H, H, N, seed=5)
