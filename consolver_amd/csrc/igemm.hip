@@ -580,6 +580,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl<N>(static_ca
 // then (p < MT) one k-half-1 activation fragment, then (p = QB, QB + 1) two next-step activation fragments.
 // FAST addressing of conv3_lw_kernel: halo row (relative to the wave's first one) read by output row j of the wave under tap row dy
 constexpr int lw_rowi(bool up, int j, int dy) { return up ? (j + dy + 1) / 2 : dy + j; }        // (((j + dy - 1) >> 1) + 1 == (j + dy + 1) / 2 for j + dy >= 0)
+constexpr int lw_rowf(int fast, bool up, int j, int dy) { return fast == 2 ? 2 * j + dy : lw_rowi(up, j, dy); }     // (FAST 2: output tile j = image rows 2 j, 2 j + 1)
 constexpr int lw_reads_of(int p, int MT, int QB) { return 1 + (p < MT ? 1 : 0) + ((p == QB || p == QB + 1) ? 2 : 0); }
 constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
     // the weight fragment of item q was the FIRST read of item q - LA (mod NQ)
@@ -611,7 +612,9 @@ constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
 //     (conflict-free like the row-index form: within a ds_read_b128 lane group the (row parity, 16-byte slot) pairs stay distinct because HALO_W is even);
 //   * taps and halo-buffer parity are compile-time (the chunk loop runs one of two 9-step bodies), the weight buffer of tap t is t % 3 (9 % 3 == 0), and
 //     (output row j + tap row dy) * 18 * 128 + parity * 41 KiB < 64 Ki fits the 16-bit offset field of ds_read.
-template <bool UP, int BN, bool TRACE = false, bool FAST = false>
+// FAST = 2: four whole 8 x 8 images per tile (the UNet's 8 x 8 level): wave w multiplies image w, a fragment covers two image rows (lane bit 3), HALO_W = 10, 400 halo rows,
+// 50 pieces; the same column swizzle is conflict-free for it (simulated over the four 16-lane service groups of ds_read_b128 for every tap and output tile).
+template <bool UP, int BN, bool TRACE = false, int FAST = 0>
 __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     unsigned long long tw_entry = 0;
     if (TRACE) tw_entry = __builtin_amdgcn_s_memrealtime();
@@ -624,7 +627,8 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     static_assert(NBQ % 4 == 0, "every loader wave issues the same number of weight pieces");
     constexpr int WPL = NBQ / 4;                             // ... per loader wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int A_BYTES = FAST ? (UP ? 13 : 41) * 1024 : p.NQ * 1024;          // halo buffer: NQ pieces of 8 rows (<= HALO_ROWS_MAX * 128)
+    static_assert(FAST != 2 || !UP, "the multi-image form has no fused upsample");
+    const int A_BYTES = FAST ? (FAST == 2 ? 50 : UP ? 13 : 41) * 1024 : p.NQ * 1024;          // halo buffer: NQ pieces of 8 rows (<= HALO_ROWS_MAX * 128)
     char* const lA = smem;                    // [2][A_BYTES]
     char* const lB = smem + 2 * A_BYTES;      // [NWB][B_BYTES]: stage g lives in buffer g % 3
 
@@ -784,9 +788,10 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     if constexpr (FAST) {
         // per-tile address registers: VA[dx][ks] = halo row of (output row 4 w, tap row 0) at column fx + dx, k half ks, in the CURRENT chunk's halo buffer
         // (moved to the other buffer once per chunk: 7 v_add per 720 MFMAs); VN = VA[0][0] in the other buffer; WB[wb][ks] = weight tile 0 of buffer wb
-        constexpr int HW_F = UP ? 10 : 18, AB_F = (UP ? 13 : 41) * 1024, ROWB = HW_F * 128;
-        const int fxl = lane & 15;
-        const unsigned rowb = lA_base + (unsigned)((UP ? 2 : 4) * wm * HW_F) * 128;
+        constexpr int HW_F = (UP || FAST == 2) ? 10 : 18, AB_F = (FAST == 2 ? 50 : UP ? 13 : 41) * 1024, ROWB = HW_F * 128;
+        const int fxl = FAST == 2 ? (lane & 7) : (lane & 15);
+        // first halo row of this lane's fragments: the wave's four output rows of the 16 x 16 patch, or (FAST 2) image wm of the tile, its row 0 or 1 by lane bit 3
+        const unsigned rowb = FAST == 2 ? lA_base + (unsigned)(wm * 100 + ((lane >> 3) & 1) * HW_F) * 128 : lA_base + (unsigned)((UP ? 2 : 4) * wm * HW_F) * 128;
         unsigned VA[3][2], VN, WB[NWB][2];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -799,8 +804,8 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         for (int b3 = 0; b3 < NWB; ++b3) { WB[b3][0] = lB_base + b3 * B_BYTES + wfrag0; WB[b3][1] = lB_base + b3 * B_BYTES + wfrag1; }
         __builtin_amdgcn_s_barrier();                                           // K(-1): stage 0 has landed
         // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (tap (0, 0), halo buffer 0, weight buffer 0)
-        lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowi(UP, 0, 0) * ROWB>(fa[0][0], VA[0][0]); lds_read<lw_rowi(UP, 1, 0) * ROWB>(fa[0][1], VA[0][0]);
-        lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowi(UP, 2, 0) * ROWB>(fa[0][2], VA[0][0]); lds_read<lw_rowi(UP, 3, 0) * ROWB>(fa[0][3], VA[0][0]);
+        lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowf(FAST, UP, 0, 0) * ROWB>(fa[0][0], VA[0][0]); lds_read<lw_rowf(FAST, UP, 1, 0) * ROWB>(fa[0][1], VA[0][0]);
+        lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowf(FAST, UP, 2, 0) * ROWB>(fa[0][2], VA[0][0]); lds_read<lw_rowf(FAST, UP, 3, 0) * ROWB>(fa[0][3], VA[0][0]);
         lds_read<2 * 2048>(fw[2], WB[0][0]);
         if constexpr (LA == 4) lds_read<3 * 2048>(fw[3], WB[0][0]);
         static_assert(LA == 3 || LA == 4, "prologue reads");
@@ -820,13 +825,13 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
                         else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], WB[WBC][1]);
                         else lds_read<(r - NQ) * 2048>(fw[r % RS], WB[WBN][0]);
                     }
-                    if constexpr (q < MT) lds_read<lw_rowi(UP, q, DY) * ROWB>(fa[1][q], VA[DX][1]);
+                    if constexpr (q < MT) lds_read<lw_rowf(FAST, UP, q, DY) * ROWB>(fa[1][q], VA[DX][1]);
                     if constexpr (q == QB || q == QB + 1) {
                         constexpr int j0 = (q - QB) * 2;
                         if constexpr (T == 8) {
-                            lds_read<lw_rowi(UP, j0, 0) * ROWB>(fa[0][j0], VN); lds_read<lw_rowi(UP, j0 + 1, 0) * ROWB>(fa[0][j0 + 1], VN);
+                            lds_read<lw_rowf(FAST, UP, j0, 0) * ROWB>(fa[0][j0], VN); lds_read<lw_rowf(FAST, UP, j0 + 1, 0) * ROWB>(fa[0][j0 + 1], VN);
                         } else {
-                            lds_read<lw_rowi(UP, j0, DYN) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<lw_rowi(UP, j0 + 1, DYN) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
+                            lds_read<lw_rowf(FAST, UP, j0, DYN) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<lw_rowf(FAST, UP, j0 + 1, DYN) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
@@ -1711,10 +1716,13 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)hbn * 128);
                 // FAST: plain conv on 16 x 16 patches (every UNet level down to 16 x 16, the VAE): immediate-offset LDS addressing
                 const bool fast = TW == 16 && TH == 16 && g_tune_conv_lw != 2 && (a.upsample ? (h.HALO_W == 10 && h.NQ == 13) : (h.HALO_W == 18 && h.NQ == 41));
+                const bool fast8 = hbn == 160 && TW == 8 && TH == 8 && !a.upsample && IPT == 4 && PP == 1 && h.HALO_W == 10 && h.NQ == 50 && g_tune_conv_lw != 2 &&
+                                   !((g_tune_debug & 16384) != 0);
                 typedef void (*lw_fn)(HaloParams);
-                static const lw_fn variants[10] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
+                static const lw_fn variants[11] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
                                                    conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>, conv3_lw_kernel<true, 160, false, true>,
-                                                   conv3_lw_kernel<false, 128, false, true>, conv3_lw_kernel<false, 128>, conv3_lw_kernel<true, 128>, conv3_lw_kernel<true, 128, false, true>};
+                                                   conv3_lw_kernel<false, 128, false, true>, conv3_lw_kernel<false, 128>, conv3_lw_kernel<true, 128>, conv3_lw_kernel<true, 128, false, true>,
+                                                   conv3_lw_kernel<false, 160, false, 2>};
                 static bool configured_lw = false;
                 if (!configured_lw) {
                     for (lw_fn f : variants)
@@ -1723,7 +1731,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 }
                 auto launch = [&](lw_fn kfn) -> int { hipLaunchKernelGGL(kfn, grid, dim3(512), llw, s, h); return CS_OK; };
                 const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations (plain conv only)
-                if (hbn == 128) rc = launch(variants[a.upsample ? (fast ? 9 : 8) : (fast ? 6 : 7)]);
+                if (fast8) rc = launch(variants[10]);
+                else if (hbn == 128) rc = launch(variants[a.upsample ? (fast ? 9 : 8) : (fast ? 6 : 7)]);
                 else if (trace) rc = launch(variants[fast ? 3 : 4]);
                 else if (a.upsample) rc = launch(variants[fast ? 5 : 2]);
                 else rc = launch(variants[fast ? 0 : 1]);
