@@ -15,7 +15,10 @@
 #include "el.h"
 #include <algorithm>
 
+#include <utility>
+
 int g_tune_gemm2_prio = 0;
+int g_tune_gemm2_w8 = 1;       // 1: main launches run the hand-scheduled k loop (W8 instantiation of gemm2_kernel; bit-identical), 0: the compiler-scheduled one
 
 namespace {
 
@@ -67,7 +70,44 @@ __device__ __forceinline__ void g2_tile_coords(const G2Params& p, int id, int& t
     tn = rem / gsz; tm = band * GM + (rem - tn * gsz);
 }
 
-template <typename T, int ACT>
+// ---- hand-counted LDS reads / in-place MFMAs for the W8 k loop (the counterpart of gemm_w8_kernel in igemm.hip) --------------------------------
+template <int OFF, typename F>
+__device__ __forceinline__ void g2_lds_read(F& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <typename T> struct G2Mfma;
+template <> struct G2Mfma<f16> {
+    static __device__ __forceinline__ void run(f32x4& c, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+};
+template <> struct G2Mfma<bf16_el> {
+    static __device__ __forceinline__ void run(f32x4& c, const bf16x8_t& a, const bf16x8_t& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+};
+template <int N, class F, int... I>
+__device__ __forceinline__ void g2_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void g2_for(F&& f) { g2_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+// reads in front of item p's MFMAs: one weight fragment (for item p + LA), p < MT: one k-half-1 activation fragment, p = QB, QB + 1: two next-step activation
+// fragments; the wait in front of item q = number of reads issued after the youngest read item q needs (LDS returns in order)
+constexpr int g2_reads_of(int p, int MT, int QB) { return 1 + (p < MT ? 1 : 0) + ((p == QB || p == QB + 1) ? 2 : 0); }
+constexpr int g2_wait_count(int q, int NQ, int LA, int MT, int QB) {
+    int n = 0;
+    for (int d = LA; d >= 0; --d) n += g2_reads_of(((q - d) % NQ + NQ) % NQ, MT, QB);
+    const int after_w = n - 1;
+    int after_a = after_w;
+    if (q < 2) {
+        int m = 0;
+        for (int pp = QB + 2; pp < NQ; ++pp) m += g2_reads_of(pp, MT, QB);
+        for (int pp = 0; pp <= q; ++pp) m += g2_reads_of(pp, MT, QB);
+        after_a = m;
+    }
+    return after_a < after_w ? after_a : after_w;
+}
+
+// W8 (round 3): the k loop with the schedule written out by hand, as gemm_w8_kernel does for the 256 x 320 tile: staging by buffer_load ... lds with per-piece
+// 32-bit row offsets computed once and the k offset in an SGPR (no per-piece address arithmetic or zero-page select: rows past M / N are clamped, their products
+// are never stored), every fragment read an inline-asm ds_read_b128 at (per-tile register + immediate), every wait a counted lgkmcnt, MFMAs in place.  Items
+// q = (k half, weight tile) of 4 MFMAs, 16 per step; weight fragments through a 4-slot ring 3 items ahead; the step's barrier in front of item 13 with all of the
+// stage's fragments in registers; pieces 0..2 of stage kt + 2 go out with items 13..15 (their buffer is free behind the barrier), pieces 3..7 with items 0..4 of
+// the next step, vmcnt(0) in front of the next barrier.  Needs 32-bit byte offsets into A and W and no k split (the split-K tail keeps the other loop).
+template <typename T, int ACT, bool W8 = false>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
     constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -100,6 +140,99 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     const int m_blk = tm * BMX, n_blk = tn * BNX;
 
     const int pch = lane & 7;
+    // Accumulators start from the bias (this lane's output channels n_blk + wn*128 + i*16 + 4*(lane>>4) .. +3), so the epilogue has no bias
+    // loads: there each sat in its own `if (p.bias)` block followed by s_waitcnt vmcnt(0), which on gfx9 also drains the stores in flight.
+    // (split-K partial tiles start from zero: the reduce kernel adds the bias once.)
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        const int n = n_blk + wn * 128 + i * 16 + (lane >> 4) * 4;
+        if (p.bias && pp.splits == 1 && n < p.N) {
+            const u32x2 t = *reinterpret_cast<const u32x2*>(p.bias + n);
+            b = f32x4{El<T>::tof((u16)(t[0] & 0xffff)), El<T>::tof((u16)(t[0] >> 16)), El<T>::tof((u16)(t[1] & 0xffff)), El<T>::tof((u16)(t[1] >> 16))};
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = b;
+    }
+
+    if constexpr (W8) {
+        constexpr int NQ = 2 * NT, RS = NT / 2, LA = RS - 1, QB = NQ - LA;
+        static_assert(NT == 8 && MT == 4 && LA == 3 && QB == 13, "read / piece schedule");
+        const int lr = lane >> 3;
+        unsigned aoff[4], woff[4];                                   // byte offsets from A / W: mapped row * row length + swizzled 16-byte chunk
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 8 * (w * 4 + j) + lr;
+            const unsigned ch = (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
+            aoff[j] = (unsigned)(rowmap(min(m_blk + r, p.M - 1), p.a_seg, p.a_stride, p.a_off) * p.lda * 2) + ch;
+            woff[j] = (unsigned)min(n_blk + r, p.N - 1) * (unsigned)(p.K * 2) + ch;
+        }
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xffffffff, 0x00020000);
+        auto piece = [&](auto n_tag, int kt, int buf) {              // piece n (0..3 activations, 4..7 weights) of stage kt into stage buffer buf
+            constexpr int n = decltype(n_tag)::value;
+            if constexpr (n < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(smem + buf * STAGE + (w * 4 + n) * 1024), 16, aoff[n], kt * (BK * 2), 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(smem + buf * STAGE + A_BYTES + (w * 4 + n - 4) * 1024), 16, woff[n - 4], kt * (BK * 2), 0, 0);
+        };
+        const int gq = lane >> 4, swz = (lane >> 1) & 7;
+        const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const unsigned wfrag0 = (lane & 15) * 128 + (gq ^ swz) * 16, wfrag1 = (lane & 15) * 128 + ((4 + gq) ^ swz) * 16;
+        unsigned SA[2][2], SW[2][2];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+            SA[b2][0] = sbase + b2 * STAGE + wm * 8192 + wfrag0; SA[b2][1] = sbase + b2 * STAGE + wm * 8192 + wfrag1;
+            SW[b2][0] = sbase + b2 * STAGE + A_BYTES + wn * 16384 + wfrag0; SW[b2][1] = sbase + b2 * STAGE + A_BYTES + wn * 16384 + wfrag1;
+        }
+        frag fa[2][MT], fw[RS];
+        g2_for<8>([&](auto nc) { piece(nc, 0, 0); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (KT > 1) g2_for<3>([&](auto nc) { piece(nc, 1, 1); });
+        // what items 13..15 of a step read: the next step's first weight fragments and k-half-0 activation fragments
+        g2_lds_read<0>(fw[0], SW[0][0]); g2_lds_read<0>(fa[0][0], SA[0][0]); g2_lds_read<2048>(fa[0][1], SA[0][0]);
+        g2_lds_read<2048>(fw[1], SW[0][0]); g2_lds_read<2 * 2048>(fa[0][2], SA[0][0]); g2_lds_read<3 * 2048>(fa[0][3], SA[0][0]);
+        g2_lds_read<2 * 2048>(fw[2], SW[0][0]);
+        int kt = 0;
+        auto step = [&](auto b_tag) {                                // stage kt in buffer B
+            constexpr int B = decltype(b_tag)::value, BO = B ^ 1;
+            g2_for<NQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
+                if constexpr (q == QB) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's pieces of stage kt + 1 have landed, its reads of stage kt are done
+                    __builtin_amdgcn_s_barrier();
+                }
+                {
+                    constexpr int r = q + LA;
+                    if constexpr (r < NT) g2_lds_read<r * 2048>(fw[r % RS], SW[B][0]);
+                    else if constexpr (r < NQ) g2_lds_read<(r - NT) * 2048>(fw[r % RS], SW[B][1]);
+                    else g2_lds_read<(r - NQ) * 2048>(fw[r % RS], SW[BO][0]);
+                }
+                if constexpr (q < MT) g2_lds_read<q * 2048>(fa[1][q], SA[B][1]);
+                if constexpr (q == QB || q == QB + 1) {
+                    constexpr int j0 = (q - QB) * 2;
+                    g2_lds_read<j0 * 2048>(fa[0][j0], SA[BO][0]); g2_lds_read<(j0 + 1) * 2048>(fa[0][j0 + 1], SA[BO][0]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(g2_wait_count(q, NQ, LA, MT, QB)));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) G2Mfma<T>::run(acc[i][j], fw[q % RS], fa[ks][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (q < 5) { if (kt + 1 < KT) piece(std::integral_constant<int, 3 + q>{}, kt + 1, BO); }
+                if constexpr (q >= QB) { if (kt + 2 < KT) piece(std::integral_constant<int, q - QB>{}, kt + 2, B); }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        for (;;) {
+            step(std::integral_constant<int, 0>{}); if (++kt == KT) break;
+            step(std::integral_constant<int, 1>{}); if (++kt == KT) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));        // (the epilogue's reads stay behind the padding: hipcc pads nothing behind an asm MFMA)
+    } else {
     const u16* a_src[4]; bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -128,22 +261,6 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
     };
-
-    // Accumulators start from the bias (this lane's output channels n_blk + wn*128 + i*16 + 4*(lane>>4) .. +3), so the epilogue has no bias
-    // loads: there each sat in its own `if (p.bias)` block followed by s_waitcnt vmcnt(0), which on gfx9 also drains the stores in flight.
-    // (split-K partial tiles start from zero: the reduce kernel adds the bias once.)
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        const int n = n_blk + wn * 128 + i * 16 + (lane >> 4) * 4;
-        if (p.bias && pp.splits == 1 && n < p.N) {
-            const u32x2 t = *reinterpret_cast<const u32x2*>(p.bias + n);
-            b = f32x4{El<T>::tof((u16)(t[0] & 0xffff)), El<T>::tof((u16)(t[0] >> 16)), El<T>::tof((u16)(t[1] & 0xffff)), El<T>::tof((u16)(t[1] >> 16))};
-        }
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = b;
-    }
 
     const int swz = (lane >> 1) & 7;
     const int frag_off0 = (lane & 15) * 128 + (((lane >> 4)) ^ swz) * 16;
@@ -202,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         for (int q = 0; q < 8; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
+    }
     }
     __syncthreads();
 
@@ -396,15 +514,24 @@ static int g2_fill(const Gemm2Args& a, G2Params& p) {
 
 constexpr int G2_CUS = 256;
 
+// the W8 loop addresses A and W with 32-bit byte offsets
+static bool g2_fits32(const G2Params& p) {
+    const long a_rows = p.a_seg ? (long)((p.M + p.a_seg - 1) / p.a_seg) * p.a_stride + p.a_off : (long)p.M + p.a_off;
+    return a_rows * p.lda * 2 < 0xfff00000L && (long)p.N * p.K * 2 < 0xfff00000L && a_rows >= 0;
+}
+
 template <typename T, int ACT>
 static int g2_launch_t(const G2Pair& pp, hipStream_t s, dim3 grid) {
     constexpr size_t lds = 2 * (256 * BK * 2 + 256 * BK * 2);
     static bool configured = false;
     if (!configured) {
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, ACT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm2_kernel<T, ACT>), grid, dim3(512), lds, s, pp);
+    const bool w8 = g_tune_gemm2_w8 && pp.splits == 1 && g2_fits32(pp.p[0]) && g2_fits32(pp.p[1]);
+    if (w8) hipLaunchKernelGGL((gemm2_kernel<T, ACT, true>), grid, dim3(512), lds, s, pp);
+    else hipLaunchKernelGGL((gemm2_kernel<T, ACT, false>), grid, dim3(512), lds, s, pp);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

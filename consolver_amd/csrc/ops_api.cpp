@@ -7,6 +7,7 @@ extern int g_tune_halo;
 extern int g_tune_conv_lw;
 extern int g_tune_gemm_w8;
 extern int g_tune_gemm_lw;
+extern int g_tune_gemm2_w8;
 extern int g_tune_attn_lw;
 extern int g_tune_debug;
 extern int g_tune_gemm_gm;
@@ -26,6 +27,7 @@ int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
     if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
     if (!strcmp(key, "gemm_lw")) { g_tune_gemm_lw = value; return CS_OK; }
+    if (!strcmp(key, "gemm2_w8")) { g_tune_gemm2_w8 = value; return CS_OK; }
     if (!strcmp(key, "attn_lw")) { g_tune_attn_lw = value; return CS_OK; }
     if (!strcmp(key, "gemm_w8")) { g_tune_gemm_w8 = value; return CS_OK; }
     if (!strcmp(key, "conv_lw")) { g_tune_conv_lw = value; return CS_OK; }

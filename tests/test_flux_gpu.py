@@ -51,6 +51,35 @@ def test_gemm2_and_bf16_attention_ops():
         assert rel_l2(o.float(), ref) < (2e-2 if dt == torch.bfloat16 else 3e-3), dt
 
 
+@pytest.mark.parametrize("M,K,N,act,gated,code", [(700, 512, 768, 1, True, 2), (256, 64, 256, 0, False, 1), (1500, 3072, 1024, 0, True, 2), (8704, 1024, 512, 1, False, 2),
+                                                  (300, 192, 1280, 0, False, 1), (4352, 12288, 768, 0, True, 2)])
+def test_gemm2_hand_scheduled_k_loop_matches(M, K, N, act, gated, code):
+    """the W8 instantiation of gemm2_kernel (buffer-load staging with clamped rows, counted waits, in-place asm MFMAs) multiplies the same fragments in the same
+    order as the compiler-scheduled loop: bit-identical, for both dtypes, every epilogue form, ragged M, one k step and long K"""
+    from consolver_amd import ops
+    dt = torch.bfloat16 if code == 2 else torch.float16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g).to(dt).to(DEV); w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+    b = torch.randn(N, generator=g).to(dt).to(DEV)
+    res = torch.randn(M, N, generator=g).to(dt).to(DEV) if gated else None
+    gate = torch.randn((M + 99) // 100, N, generator=g).to(DEV) if gated else None
+    outs = {}
+    for w8 in (1, 0):
+        ops.set_tuning("gemm2_w8", w8)
+        try:
+            out = torch.empty(M, N, dtype=dt, device=DEV)
+            L.check(L.lib().cs_op_gemm2(x.data_ptr(), M, K, w.data_ptr(), b.data_ptr(), N, L.ptr(res), L.ptr(gate), N, 100, act,
+                                        out.data_ptr(), N, 0, code, L.stream_ptr(x.device)))
+            outs[w8] = out
+        finally:
+            ops.set_tuning("gemm2_w8", 1)
+    v = x.float() @ w.float().T + b.float()
+    if act: v = torch.nn.functional.gelu(v, approximate="tanh")
+    ref = (res.float() + gate.repeat_interleave(100, 0)[:M] * v) if gated else v
+    assert rel_l2(outs[1].float(), ref) < (8e-3 if code == 2 else 1.5e-3)
+    assert torch.equal(outs[1], outs[0])
+
+
 def test_gemm2_pair_matches_two_single_launches():
     """grouped launch (image-stream + text-stream linear of one FLUX stage) == the two problems launched one by one, bit for bit"""
     import ctypes as C
