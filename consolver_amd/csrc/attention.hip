@@ -24,7 +24,7 @@
 int g_tune_attn_qt40 = 4;
 int g_tune_attn_prio = -1;
 extern int g_tune_debug;
-int g_tune_attn_lw = 1;        // 1: head dim 40 self-attention (Nq % 256 == 0, Nk % 64 == 0) runs attn40_lw_kernel (loader waves + hand-placed stream), 0: attn_kernel     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
+int g_tune_attn_lw = 1;        // 1: head dim 40 self-attention (Nq % 256 == 0, Nk % 64 == 0) runs attn40_lw_kernel (loader waves + hand-placed stream), 2: the same with 16x16x32 MFMAs for both k steps (bit-identical to attn_kernel), 0: attn_kernel     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
 
 namespace {
 
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int row
 //     redoes its 64 rows alone with a plain maxima-tracking loop straight from global memory (never seen on real inputs; tests force it).
 // Bit-identical to attn_kernel<f16, 40, 4> (same MFMA chains, same exponent arguments, same rounding, same accumulation order).
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) unsigned g_attn_ones_chunk[4] = {0x00003c00u, 0u, 0u, 0u};     // fp16 (1, 0, 0, 0, 0, 0, 0, 0)
+__device__ __attribute__((aligned(16))) unsigned g_attn_ones_chunk[8] = {0x00003c00u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};     // fp16 (1, 0, 0, 0, 0, 0, 0, 0) | eight zeros
 
 typedef const __attribute__((address_space(1))) void* a40_gptr;
 typedef __attribute__((address_space(3))) void* a40_lptr;
@@ -505,6 +505,11 @@ template <int OFF>
 __device__ __forceinline__ void a40_read_k(f16x8& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 template <int OFF>
 __device__ __forceinline__ void a40_read_vt(u32x2& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+template <int OFF>
+__device__ __forceinline__ void a40_read_k64(u32x2& d, unsigned addr) { asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
+__device__ __forceinline__ void a40_mfma16(f32x4& c, const u32x2& a, const u32x2& b) { asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+template <int N>
+__device__ __forceinline__ void a40_wait64(u32x2& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
 template <int N>
 __device__ __forceinline__ void a40_wait(f16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
 template <int N>
@@ -529,7 +534,10 @@ __device__ __forceinline__ void a40_for(F&& f) { a40_for_impl<N>(static_cast<F&&
 __device__ unsigned long long g_a40_trace[A40_TRACE_SLOTS * A40_TRACE_W];
 
 // DBG (TRACE builds only, results wrong): 1 steady loop without the exponentials / conversions, 2 without the MFMAs
-template <int NS, bool TRACE = false, int DBG = 0, int PAD = 0>
+// K16: the second k step of the scores (head dims 32..39 of 40) as v_mfma_f32_16x16x16_f16 on 64-bit fragments (head dims 32..47; K's pad chunk is zeros then)
+// instead of a 16x16x32 whose upper 24 k are padding: the same instruction count and matrix-pipe time, half the multiplies of a quarter of the MFMAs -- under the
+// board's power limit that is clock (profiles/r03_probe_exp.txt, mode 6).  The sums associate differently: not bit-identical to attn_kernel any more.
+template <int NS, bool TRACE = false, int DBG = 0, int PAD = 0, bool K16 = true>
 __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     unsigned long long te0 = 0;
     if (TRACE) te0 = __builtin_amdgcn_s_memrealtime();
@@ -560,7 +568,8 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
         for (int j = 0; j < 3; ++j) {
             const int q = l + 4 * j, kv = q >= 6 ? 1 : 0, pq = q - 6 * kv;
             const int off = pq * 1024 + lane * 16, row = off / RS, ch = (off - row * RS) >> 4;
-            if (!kv) { src[j] = reinterpret_cast<const char*>(kbase + (size_t)row * p.k_stride + (ch == 5 ? 0 : ch) * 8); step[j] = (size_t)64 * p.k_stride * 2; }
+            if (!kv && ch == 5 && K16) { src[j] = reinterpret_cast<const char*>(g_attn_ones_chunk + 4); step[j] = 0; }        // (zeros: the 16x16x16 step multiplies head dims 40..47)
+            else if (!kv) { src[j] = reinterpret_cast<const char*>(kbase + (size_t)row * p.k_stride + (ch == 5 ? 0 : ch) * 8); step[j] = (size_t)64 * p.k_stride * 2; }
             else if (ch < 5) { src[j] = reinterpret_cast<const char*>(vbase + (size_t)row * p.v_stride + ch * 8); step[j] = (size_t)64 * p.v_stride * 2; }
             else { src[j] = reinterpret_cast<const char*>(g_attn_ones_chunk); step[j] = 0; }
         }
@@ -592,25 +601,38 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     // =============================== compute waves ===============================
     if (p.prio) __builtin_amdgcn_s_setprio(1);                 // (cs_set_tuning("attn_prio", 1): static priority over the loader partner; measured)
     const int q0 = qblk * 256 + w * 64;
-    f16x8 qf[4][2];
+    f16x8 qf[4][2];                     // B operands of the score MFMAs: head dims 0..31 (and, without K16, 32..63 with 40.. zero)
+    u32x2 qh[4];                        // K16: head dims 32 + 4 g .. + 3 as the 16x16x16 step's B operand (g >= 2: zero)
+    auto load_qf = [&](int t, int ks) {                                          // Q fragment pre-scaled by scale * log2(e)
+        const int qrow = q0 + t * 16 + i16, d = ks * 32 + 8 * g;
+        u32x4 v = {0, 0, 0, 0};
+        if (d < DH) {
+            v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = pack2<f16>(El<f16>::tof((u16)(v[e] & 0xffff)) * p.c, El<f16>::tof((u16)(v[e] >> 16)) * p.c);
+        }
+        return as_frag<f16>(v);
+    };
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int qrow = q0 + t * 16 + i16;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int d = ks * 32 + 8 * g;
-            u32x4 v = {0, 0, 0, 0};
+        qf[t][0] = load_qf(t, 0);
+        if constexpr (!K16) { qf[t][1] = load_qf(t, 1); qh[t] = u32x2{0, 0}; }
+        else {
+            qf[t][1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            const int qrow = q0 + t * 16 + i16, d = 32 + 4 * g;
+            u32x2 v = {0, 0};
             if (d < DH) {
-                v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+                v = *reinterpret_cast<const u32x2*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 2; ++e)
                     v[e] = pack2<f16>(El<f16>::tof((u16)(v[e] & 0xffff)) * p.c, El<f16>::tof((u16)(v[e] >> 16)) * p.c);
             }
-            qf[t][ks] = as_frag<f16>(v);
+            qh[t] = v;
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));     // (the conversions above complete in front of the asm MFMAs that read them)
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]), "+v"(qh[t]));     // (the conversions above complete in front of the asm MFMAs that read them)
     asm volatile("s_nop 7" ::: "memory");
     f32x4 o_acc[3][4];
 #pragma unroll
@@ -622,6 +644,8 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     f32x4 negm[4];
     float m_run[4];
     f16x8 kf[4];                        // K fragments of the NEXT unit: (kt', ks) = (0,0) (0,1) (1,0) (1,1)
+    u32x2 kh[2];                        // K16: the ks = 1 fragments as 64-bit operands (head dims 32 + 4 g .. + 3 of key tile kt')
+    const unsigned g8 = (unsigned)g * 8;
     u32x2 vlo[3], vhi[3];               // V^T fragments (a = 0..2) of the unit whose P V product runs in the next slot
     const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned kl = sbase + i16 * RS + g * 16;
@@ -657,14 +681,19 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
         };
         auto s_group = [&](auto j_tag) {                      // j = kt' * 2 + ks
             constexpr int J = decltype(j_tag)::value, KT = J / 2, KS = J % 2, G = 2 * J;
-            a40_wait<9>(kf[J]);
+            constexpr bool H16 = K16 && KS == 1;              // this group's fragment is the 64-bit one
+            if constexpr (H16) a40_wait64<9>(kh[KT]); else a40_wait<9>(kf[J]);
             a40_for<4>([&](auto t_tag) {
                 constexpr int T = decltype(t_tag)::value;
-                if constexpr (DO_S == 1) { if constexpr (KS == 0) a40_mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]); else a40_mfma(sc[PAR][KT][T], kf[J], qf[T][1]); }
-                if constexpr (DO_S == 2) { if constexpr (KS == 0) a40_mfma_z(sc[PAR][KT][T], kf[J], qf[T][0]); else a40_mfma(sc[PAR][KT][T], kf[J], qf[T][1]); }
+                if constexpr (DO_S != 0) {
+                    if constexpr (KS == 0) { if constexpr (DO_S == 1) a40_mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]); else a40_mfma_z(sc[PAR][KT][T], kf[J], qf[T][0]); }
+                    else if constexpr (H16) a40_mfma16(sc[PAR][KT][T], kh[KT], qh[T]);
+                    else a40_mfma(sc[PAR][KT][T], kf[J], qf[T][1]);
+                }
                 filler(std::integral_constant<int, G * 4 + T>{});
             });
-            a40_read_k<(2 * H2 + KT) * 16 * RS + KS * 64>(kf[J], ka);
+            if constexpr (H16) a40_read_k64<(2 * H2 + KT) * 16 * RS + 64>(kh[KT], ka - g8);
+            else a40_read_k<(2 * H2 + KT) * 16 * RS + KS * 64>(kf[J], ka);
         };
         auto p_group = [&](auto a_tag) {
             constexpr int A = decltype(a_tag)::value, G = 2 * A + 1;
@@ -699,6 +728,7 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     // (the priming slot only issues the reads of a slot, so that every counted wait below sees the steady-state history; its waits are trivially true)
 #pragma unroll
     for (int j = 0; j < 4; ++j) kf[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    kh[0] = u32x2{0, 0}; kh[1] = u32x2{0, 0};
 #pragma unroll
     for (int a = 0; a < 3; ++a) { vlo[a] = u32x2{0, 0}; vhi[a] = u32x2{0, 0}; }
     slot(I1{}, I0{}, BF{}, BF{}, kl, vl);                                         // reads K(unit 0)
@@ -776,6 +806,7 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");   // the slot's own trailing reads land before their registers are reused
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(kf[j]));
+    asm volatile("" : "+v"(kh[0]), "+v"(kh[1]));
 #pragma unroll
     for (int a = 0; a < 3; ++a) asm volatile("" : "+v"(vlo[a]), "+v"(vhi[a]));
 #pragma unroll
@@ -807,7 +838,7 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
                 for (int t = 0; t < 4; ++t) {
                     const float nm = tile == 0 ? 0.f : -m_run[t];
                     s2[kt][t] = El<f16>::mfma(as_frag<f16>(k0), qf[t][0], f32x4{nm, nm, nm, nm});
-                    s2[kt][t] = El<f16>::mfma(as_frag<f16>(k1), qf[t][1], s2[kt][t]);
+                    s2[kt][t] = El<f16>::mfma(as_frag<f16>(k1), K16 ? load_qf(t, 1) : qf[t][1], s2[kt][t]);
                 }
             }
 #pragma unroll
@@ -937,10 +968,11 @@ int launch_attn40_lw(AttnParams p, int B, hipStream_t s) {
     constexpr size_t lds = (size_t)A40_NS * 12288;
     const bool trace = (g_tune_debug & 16384) != 0;
     auto kfn = trace ? ((g_tune_debug & 1) ? attn40_lw_kernel<A40_NS, true, 1> : (g_tune_debug & 2) ? attn40_lw_kernel<A40_NS, true, 2> : attn40_lw_kernel<A40_NS, true>)
-                     : attn40_lw_kernel<A40_NS, false>;
+                     : g_tune_attn_lw == 2 ? attn40_lw_kernel<A40_NS, false, 0, 0, false> : attn40_lw_kernel<A40_NS, false>;
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, false, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

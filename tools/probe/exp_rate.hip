@@ -8,6 +8,8 @@
 //   mode 3: blocked: 28 MFMAs, then the 48 VALU instructions
 //   mode 4: blocked, waves 4-7 run the VALU block FIRST: SIMD partners in anti-phase (two waves per SIMD only)
 //   mode 5: packed-fp16 polynomial exp2 in the interleaved stream (8 packed instructions per two values; numerically unusable)
+//   mode 6: mode 2 with the second k step of the score MFMAs (head dim 32..39 of 40) as v_mfma_f32_16x16x16_f16: same instruction count and pipe time, half the
+//           multiplies of those 16 instructions -- does the lower energy buy clock?  (compare the ms column, not the cycles)
 // waves per SIMD: 1 (256-thread workgroup, one per CU) or 2 (512 threads); one s_barrier per two slots in every mode.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/probe/bin/exp_rate tools/probe/exp_rate.hip
 #include <hip/hip_runtime.h>
@@ -22,6 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void mfma_ip(f32x4& c, const f16x8& a, const f16x8& b) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_ip16(f32x4& c, const f16x4& a, const f16x4& b) { asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void mfma_c(f32x4& d, const f16x8& a, const f16x8& b, const f32x4& c) { asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 #define p_exp(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 #define p_cvt(d, a, b) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
@@ -88,7 +92,11 @@ __global__ __launch_bounds__(WPS * 256) void slot_kernel(int slots2, float* sink
         constexpr int PAR = decltype(par_tag)::value, M = decltype(m_tag)::value, G = M / 4, T = M % 4;
         if constexpr (G % 2 == 0) {
             constexpr int J = G / 2, KT = J / 2, KS = J % 2;
-            if constexpr (KS == 0) mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]); else mfma_ip(sc[PAR][KT][T], kf[J], qf[T][1]);
+            if constexpr (KS == 0) mfma_c(sc[PAR][KT][T], kf[J], qf[T][0], negm[T]);
+            else if constexpr (MODE == 6) {
+                const f16x4 a4 = {kf[J][0], kf[J][1], kf[J][2], kf[J][3]}, b4 = {qf[T][1][0], qf[T][1][1], qf[T][1][2], qf[T][1][3]};
+                mfma_ip16(sc[PAR][KT][T], a4, b4);
+            } else mfma_ip(sc[PAR][KT][T], kf[J], qf[T][1]);
         } else {
             constexpr int A = G / 2;
             union { u32x4 u; f16x8 f; } b; b.u = pfw[PAR][T];
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(WPS * 256) void slot_kernel(int slots2, float* sink
         using SP = std::integral_constant<int, 1 - PAR>;
         if constexpr (MODE == 0) sfor<28>([&](auto m) { mfma_m(par_tag, m); });
         else if constexpr (MODE == 1) sfor<48>([&](auto q) { e_instr(SP{}, q); });
-        else if constexpr (MODE == 2 || MODE == 5) {
+        else if constexpr (MODE == 2 || MODE == 5 || MODE == 6) {
             sfor<28>([&](auto m) {
                 constexpr int M = decltype(m)::value, LO = 48 * M / 28, HI = 48 * (M + 1) / 28;
                 mfma_m(par_tag, m);
@@ -148,8 +156,8 @@ static void run(float* sink, unsigned long long* cyc, const char* tag) {
     (void)hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double per_tile = (double)h[128] / slots2;              // two slots = one 64-key tile of one wave
-    printf("%-72s %d wave(s) / SIMD : %7.1f cycles per 64-key tile and wave = %7.1f of SIMD time per wave-tile (56 MFMAs = 896) | clock %.2f GHz\n", tag, WPS, per_tile,
-           per_tile / WPS, (double)h[128] / (ms * 1e-3) / 1e9);
+    printf("%-72s %d wave(s) / SIMD : %7.1f cycles per 64-key tile and wave = %7.1f of SIMD time per wave-tile (56 MFMAs = 896) | clock %.2f GHz | %.3f ms\n", tag, WPS, per_tile,
+           per_tile / WPS, (double)h[128] / (ms * 1e-3) / 1e9, ms);
 }
 
 int main() {
@@ -160,6 +168,9 @@ int main() {
     run<2, 1>(sink, cyc, "2 interleaved (1-2 VALU behind every MFMA)");
     run<3, 1>(sink, cyc, "3 blocked (28 MFMAs, then 48 VALU)");
     run<5, 1>(sink, cyc, "5 interleaved, packed-fp16 polynomial exp2");
+    run<6, 1>(sink, cyc, "6 interleaved, k step 2 of the scores as 16x16x16");
+    run<2, 1>(sink, cyc, "2 interleaved (again)");
+    run<6, 1>(sink, cyc, "6 interleaved, k step 2 of the scores as 16x16x16 (again)");
     run<0, 2>(sink, cyc, "0 MFMAs only");
     run<1, 2>(sink, cyc, "1 v_exp_f32 x 64 + v_cvt_pk_f16_f32 x 32 only");
     run<2, 2>(sink, cyc, "2 interleaved");
