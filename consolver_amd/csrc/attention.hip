@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p, int row
 //     for LDS;
 //   * the reference maximum of the softmax is the first tile's column maximum (as in attn_kernel's FAST path); a wave whose denominators come out non-finite
 //     redoes its 64 rows alone with a plain maxima-tracking loop straight from global memory (never seen on real inputs; tests force it).
-// Bit-identical to attn_kernel<f16, 40, 4> (same MFMA chains, same exponent arguments, same rounding, same accumulation order).
+// With K16 = false bit-identical to attn_kernel<f16, 40, 4> (same MFMA chains, same exponent arguments, same rounding, same accumulation order); the default K16 form sums
+// head dims 32..39 in a 16x16x16 MFMA (another association of the same products).
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned g_attn_ones_chunk[8] = {0x00003c00u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};     // fp16 (1, 0, 0, 0, 0, 0, 0, 0) | eight zeros
 
