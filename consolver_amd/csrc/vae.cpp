@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cmath>
 
+extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
+
 namespace {
 
 struct HostT { std::vector<int64_t> shape; std::vector<f16> data; };
@@ -173,6 +175,26 @@ bool make_conv_padded64(CsVae* v, const std::string& p, VConv& c) {
 struct Run {
     CsVae* v; hipStream_t s; bool dry; int B; int rc = CS_OK;
     float* gn_ws = nullptr;
+    // GroupNorm statistics a conv left for its output (IgemmArgs::gn_stats, [B][HW/64][C/2][2] partial sums): three rotating buffers are enough, a tensor is
+    // normalised at most two convolutions after it was written (x -> conv1 -> conv2 (+ shortcut) -> next resnet)
+    float* st_buf[3] = {nullptr, nullptr, nullptr}; const f16* st_of[3] = {nullptr, nullptr, nullptr}; int st_S[3] = {0, 0, 0}; int st_next = 0;
+    size_t st_floats = 0;
+    void init_stats(size_t floats) {
+        if (!g_tune_gn_fuse) return;
+        st_floats = floats;
+        for (auto& b : st_buf) b = (float*)alloc(floats * 2);           // (alloc counts halfs)
+    }
+    float* stats_for_output(const f16* out, int HW, int C) {
+        if (!st_buf[0] || HW % 64 || C % 2 || (size_t)B * (HW / 64) * C > st_floats) return nullptr;
+        const int k = st_next; st_next = (st_next + 1) % 3;
+        st_of[k] = out; st_S[k] = HW / 64;
+        return st_buf[k];
+    }
+    const float* stats_of(const f16* x, int* S) const {
+        for (int k = 0; k < 3; ++k) if (st_of[k] == x && x) { *S = st_S[k]; return st_buf[k]; }
+        return nullptr;
+    }
+    void forget_stats(const f16* t) { for (auto& o : st_of) if (o == t) o = nullptr; }      // the tensor is about to be overwritten by something that leaves no statistics
 
     f16* alloc(size_t halfs) {
         void* p = v->arena.alloc(halfs * sizeof(f16));
@@ -187,23 +209,30 @@ struct Run {
         IgemmArgs a{};
         a.a0 = x; a.c0 = c.cin; a.B = B; a.Hi = H; a.Wi = W; a.Ho = up ? 2 * H : H; a.Wo = up ? 2 * W : W; a.taps = c.taps; a.stride = 1;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.res = res; a.out = out;
-        launch(igemm_flops(a), [&] { return launch_igemm(a, s); });
+        forget_stats(out);
+        a.gn_stats = c.taps == 9 ? stats_for_output(out, a.Ho * a.Wo, c.cout) : nullptr;
+        launch(igemm_flops(a), [&] { return launch_igemm(a, s); });             // (a kernel without a statistics epilogue is followed by a statistics pass in the same layout)
     }
     void conv_down(const VConv& c, const f16* x, int H, int W, f16* out) {       // pad (0,1,0,1) + 3x3 stride 2 (encoder downsample)
         IgemmArgs a{};
         a.a0 = x; a.c0 = c.cin; a.B = B; a.Hi = H; a.Wi = W; a.Ho = H / 2; a.Wo = W / 2; a.taps = 9; a.stride = 2; a.pad_after_only = 1;
         a.N = c.cout; a.w = c.w; a.bias = c.b; a.out = out;
+        forget_stats(out);
         launch(igemm_flops(a), [&] { return launch_igemm(a, s); });
     }
     void gemm(const f16* x, int M, int K, const f16* w, const f16* b, int N, const f16* res, f16* out) {
         IgemmArgs a{};
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res; a.out = out;
+        forget_stats(out);
         launch(igemm_flops(a), [&] { return launch_igemm(a, s); });
     }
     void group_norm(const VNorm& n, const f16* x, int HW, bool silu, f16* out) {
         GroupNormArgs a{};
         a.x0 = x; a.c0 = n.c; a.B = B; a.HW = HW; a.groups = v->cfg.norm_num_groups; a.eps = 1e-6f; a.silu = silu;
         a.gamma = n.g; a.beta = n.b; a.partial = gn_ws; a.out = out; a.splits = VAE_GN_SPLITS;
+        int S = 0;
+        if (const float* st = stats_of(x, &S)) { a.stats0 = st; a.S0 = S; }
+        forget_stats(out);
         launch(0, [&] { return launch_group_norm(a, s); });
     }
     // x [B,HW,cin] -> out [B,HW,cout]; n/h are scratch of the larger channel count
@@ -270,6 +299,7 @@ int run_decode(CsVae* v, bool dry, const f16* latents, int B, float in_scale, fl
     f16* z = R.alloc((size_t)B * (wide ? 64 : L) * H * W);
     f16* bufs[4];
     for (auto& b : bufs) b = R.alloc((size_t)B * maxact);
+    R.init_stats((size_t)B * (maxact / 64));
     if (R.rc != CS_OK) return R.rc;
     f16 *x = bufs[0], *y = bufs[1], *n = bufs[2], *h = bufs[3];
 
@@ -319,6 +349,7 @@ int run_encode(CsVae* v, bool dry, const f16* images, int B, float out_scale, fl
     for (auto& b : bufs) b = R.alloc((size_t)B * maxact);
     const int mo = c.use_quant_conv ? 2 * L : L;
     f16* mom = R.alloc((size_t)B * mo * c.sample_size * c.sample_size);
+    R.init_stats((size_t)B * (maxact / 64));
     if (R.rc != CS_OK) return R.rc;
     f16 *x = bufs[0], *y = bufs[1], *n = bufs[2], *h = bufs[3];
     R.launch(0, [&] { return launch_latent_to_nhwc64(images, nullptr, nullptr, n, B, c.out_channels, H * W, 1.0f, 0.0f, s); });

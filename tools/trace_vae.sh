@@ -13,7 +13,7 @@ fw = rows[idx[-1]:]
 agg = collections.OrderedDict()
 for r in fw:
     name = r["Kernel_Name"]
-    mm = re.search(r"(conv3_halo_kernel<[^>]*>|gemm_big_kernel<[^>]*>|igemm_kernel<[^>]*>|splitk_reduce_kernel)", name)
+    mm = re.search(r"(conv3_halo_kernel<[^>]*>|conv3_lw_kernel<[^>]*>|gemm_w8_kernel<[^>]*>|gemm_lw_kernel|gemm_big_kernel<[^>]*>|igemm_kernel<[^>]*>|splitk_reduce_kernel)", name)
     short = mm.group(1) if mm else re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", name)[:36]
     key = (short, r.get("Grid_Size_X", r.get("Grid_Size", "")))
     agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
