@@ -10,7 +10,9 @@ lib = L.lib()
 EXTRA = int(os.environ.get("CS_TIMELINE_DEBUG", "0"))      # extra debug bits (e.g. the touch distance << 20) for the stamped launches
 dev = torch.device("cuda:0")
 shapes = [("qkv L0", 131072, 320, 960, False, False), ("out+res L0", 131072, 320, 320, True, False), ("ff1 geglu L0", 131072, 320, 2560, False, True),
-          ("ff2+res L0", 131072, 1280, 320, True, False), ("qkv L1", 32768, 640, 1920, False, False)]
+          ("ff2+res L0", 131072, 1280, 320, True, False), ("qkv L1", 32768, 640, 1920, False, False),
+          ("out+res L1 (one round)", 32768, 640, 640, True, False), ("to_q L1 (one round)", 32768, 640, 640, False, False)]
+if os.environ.get("CS_TIMELINE_ONLY"): shapes = [sh for sh in shapes if os.environ["CS_TIMELINE_ONLY"] in sh[0]]
 for tag, M, K, N, res, geglu in shapes:
     x = torch.randn(M, K, device=dev, dtype=torch.float16)
     w = torch.randn(N, K, device=dev, dtype=torch.float16) * 0.05
@@ -55,7 +57,7 @@ for tag, M, K, N, res, geglu in shapes:
         firsts.append(us[o[0], 0])
         for a, b2 in zip(o[:-1], o[1:]):
             gaps.append(us[b2, 0] - us[a, 4])
-    gaps = np.array(gaps)
+    gaps = np.array(gaps if gaps else [0.0])
     print("   per-CU turnaround (previous workgroup drained -> next workgroup's entry), us: median %.2f  p10 %.2f  p90 %.2f ; first entry median %.2f us"
           % (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90), np.median(firsts)))
     # spread of phases across the chip: how synchronised are the CUs?  (std of the epilogue start times modulo the period, first round)
