@@ -128,6 +128,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "gemm_w8":   1 (default) the 256x320 GEMM runs its hand-scheduled k loop (gemm_w8_kernel; needs 32-bit operand offsets), 0 the
  *                compiler-scheduled gemm_big_kernel (bit-identical results);
  *   "gemm_lw":   1 (default) layers served by the 256x160 GEMM tile run the loader-wave kernel (gemm_lw_kernel), 0 gemm_big_kernel<.,160>;
+ *   "gemm2_w8":  1 (default) cs_op_gemm2 / cs_op_gemm2_pair run the hand-scheduled k loop of gemm2_kernel where 32-bit operand offsets suffice (bit-identical),
+ *                0 the compiler-scheduled loop;
  *   "attn_lw":   1 (default) head dim 40 self-attention with Nq % 256 == 0 and Nk % 64 == 0 runs attn40_lw_kernel, 2 the same with 16x16x32 MFMAs for both
  *                score k steps (bit-identical to attn_kernel), 0 attn_kernel;
  *   "gemm_gm":   tile order of the 256-row GEMM kernel: -1 (default) bands of 4 tile rows when there are >= 12 tile columns, 0 / 1 row-major, n bands of n;
