@@ -11,6 +11,6 @@ for sec in conv gemm attn; do
   done
 done
 cd $R
-for sec in conv gemm attn; do echo "== $sec"; python3 tools/pmc_summary.py gpurun_out/pmc_k/$sec | grep -A1 -E "conv3_halo|gemm_big|attn_kernel|igemm_kernel" | head -60; done > gpurun_out/pmc_kernels.txt
+for sec in conv gemm attn; do echo "== $sec"; python3 tools/pmc_summary.py gpurun_out/pmc_k/$sec | grep -A1 -E "conv3_halo|conv3_lw|gemm_big|gemm_w8|gemm_lw|attn_kernel|attn40_lw|igemm_kernel" | head -60; done > gpurun_out/pmc_kernels.txt
 rm -rf gpurun_out/pmc_k gpurun_out/pmc_k_*.log
 wc -l gpurun_out/pmc_kernels.txt
