@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 MFMA (MI355X_MICROARCH.md)
+DEFAULT_RESIDUAL = "f16x2"
 
 
 def usable_cores():
@@ -49,11 +50,14 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
     from consolver_amd.synth import synthetic_prompt_embeds
     cores = usable_cores()
     torch.set_num_threads(cores)
-    orc = UNetOracle(sd, cfg, round_weights_to_f16=False)
+    # weights rounded to fp16 once, arithmetic fp32: the reference pipeline's weights ARE fp16 (gen_ppo.py:193-195), and with them the latents this
+    # leg produces are the fp32 reference the HIP engine's latents are gated against (`parity` in the JSON line).  Same CPU time either way.
+    orc = UNetOracle(sd, cfg, round_weights_to_f16=True)
     g = torch.Generator().manual_seed(43)
     S = cfg["sample_size"]
-    lat = torch.randn(1, 4, S, S, generator=g).numpy()
-    ctx = torch.cat([synthetic_prompt_embeds(1, seed=1002), synthetic_prompt_embeds(1, seed=1001)])
+    lat = torch.randn(1, 4, S, S, generator=g).half().float().numpy()      # fp16-representable inputs: both sides start from identical values
+    noise0 = lat.copy()
+    ctx = torch.cat([synthetic_prompt_embeds(1, seed=1002), synthetic_prompt_embeds(1, seed=1001)]).half().float()
     gw = torch.Generator().manual_seed(20251226)
     w = {}
     for k, shp in (("mlp.0.weight", (256, 2)), ("mlp.0.bias", (256,)), ("mlp.2.weight", (256, 256)), ("mlp.2.bias", (256,)),
@@ -64,9 +68,11 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
     sch.set_timesteps(steps_total)
     rng = np.random.default_rng(0)
     done, t0 = 0, time.perf_counter()
+    idx_used = []
     for i, t in enumerate(sch.timesteps):
         e = orc(torch.from_numpy(np.concatenate([lat, lat])), int(t), ctx).numpy()
-        lat = sch.step(so.cfg_combine(e[:1], e[1:], guidance), int(t), lat, rng.integers(0, 11, size=(1, 3)))["prev_sample"]
+        idx_used.append(rng.integers(0, 11, size=(1, 3)))
+        lat = sch.step(so.cfg_combine(e[:1], e[1:], guidance), int(t), lat, idx_used[-1], cond_dtype="f16")["prev_sample"]
         done += 1
         el = time.perf_counter() - t0
         if el / done * (done + 1) > budget_s:
@@ -84,6 +90,39 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
         dec = time.perf_counter() - t1
         out["pixel_images_per_s"] = 1.0 / (per_image + dec)
         out["sample"] += f"; + 1 VAE decode fp32 ({dec:.1f} s) for pixel_images_per_s"
+    # private hand-over to parity_vs_oracle (popped before the record is printed): the fp32 reference latents after `done` steps and their inputs
+    out["_replay"] = {"latents": lat, "noise": noise0, "ctx": ctx, "idx": idx_used, "weights": w, "steps_done": done, "steps_total": steps_total}
+    return out
+
+
+def parity_vs_oracle(unet, replay, guidance, dev, modes):
+    """`latent L2 vs ref`, the second half of BASELINE.json's metric: configs[0]'s inputs (1 prompt, 8 steps, CFG 3, the noise / prompt embeddings /
+    replayed action indices / policy weights of the cpu_baseline leg) through the HIP engine on the GPU, relative L2 of the final latents against the
+    fp32 oracle latents that leg just produced.  No extra oracle time.  north_star gate: 1e-3."""
+    import consolver_amd
+    import numpy as np
+    n_done, n = replay["steps_done"], replay["steps_total"]
+    out = {"gate": 1e-3, "config": f"configs[0] inputs (1 prompt, CFG 3, replayed action indices), {n_done} of {n} solver steps, "
+                                   "fp16 HIP engine vs the fp32 CPU oracle (relative L2 of the latents)"}
+    want = torch.from_numpy(replay["latents"]).double()
+    keep = unet.residual
+    for mode in modes:
+        unet.set_residual_precision(mode)
+        sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
+                                         order_dim=4, scaler_dim=0, factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=11))
+        sch.factor_net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in replay["weights"].items()}, strict=False)
+        sch.factor_net.to(dev)
+        sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(dev) for i in replay["idx"]]
+        sch.set_timesteps(n, device=dev)
+        x = torch.from_numpy(replay["noise"]).half().to(dev)
+        ctx = replay["ctx"].half().to(dev)
+        for i, t in enumerate(sch.timesteps[:n_done]):
+            eps = unet(x, t, encoder_hidden_states=ctx, dup=2, reuse_kv=(i > 0))[0]
+            x = sch.step(eps[1:], t, x, return_dict=False, eps_uncond=eps[:1], guidance_scale=guidance)[0]
+        got = x.double().cpu()
+        out[mode] = float((got - want).norm() / want.norm())
+    unet.set_residual_precision(keep)
+    unet.invalidate_kv()
     return out
 
 
@@ -252,13 +291,20 @@ def dry_run(args):
         all_b = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(all_b, torch.tensor([lo, hi], dtype=torch.int64))
         bounds = [b.tolist() for b in all_b]
+    # the same per-rank record main() gathers over RCCL (rank, local rank, device stand-in, images, elapsed, shard, checksum stand-in)
+    from consolver_amd.launch import gather_rank_records
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rows = gather_rank_records(dist, [rank, local, local, B * args.steps, 0.001 * (rank + 1), lo, hi, float(lo + hi)])
+    assert len(rows) == world
+    per_rank = [{"rank": int(r[0]), "local_rank": int(r[1]), "device": int(r[2]), "images": int(r[3]), "elapsed_s": r[4],
+                 "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7]} for r in rows]
     # what main() runs OUTSIDE the timed region on this launch: the cpu_baseline leg and the sub-record extras are N = 1 only (same conditions as in
     # main()), so an 8-GPU timed region and its barriers see nothing but the sampling loop
     side_work = {"cpu_baseline": world == 1 and not args.no_cpu_baseline, "extras": world == 1 and bool(args.extras),
                  "ceilings": world == 1 and bool(args.ceilings), "kernel_profile_pass": rank == 0 and bool(args.profile_kernels)}
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                          "images": B * world * args.steps, "max_elapsed_s": elapsed, "shards": bounds,
+                          "images": B * world * args.steps, "max_elapsed_s": elapsed, "shards": bounds, "per_rank": per_rank,
                           "local_rank_env": os.environ.get("LOCAL_RANK"), "cuda_initialised": torch.cuda.is_initialized(),
                           "side_work_after_timed_region": side_work}))
     if dist is not None:
@@ -280,6 +326,10 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=1, help="extra untimed pass with per-kernel-class HIP events")
     ap.add_argument("--extras", type=int, default=1, help="1 (N = 1 only): also measure configs[2] per-GPU shape, configs[3] (full FLUX edit), "
                     "configs[4] (PPO rollout iteration) and the solver kernels, reported as sub-records of the same JSON line")
+    ap.add_argument("--residual", default=DEFAULT_RESIDUAL, choices=["f16", "f16x2", "residual_fp32"],
+                    help="residual-stream storage of the UNet executor for the headline number (include/consolver_hip.h CS_RESIDUAL_*): f16x2 "
+                         "(split-fp16, meets the 1e-3 latent gate) or f16 (one plane, the reference pipeline's own arithmetic class); the other "
+                         "mode is timed too and reported under `residual_modes`")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch / rendezvous / sharding / reduction path without touching a GPU")
     args = ap.parse_args()
 
@@ -315,7 +365,9 @@ def main():
     from consolver_amd.launch import shard_bounds
     from consolver_amd.vae import HipAutoencoderKL
 
-    unet = HipUNet2DConditionModel(device=dev)
+    headline_mode = "f16x2" if args.residual in ("f16x2", "residual_fp32") else "f16"
+    other_mode = "f16" if headline_mode == "f16x2" else "f16x2"
+    unet = HipUNet2DConditionModel(device=dev, residual=headline_mode)
     sd = synthetic_unet_state_dict(unet.manifest(), seed=20251226)
     unet.load_state_dict(sd)
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -360,11 +412,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all()
+
+    # ---- N > 1: every rank's own record, gathered over RCCL (proves the collective saw `world` ranks on `world` distinct devices) ----
+    per_rank = None
+    if dist is not None:
+        from consolver_amd.launch import gather_rank_records
+        mine = [float(rank), float(local), float(torch.cuda.current_device()), float(B * args.steps), float(elapsed_local), float(lo), float(hi),
+                float(out.float().abs().sum().item())]
+        rows = gather_rank_records(dist, mine, dev)
+        assert len(rows) == world, (len(rows), world)
+        per_rank = [{"rank": int(r[0]), "local_rank": int(r[1]), "device": int(r[2]), "images": int(r[3]), "elapsed_s": r[4],
+                     "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7]} for r in rows]
+        assert sorted(p["rank"] for p in per_rank) == list(range(world)) and len({p["device"] for p in per_rank}) == world, per_rank
 
     # ---- roofline of the dominant unit: the UNet forward (MFMA bound), HIP events on the launch stream -------
     eff_batch = 2 * B if args.guidance > 1 else B
@@ -419,6 +484,29 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": "unet_forward (all kernels of one CFG dual-batch denoiser call)",
                 "launch_ms": fwd_ms, "flops_per_launch": flops_fwd, "flops_executed_per_launch": flops_exec}
 
+    # ---- the other residual-stream mode, same K generations, same box, same process (N = 1 only: nothing else may sit between an 8-GPU run's barriers) ----
+    modes = {headline_mode: {"images_per_s": B * world * args.steps / elapsed, "unet_forward_ms": fwd_ms, "roofline_frac": achieved / PEAK_F16_TFLOPS,
+                             "headline": True}}
+    if world == 1 and not args.graph:
+        unet.set_residual_precision(other_mode)
+        one(); torch.cuda.synchronize()
+        eng.forward_events = []
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            o2 = one()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        f2 = sum(a.elapsed_time(b) for a, b in eng.forward_events) / len(eng.forward_events)
+        eng.forward_events = None
+        assert torch.isfinite(o2).all()
+        modes[other_mode] = {"images_per_s": B * args.steps / el2, "unet_forward_ms": f2, "roofline_frac": flops_fwd / (f2 * 1e-3) / 1e12 / PEAK_F16_TFLOPS,
+                             "headline": False}
+        unet.set_residual_precision(headline_mode)
+        one(); torch.cuda.synchronize()                    # workspace of the headline mode back in place for the passes below
+    modes["note"] = ("residual-stream storage of the UNet executor (include/consolver_hip.h): f16x2 = split-fp16 hi + lo planes, fp32-class adds along "
+                     "the stream, meets the 1e-3 latent gate; f16 = one plane, the reference fp16 pipeline's own arithmetic class, 1.4e-3.  GEMM operands are "
+                     "fp16 in both.")
+
     kernels = None
     if args.profile_kernels and rank == 0:
         unet.set_profiling(True)
@@ -470,12 +558,15 @@ def main():
             "metric": "images/sec at 8-step ConsistencySolver 512x512 (final latents; SD1.5 UNet fp16 + PPOScheduler, CFG 3)",
             "value": images / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic (seeded weights, prompt embeddings and noise of the SD1.5 shapes)",
+            "dtype": "f16", "residual_stream": headline_mode, "data": "synthetic (seeded weights, prompt embeddings and noise of the SD1.5 shapes)",
             "config": {"workload": "configs[1]: SD1.5 + PPOScheduler 8-step fp16, batch 16, 512x512 on 1 MI355X",
                        "batch_per_gpu": B, "num_inference_steps": n, "guidance_scale": args.guidance, "order_dim": 4,
                        "parallelism": f"dp{world} (prompt shards, no data-path collective)", "hipgraph": bool(args.graph)},
             "roofline": roofline,
+            "residual_modes": modes,
         }
+        if per_rank is not None:
+            rec["per_rank"] = per_rank
         if decode_ms is not None:
             rec["pixel_images_per_s"] = images / pixel_elapsed          # latents + AutoencoderKL decode (row f-1), own timed loop
             rec["vae_decode"] = {"ms_per_batch": decode_ms, "tflops": vae.flops(B) / (decode_ms * 1e-3) / 1e12,
@@ -489,8 +580,18 @@ def main():
             rec["roofline"]["frac_of_vendor_gemm"] = achieved / ceilings["vendor_gemm_f16_8192_tflops"]
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance, vae_sd=vae_sd)
+            # "latent L2 vs ref" (the metric's second half): the HIP engine on the inputs of the CPU leg, against the fp32 latents it just produced
+            replay = rec["cpu_baseline"].pop("_replay")
+            try:
+                par = parity_vs_oracle(unet, replay, args.guidance, dev, [headline_mode, other_mode])
+                par["latent_rel_l2"] = par[headline_mode]
+                par["gate_met"] = bool(par[headline_mode] <= par["gate"])
+                rec["parity"] = par
+            except Exception as e:
+                rec["parity"] = {"error": f"{type(e).__name__}: {e}"}
         elif world == 1:
             rec["cpu_baseline"] = None
+            rec["parity"] = None
         print(json.dumps(rec))
     if dist is not None:
         dist.destroy_process_group()

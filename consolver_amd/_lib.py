@@ -124,6 +124,8 @@ SYMBOLS = {
     "cs_unet_flops_executed": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
     "cs_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "cs_unet_set_residual_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "cs_unet_get_residual_precision": (C.c_int, [C.c_void_p]),
     "cs_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_unet_profile_entries": (C.c_int, [C.c_void_p]),
     "cs_unet_profile_entry": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -169,7 +171,19 @@ SYMBOLS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_op_xattn_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "cs_op_conv2d_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_op_linear_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cs_op_group_norm_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_op_layer_norm_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "cs_op_xattn_block_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "cs_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "cs_reset_tuning": (C.c_int, []),
     "cs_op_conv2d_gn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "cs_op_group_norm_pre": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
@@ -201,14 +215,25 @@ def lib():
         f.argtypes = args
     if l.cs_abi_version() != 2:
         raise RuntimeError("libconsolver_hip.so ABI version mismatch")
-    # CS_TUNE="key=value,..." applies kernel-selection knobs (cs_set_tuning) at load time: A/B runs of tests and tools without code changes
+    _lib = l
+    apply_env_tuning()
+    return l
+
+
+def apply_env_tuning():
+    """CS_TUNE="key=value,..." applies kernel-selection knobs (cs_set_tuning): A/B runs of tests and tools without code changes.  Called at load
+    time and by reset_tuning()."""
     for kv in os.environ.get("CS_TUNE", "").split(","):
         if "=" in kv:
             k, v = kv.split("=", 1)
-            if l.cs_set_tuning(k.strip().encode(), int(v)) != 0:
-                raise RuntimeError(f"CS_TUNE: {l.cs_last_error().decode()}")
-    _lib = l
-    return l
+            if _lib.cs_set_tuning(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"CS_TUNE: {_lib.cs_last_error().decode()}")
+
+
+def reset_tuning():
+    """every knob back to its default (then CS_TUNE re-applied): what tests/conftest.py runs after each test."""
+    lib().cs_reset_tuning()
+    apply_env_tuning()
 
 
 def check(code):

@@ -61,6 +61,17 @@ class SolverConfig(dict):
     __setitem__ = __delitem__ = update = pop = popitem = setdefault = clear = _frozen
     __setattr__ = _frozen
 
+    # frozen, but copyable and picklable like diffusers' FrozenDict (copy.deepcopy(scheduler), torch.save, spawned workers): rebuilt from a plain dict
+    def __reduce__(self):
+        return (SolverConfig, (dict(self),))
+
+    def __copy__(self):
+        return SolverConfig(dict(self))
+
+    def __deepcopy__(self, memo):
+        import copy
+        return SolverConfig(copy.deepcopy(dict(self), memo))
+
 
 if not HAVE_DIFFUSERS:
     SCHEDULER_CONFIG_NAME = "scheduler_config.json"

@@ -132,7 +132,7 @@ struct FRun {
     void* alloc(size_t bytes) {
         void* p = f->arena.alloc(bytes);
         if (!p && rc == CS_OK) { cs_set_error("flux: workspace too small"); rc = CS_E_ARG; }
-        return p;
+        return p ? p : reinterpret_cast<void*>((uintptr_t)1 << 41);      // poison base, never dereferenced (nothing is launched once rc is set)
     }
     static Gemm2Args gargs(const Lin& L, const void* a, long lda, int M, void* out, long ldc, int col_off, int act, const void* res,
                            const float* gate, long gate_stride, int rows_per_sample, int a_seg, int a_stride, long a_off, int c_seg, int c_stride, long c_off) {

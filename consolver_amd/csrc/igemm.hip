@@ -46,6 +46,10 @@ struct IgemmParams {
     int M, N, KT, cpt;   // KT = K / 64 ; cpt = chunks (of 64 channels) per tap
     int Ktot;            // row length of w
     const f16* w; const f16* bias; const f16* temb; int temb_stride; const f16* res; f16* out;
+    const f16* res_lo; f16* out_lo;   // split-fp16 residual stream (IgemmArgs::res_lo / out_lo) or null
+    // split-fp16 A operand of a 1x1 / linear layer (IgemmArgs::a0_lo / a1_lo): k steps [0, KTh) multiply the hi planes a0 | a1, k steps [KTh, KT = 2 KTh) the lo
+    // planes a0_lo | a1_lo against the SAME weight columns (the k offset into w wraps at KTh).  Without lo planes KTh == KT and nothing wraps.
+    const f16* a0_lo; const f16* a1_lo; int KTh;
     int tiles_n, nblk;
     float* partial;     // split-K scratch of the generic kernel ([splits][M][N] fp32) or null
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
@@ -204,10 +208,21 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                         const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + off);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
+                        if (p.res_lo) {                       // split-fp16 residual stream: value = hi + lo
+                            const f16x8 t2 = *reinterpret_cast<const f16x8*>(p.res_lo + off);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) f[r] += (float)t2[r];
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
+                    if (p.out_lo) {                           // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
+                        f16x8 l;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) l[r] = (f16)(f[r] - (float)o[r]);
+                        *reinterpret_cast<f16x8*>(p.out_lo + off) = l;
+                    }
                 }
                 // (the fp16 values of chunk ch go where the fp32 values of chunks ch / 2 were: every lane has read its fp32 slot by now -- LDS operations of a
                 //  wave execute in order -- and later iterations read other rows)
@@ -244,7 +259,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
     if constexpr (!GEGLU) {
-        if (p.temb || p.res) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
+        if (p.temb || p.res || p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
     }
     igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false>(p, acc, rows, n_base, lane, wave_lds);
 }
@@ -556,7 +571,10 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
 //     and one slice of the next chunk's halo, wait for the weights with a COUNTED vmcnt (the halo slice may stay in flight for
 //     another step), and join barrier K(g).  All their per-piece addresses are computed once per tile.
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(256))) unsigned g_zero_region[(64 * 128 + 256) / 4];     // padding rows: the chunk offset (< 64 * 128 B) is added to every source
+// padding rows of conv3_lw_kernel: the chunk offset c * 128 B (c < LW_ZERO_CHUNKS) is added to every source, the zero source included, so the region spans
+// LW_ZERO_CHUNKS chunks + one 128-byte row + slack.  launch_igemm_impl sends Cin > 64 * LW_ZERO_CHUNKS (SD1.5 / VAE: <= 2560) to the halo kernels.
+constexpr int LW_ZERO_CHUNKS = 64;
+__device__ __attribute__((aligned(256))) unsigned g_zero_region[(LW_ZERO_CHUNKS * 128 + 256) / 4];
 
 // ---- hand-counted LDS reads for the one-wave-per-SIMD kernels: hipcc neither sees nor waits for these -----------------------------------
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
@@ -984,15 +1002,21 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
             const int r = 8 * (l + 4 * j) + lr;
             wsrc[j] = p.w + (size_t)(n_blk + r) * p.Ktot + (pch ^ ((r >> 1) & 7)) * 8;
         }
+        // lo planes of a split-fp16 A operand: same layout as the hi planes, so a k step >= KTh adds the (uniform) distance between the planes
+        const long dlo0 = p.a0_lo ? p.a0_lo - p.a0 : 0, dlo1 = (p.a1_lo && p.c1) ? p.a1_lo - p.a1 : dlo0;
+        const int KTh = p.KTh;
         auto issue = [&](int kt, int buf) {
             char* st = smem + buf * STAGE;
-            const int cc = kt * BK;
+            const bool lo = kt >= KTh;
+            const int cc = (lo ? kt - KTh : kt) * BK;
             if (cc < p.c0) {
+                const long o = cc + (lo ? dlo0 : 0);
 #pragma unroll
-                for (int j = 0; j < APL; ++j) glds16(asrc0[j] + cc, st + (l + 4 * j) * 1024);
+                for (int j = 0; j < APL; ++j) glds16(asrc0[j] + o, st + (l + 4 * j) * 1024);
             } else {
+                const long o = (cc - p.c0) + (lo ? dlo1 : 0);
 #pragma unroll
-                for (int j = 0; j < APL; ++j) glds16(asrc1[j] + (cc - p.c0), st + (l + 4 * j) * 1024);
+                for (int j = 0; j < APL; ++j) glds16(asrc1[j] + o, st + (l + 4 * j) * 1024);
             }
 #pragma unroll
             for (int j = 0; j < WPL; ++j) glds16(wsrc[j] + cc, st + A_BYTES + (l + 4 * j) * 1024);
@@ -1137,14 +1161,24 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.c1 ? p.a1 : p.a0), 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0xffffffff, 0x00020000);
+    // lo planes of a split-fp16 A operand (same row offsets as the hi planes): k steps >= KTh
+    const __amdgpu_buffer_rsrc_t ra0l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a0_lo ? p.a0_lo : p.a0), 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1l = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1_lo ? p.a1_lo : (p.c1 ? p.a1 : p.a0)), 0, 0xffffffff, 0x00020000);
+    const int KTh = p.KTh;
     // piece n (0..8) of stage kt into stage buffer `buf`
     auto piece = [&](auto n_tag, int kt, int buf) {
         constexpr int n = decltype(n_tag)::value;
-        const int cc = kt * BK;
+        const bool lo = kt >= KTh;                              // (scalar: kt and KTh are wave-uniform)
+        const int cc = (lo ? kt - KTh : kt) * BK;
         if constexpr (n < 4) {
             lptr_t dst = (lptr_t)(smem + buf * STAGE + (w * 4 + n) * 1024);
-            if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, dst, 16, aoff0[n], cc * 2, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, dst, 16, aoff1[n], (cc - p.c0) * 2, 0, 0);
+            if (!lo) {
+                if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, dst, 16, aoff0[n], cc * 2, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, dst, 16, aoff1[n], (cc - p.c0) * 2, 0, 0);
+            } else {
+                if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0l, dst, 16, aoff0[n], cc * 2, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1l, dst, 16, aoff1[n], (cc - p.c0) * 2, 0, 0);
+            }
         } else {
             lptr_t dst = (lptr_t)(smem + buf * STAGE + A_BYTES + (w + 8 * (n - 4)) * 1024);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, woff[n - 4], cc * 2, 0, 0);
@@ -1246,10 +1280,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
         if (p.res) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.N + n);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+        if (p.res && p.res_lo) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res_lo + (size_t)m * p.N + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
         f16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
         *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
+        if (p.out_lo) {
+            f16x8 l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) l[k] = (f16)(v[k] - (float)o[k]);
+            *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * p.N + n) = l;
+        }
     }
 }
 
@@ -1501,10 +1544,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const char* zero = reinterpret_cast<const char*>(g_zero_page) + pch * 16;
 
     auto stage = [&](int kt, int buf) {
-        const int tap = kt / p.cpt;
+        const int tap = kt / p.cpt;                 // (1x1 with a split-fp16 A operand: "tap" 1 = the lo planes, k steps [KTh, 2 KTh), KTh == cpt)
         const int cc = (kt - tap * p.cpt) * BK;
         const f16* src; int cs, coff;
-        if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
+        if (!CONV3 && tap) {
+            if (cc < p.c0) { src = p.a0_lo; cs = p.c0; coff = cc; } else { src = p.a1_lo; cs = p.c1; coff = cc - p.c0; }
+        } else if (cc < p.c0) { src = p.a0; cs = p.c0; coff = cc; } else { src = p.a1; cs = p.c1; coff = cc - p.c0; }
         const int dy = CONV3 ? tap / 3 : 0, dx = CONV3 ? tap - 3 * dy : 0;
         char* la = lA + buf * A_BYTES + (w * 4) * 1024;
 #pragma unroll
@@ -1527,7 +1572,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         }
         char* lb = lB + buf * B_BYTES + (w * NBI) * 1024;
 #pragma unroll
-        for (int j = 0; j < NBI; ++j) glds16(b_src[j] + (size_t)kt * BK, lb + j * 1024);
+        for (int j = 0; j < NBI; ++j) glds16(b_src[j] + (size_t)(CONV3 ? kt * BK : cc), lb + j * 1024);      // (1x1: the weight columns wrap with the lo planes)
     };
 
     f32x4 acc[NT][MT];
@@ -1655,6 +1700,15 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     if (a.pad_after_only && !(a.taps == 9 && a.stride == 2)) CS_FAIL(CS_E_ARG, "igemm: pad_after_only is the stride-2 3x3 form");
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
+    p.res_lo = a.res ? a.res_lo : nullptr; p.out_lo = a.out_lo;
+    p.a0_lo = a.a0_lo; p.a1_lo = a.c1 ? a.a1_lo : nullptr; p.KTh = p.KT;
+    const bool split_a = a.a0_lo != nullptr;
+    if (split_a) {
+        if (a.taps != 1 || a.geglu) CS_FAIL(CS_E_ARG, "igemm: a split-fp16 A operand (a0_lo) is built for 1x1 / linear layers without GEGLU");
+        if (a.c1 && !a.a1_lo) CS_FAIL(CS_E_ARG, "igemm: a0_lo without a1_lo");
+        p.KT = 2 * p.KTh;                                  // Ktot (row length of w) stays cin: the lo k steps re-read the same weight columns
+    }
+    if (a.geglu && a.out_lo) CS_FAIL(CS_E_ARG, "igemm: the GEGLU epilogue writes no lo plane");
     p.debug = g_tune_debug; p.partial = nullptr;
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
@@ -1685,8 +1739,10 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
         else if (a.N % 256 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 256) >= 192 || g_tune_halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
         // round 3: loader-wave kernel (256 pixels x 160 channels per workgroup) wherever the channel count allows it
-        const bool lw160 = g_tune_conv_lw != 0 && a.N % 160 == 0;
-        const bool lw128 = g_tune_conv_lw != 0 && g_tune_conv_lw != 3 && !lw160 && a.N % 128 == 0;        // the VAE's widths 128 / 256 / 512 (conv_lw = 3: BN 160 only)
+        // (conv3_lw_kernel's padded halo rows read g_zero_region + chunk offset: the region covers LW_ZERO_CHUNKS 64-channel chunks, wider inputs take the halo kernels)
+        const bool lw_cin_ok = cin / BK <= LW_ZERO_CHUNKS;
+        const bool lw160 = g_tune_conv_lw != 0 && a.N % 160 == 0 && lw_cin_ok;
+        const bool lw128 = g_tune_conv_lw != 0 && g_tune_conv_lw != 3 && !lw160 && a.N % 128 == 0 && lw_cin_ok;        // the VAE's widths 128 / 256 / 512 (conv_lw = 3: BN 160 only)
         const bool lw = lw160 || lw128;
         if (lw) { hbn = lw160 ? 160 : 128; wide = false; }
         const int tiles_n = a.N / hbn;
@@ -1769,6 +1825,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             }
             // round 3: the hand-scheduled k loop (gemm_w8_kernel) whenever 32-bit byte offsets reach every operand row
             const bool off32 = (double)p.M * (a.c0 > a.c1 ? a.c0 : a.c1) * 2 < 4.0e9 && (double)a.N * p.Ktot * 2 < 4.0e9;
+            if (split_a && !(g_tune_gemm_w8 && off32 && !g_tune_debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging
             if (g_tune_gemm_w8 && off32 && !g_tune_debug) {
                 static bool configured_w8 = false;
                 if (!configured_w8) {
@@ -1798,6 +1855,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
+            if (split_a && !(g_tune_gemm_lw && !g_tune_debug)) goto generic_tiles;
             if (g_tune_gemm_lw && !g_tune_debug) {                    // round 3: the loader-wave form (three 52 KB stages)
                 constexpr size_t lds_lw = 3 * (256 * BK * 2 + 160 * BK * 2);
                 static bool configured_lw = false;
@@ -1814,6 +1872,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             return CS_OK;
         }
     }
+generic_tiles:
+    p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n; p.gm = 1; *stats_done = false;
     if (a.geglu) {
         return launch_variant<128, false, true>(p, s);
     }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void rowvec_linear_kernel(const f16* __restric
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ lat, int n_lat, int B, int H, int W,
                                                       const f16* __restrict__ w, const f16* __restrict__ bias, int Cout,
-                                                      f16* __restrict__ out) {
+                                                      f16* __restrict__ out, f16* __restrict__ out_lo) {
     extern __shared__ __attribute__((aligned(16))) f16 ws[];   // [9*CIN][Cout]
     constexpr int KK = 9 * CIN;
     for (int i = threadIdx.x; i < KK * Cout; i += blockDim.x) {
@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ la
 #pragma unroll
             for (int k = 0; k < 8; ++k) r[k] = (f16)acc[k];
             *reinterpret_cast<f16x8*>(o + ng * 8) = r;
+            if (out_lo) {                                      // split-fp16 residual stream: the part the fp16 store dropped
+                f16x8 l;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) l[k] = (f16)(acc[k] - (float)r[k]);
+                *reinterpret_cast<f16x8*>(out_lo + (size_t)m * Cout + ng * 8) = l;
+            }
         }
     }
 }
@@ -397,13 +403,13 @@ int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, 
     return launch_rowvec_linear(h1, Bt, D, w2, b2, D, out_silu, 1, s);         // linear_2, then the resnets' SiLU
 }
 
-int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s) {
+int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, f16* out_lo) {
     if (!lat || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_in: null pointer");
     if (Cin != 4 || Cout % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_in: built for 4 input channels (got %d)", Cin);
     if (B <= 0) return CS_OK;
     const long total = (long)B * H * W;
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(conv_in_kernel<4>, dim3(grid), dim3(256), (size_t)36 * Cout * sizeof(f16), s, lat, n_lat, B, H, W, w, bias, Cout, out);
+    hipLaunchKernelGGL(conv_in_kernel<4>, dim3(grid), dim3(256), (size_t)36 * Cout * sizeof(f16), s, lat, n_lat, B, H, W, w, bias, Cout, out, out_lo);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

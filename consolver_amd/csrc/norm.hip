@@ -82,10 +82,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
-// pass 3: y = [silu](x * scale + shift), two-source read, single [B][HW][Ctot] output
-template <bool SILU>
+// pass 3: y = [silu](x * scale + shift), two-source read, single [B][HW][Ctot] output.  SPLIT: the sources are split-fp16 residual-stream tensors
+// (value = hi + lo, GroupNormArgs::x0_lo / x1_lo; a null lo plane reads as zero)
+template <bool SILU, bool SPLIT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
-                                                       int HW, const float* __restrict__ scale_shift, f16* __restrict__ out) {
+                                                       int HW, const float* __restrict__ scale_shift, f16* __restrict__ out,
+                                                       const f16* __restrict__ x0_lo, const f16* __restrict__ x1_lo) {
     extern __shared__ __attribute__((aligned(16))) float ss[];    // [Ctot][2]
     const int Ctot = c0 + c1, CV = Ctot >> 3;
     const int b = blockIdx.y;
@@ -96,14 +98,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     const int r1 = min(HW, r0 + rows_per_blk);
     const int nvec = (r1 - r0) * CV;
     for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * (int)blockDim.x) {      // four independent 16-byte loads in flight per lane
-        f16x8 v[4]; int cc[4]; size_t oo[4];
+        f16x8 v[4], vl[4]; int cc[4]; size_t oo[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * (int)blockDim.x;
             const int ic = i < nvec ? i : i0;                             // tail lanes re-read a valid vector (not stored)
             const int rl = ic / CV, c = (ic - rl * CV) * 8, r = r0 + rl;
-            const f16* src = (c < c0) ? x0 + ((size_t)b * HW + r) * c0 + c : x1 + ((size_t)b * HW + r) * c1 + (c - c0);
-            v[u] = *reinterpret_cast<const f16x8*>(src);
+            const size_t so = (c < c0) ? ((size_t)b * HW + r) * c0 + c : ((size_t)b * HW + r) * c1 + (c - c0);
+            v[u] = *reinterpret_cast<const f16x8*>(((c < c0) ? x0 : x1) + so);
+            if constexpr (SPLIT) {
+                const f16* lo = (c < c0) ? x0_lo : x1_lo;
+                vl[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (lo) vl[u] = *reinterpret_cast<const f16x8*>(lo + so);
+            }
             cc[u] = c; oo[u] = ((size_t)b * HW + r) * Ctot + c;
         }
 #pragma unroll
@@ -112,7 +119,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
             f16x8 o;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float y = (float)v[u][k] * ss[2 * (cc[u] + k)] + ss[2 * (cc[u] + k) + 1];
+                float xv = (float)v[u][k];
+                if constexpr (SPLIT) xv += (float)vl[u][k];
+                float y = xv * ss[2 * (cc[u] + k)] + ss[2 * (cc[u] + k) + 1];
                 if (SILU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
                 o[k] = (f16)y;
             }
@@ -124,9 +133,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 // ---------------------------------------------------------------------------- LayerNorm
 // one wave per ROWS token rows, rows kept in registers (C <= 8 * 64 * MAXV), two-pass variance; the ROWS independent row loads keep
 // ROWS x 16 bytes in flight per lane (at C = 320 only 40 of the 64 lanes carry data: one row per wave left the kernel latency-bound)
-template <int MAXV, int ROWS>
+template <int MAXV, int ROWS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                 f16* __restrict__ out, int M, int C, float eps) {
+                                                 f16* __restrict__ out, int M, int C, float eps, const f16* __restrict__ x_lo = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + w) * ROWS;
     if (row0 >= M) return;
@@ -142,8 +151,14 @@ __global__ __launch_bounds__(256) void ln_kernel(const f16* __restrict__ x, cons
             const int cv = lane + 64 * j;
             if (cv < CV) {
                 const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + cv * 8);
+                if constexpr (SPLIT) {                          // split-fp16 residual stream: value = hi + lo
+                    const f16x8 t2 = *reinterpret_cast<const f16x8*>(x_lo + (size_t)row * C + cv * 8);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { v[q][j][k] = (float)t[k]; sum[q] += v[q][j][k]; }
+                    for (int k = 0; k < 8; ++k) { v[q][j][k] = (float)t[k] + (float)t2[k]; sum[q] += v[q][j][k]; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { v[q][j][k] = (float)t[k]; sum[q] += v[q][j][k]; }
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[q][j][k] = 0.f;
@@ -225,22 +240,34 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
     if (chunks < 1) chunks = 1;
     if (chunks > a.HW) chunks = a.HW;
     const size_t lds = (size_t)2 * Ctot * sizeof(float);
-    if (a.silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out);
-    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out);
+    const f16* nul = nullptr;
+    if (a.x0_lo || a.x1_lo) {                 // split-fp16 sources (the statistics above come from the hi planes: the lo planes move a group's mean / variance by < 1e-7 relative)
+        if (a.silu) hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo);
+        else hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo);
+    } else if (a.silu) hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, nul, nul);
+    else hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3(chunks, a.B), dim3(256), lds, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, nul, nul);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
 
-int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s) {
+int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s, const f16* x_lo) {
     if (!x || !gamma || !beta || !out) CS_FAIL(CS_E_ARG, "layer_norm: null pointer");
     if (C % 8 || C > 8 * 64 * 4) CS_FAIL(CS_E_SHAPE, "layer_norm: C=%d unsupported", C);
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
     const int nv = (C / 8 + 63) / 64;
     const dim3 block(256);
-    if (nv <= 1) hipLaunchKernelGGL((ln_kernel<1, 4>), dim3((M + 15) / 16), block, 0, s, x, gamma, beta, out, M, C, eps);
-    else if (nv == 2) hipLaunchKernelGGL((ln_kernel<2, 2>), dim3((M + 7) / 8), block, 0, s, x, gamma, beta, out, M, C, eps);
-    else if (nv == 3) hipLaunchKernelGGL((ln_kernel<3, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps);
-    else hipLaunchKernelGGL((ln_kernel<4, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps);
+    if (x_lo) {
+        if (nv <= 1) hipLaunchKernelGGL((ln_kernel<1, 4, true>), dim3((M + 15) / 16), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+        else if (nv == 2) hipLaunchKernelGGL((ln_kernel<2, 2, true>), dim3((M + 7) / 8), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+        else if (nv == 3) hipLaunchKernelGGL((ln_kernel<3, 1, true>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+        else hipLaunchKernelGGL((ln_kernel<4, 1, true>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
+    if (nv <= 1) hipLaunchKernelGGL((ln_kernel<1, 4>), dim3((M + 15) / 16), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+    else if (nv == 2) hipLaunchKernelGGL((ln_kernel<2, 2>), dim3((M + 7) / 8), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+    else if (nv == 3) hipLaunchKernelGGL((ln_kernel<3, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
+    else hipLaunchKernelGGL((ln_kernel<4, 1>), dim3((M + 3) / 4), block, 0, s, x, gamma, beta, out, M, C, eps, x_lo);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -23,6 +23,14 @@ struct IgemmArgs {
     // optional: GroupNorm statistics of the OUTPUT, written by the epilogue (or by a statistics pass when the chosen kernel cannot):
     // gn_stats[B][Ho*Wo/64][N/2][2] = (sum, sum of squares) of channel pairs over each 64-row block of a sample; needs Ho*Wo % 64 == 0, no GEGLU
     float* gn_stats;
+    // optional: split-fp16 residual stream (CS_RESIDUAL_F16X2).  A stream tensor is two fp16 planes whose sum is the value: `res_lo` is the lo plane of
+    // `res` (added in fp32 with it), `out_lo` receives what the fp16 store of `out` dropped: out_lo = f16(v - float(f16(v))).  hi + lo carries 22
+    // significant bits, so the adds along the residual stream are fp32-class while every GEMM operand stays a plain fp16 tensor (the hi plane).
+    const f16* res_lo; f16* out_lo;
+    // optional (1x1 / linear only): the A operand itself is a split-fp16 stream tensor -- a0_lo / a1_lo are the lo planes of a0 / a1 (same shapes).  The kernel
+    // runs the k loop twice over the same weights, hi planes then lo planes, into one accumulator: W (hi + lo) exactly, 2x the layer's MFMA work.  Used where
+    // a GEMM consumes the residual stream directly and its operand rounding is a stream-level error (the resnet shortcut 1x1 over [x | skip]).
+    const f16* a0_lo; const f16* a1_lo;
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);
@@ -53,17 +61,21 @@ struct GroupNormArgs {
     f16* out;
     // optional: partial sums of a source already written by its producer (IgemmArgs::gn_stats layout [B][S][C/2][2]); null -> computed here
     const float* stats0; int S0; const float* stats1; int S1;
+    // optional: lo planes of split-fp16 sources (value = x + x_lo; IgemmArgs::out_lo), null = plain fp16 source
+    const f16* x0_lo; const f16* x1_lo;
 };
 // statistics of a [B][HW][C] tensor in the producer layout: partial[B][HW/64][C/2][2] (sum, sum of squares of channel pairs per 64-row block)
 int launch_gn_stats64(const f16* x, int B, int HW, int C, float* partial, hipStream_t s);
 #define GN_SPLITS 16
 int launch_group_norm(const GroupNormArgs& a, hipStream_t s);
 
-int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s);
+// x_lo: lo plane of a split-fp16 input (value = x + x_lo) or null
+int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out, int M, int C, float eps, hipStream_t s, const f16* x_lo = nullptr);
 
 // fused cross-attention sub-block (xattn.hip): out = h + to_out(softmax(scale * to_q(LayerNorm(h)) K^T) V) + bo; C = 320, 8 heads, Nk <= 80
 struct XattnArgs {
     const f16* h; f16* out;                 // [M][C]; out may alias h
+    const f16* h_lo; f16* out_lo;           // split-fp16 residual stream: lo planes of h / out (both or neither); out_lo may alias h_lo
     const f16* ln_g; const f16* ln_b; float ln_eps;
     const f16* wq; const f16* wo; const f16* bo;
     const f16* kv;                          // [M / HW samples][Nk][2 C]: K | V projections of the text context
@@ -79,8 +91,9 @@ int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, 
 int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16* b, int N, f16* out, int act_silu, hipStream_t s);
 
 // conv_in: NCHW fp16 latents (n_lat samples, sample b reads b % n_lat) -> NHWC [B][H][W][Cout], 3x3 pad 1
+// out_lo: optional lo plane of a split-fp16 output (IgemmArgs::out_lo)
 int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias,
-                   int Cout, f16* out, hipStream_t s);
+                   int Cout, f16* out, hipStream_t s, f16* out_lo = nullptr);
 // conv_out: NHWC [B][H][W][Cin] -> NCHW [B][Cout][H][W], 3x3 pad 1 (Cout small)
 int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias, int Cout,
                     f16* out, hipStream_t s);

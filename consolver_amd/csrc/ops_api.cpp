@@ -20,27 +20,50 @@ extern int g_tune_attn_prio;
 extern int g_tune_gemm2_prio;
 extern int g_tune_biggemm;
 extern int g_tune_attn_qt40;
+extern int g_tune_x2_split_a;
 
 extern "C" {
 
+// every kernel-selection knob: name, variable, default, accepted range (or the two-value set {lo, hi} when `pair`)
+struct TuneKnob { const char* key; int* var; int def, lo, hi; bool pair; };
+static const TuneKnob* tune_knobs(int* n) {
+    static const TuneKnob k[] = {
+        {"conv_halo", &g_tune_halo, 1, 0, 4, false},     {"gemm_lw", &g_tune_gemm_lw, 1, 0, 1, false},      {"gemm2_w8", &g_tune_gemm2_w8, 1, 0, 1, false},
+        {"attn_lw", &g_tune_attn_lw, 1, 0, 2, false},    {"gemm_w8", &g_tune_gemm_w8, 1, 0, 1, false},      {"conv_lw", &g_tune_conv_lw, 1, 0, 3, false},
+        {"gemm_big", &g_tune_biggemm, 1, 0, 3, false},   {"debug", &g_tune_debug, 0, 0, 0x7fffffff, false}, {"gemm_gm", &g_tune_gemm_gm, -1, -1, 64, false},
+        {"gn_fuse", &g_tune_gn_fuse, 1, 0, 1, false},    {"xattn_fused", &g_tune_xattn_fused, 1, 0, 1, false}, {"cfg_share", &g_tune_cfg_share, 1, 0, 1, false},
+        {"gemm2_prio", &g_tune_gemm2_prio, 0, -1, 1, false}, {"attn_prio", &g_tune_attn_prio, -1, -1, 1, false}, {"attn_qt40", &g_tune_attn_qt40, 4, 2, 4, true},
+        {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false},
+    };
+    *n = (int)(sizeof(k) / sizeof(k[0]));
+    return k;
+}
+
 int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
-    if (!strcmp(key, "conv_halo")) { g_tune_halo = value; return CS_OK; }
-    if (!strcmp(key, "gemm_lw")) { g_tune_gemm_lw = value; return CS_OK; }
-    if (!strcmp(key, "gemm2_w8")) { g_tune_gemm2_w8 = value; return CS_OK; }
-    if (!strcmp(key, "attn_lw")) { g_tune_attn_lw = value; return CS_OK; }
-    if (!strcmp(key, "gemm_w8")) { g_tune_gemm_w8 = value; return CS_OK; }
-    if (!strcmp(key, "conv_lw")) { g_tune_conv_lw = value; return CS_OK; }
-    if (!strcmp(key, "gemm_big")) { g_tune_biggemm = value; return CS_OK; }
-    if (!strcmp(key, "debug")) { g_tune_debug = value; return CS_OK; }
-    if (!strcmp(key, "gemm_gm")) { g_tune_gemm_gm = value; return CS_OK; }
-    if (!strcmp(key, "gn_fuse")) { g_tune_gn_fuse = value ? 1 : 0; return CS_OK; }
-    if (!strcmp(key, "xattn_fused")) { g_tune_xattn_fused = value; return CS_OK; }
-    if (!strcmp(key, "cfg_share")) { g_tune_cfg_share = value; return CS_OK; }
-    if (!strcmp(key, "gemm2_prio")) { g_tune_gemm2_prio = value; return CS_OK; }
-    if (!strcmp(key, "attn_prio")) { g_tune_attn_prio = value; return CS_OK; }
-    if (!strcmp(key, "attn_qt40")) { if (value != 2 && value != 4) CS_FAIL(CS_E_ARG, "attn_qt40 must be 2 or 4"); g_tune_attn_qt40 = value; return CS_OK; }
+    int n; const TuneKnob* k = tune_knobs(&n);
+    for (int i = 0; i < n; ++i)
+        if (!strcmp(key, k[i].key)) {
+            const bool ok = k[i].pair ? (value == k[i].lo || value == k[i].hi) : (value >= k[i].lo && value <= k[i].hi);
+            if (!ok) CS_FAIL(CS_E_ARG, "tuning key '%s': value %d outside %s%d%s%d%s", key, value, k[i].pair ? "{" : "[", k[i].lo, k[i].pair ? ", " : " .. ", k[i].hi, k[i].pair ? "}" : "]");
+            *k[i].var = value;
+            return CS_OK;
+        }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
+}
+
+int cs_get_tuning(const char* key, int* value) {
+    if (!key || !value) CS_FAIL(CS_E_ARG, "key / value is NULL");
+    int n; const TuneKnob* k = tune_knobs(&n);
+    for (int i = 0; i < n; ++i)
+        if (!strcmp(key, k[i].key)) { *value = *k[i].var; return CS_OK; }
+    CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
+}
+
+int cs_reset_tuning(void) {
+    int n; const TuneKnob* k = tune_knobs(&n);
+    for (int i = 0; i < n; ++i) *k[i].var = k[i].def;
+    return CS_OK;
 }
 
 int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
@@ -84,6 +107,59 @@ int cs_op_xattn_block(const void* h, const void* ln_gamma, const void* ln_beta, 
                       const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* stream) {
     XattnArgs a{};
     a.h = (const f16*)h; a.out = (f16*)out; a.ln_g = (const f16*)ln_gamma; a.ln_b = (const f16*)ln_beta; a.ln_eps = ln_eps;
+    a.wq = (const f16*)wq; a.wo = (const f16*)wo; a.bo = (const f16*)bo; a.kv = (const f16*)kv;
+    a.M = M; a.HW = HW; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = scale;
+    return launch_xattn_block(a, (hipStream_t)stream);
+}
+
+int cs_op_conv2d_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int Hi, int Wi, int taps, int stride,
+                    int upsample, const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, const void* res_lo,
+                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x0; a.a1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi;
+    a.a0_lo = (const f16*)x0_lo; a.a1_lo = (const f16*)x1_lo;
+    if (stride != 1 && stride != 2) CS_FAIL(CS_E_ARG, "conv2d: stride must be 1 or 2");
+    if (res_lo && !res) CS_FAIL(CS_E_ARG, "conv2d_x2: res_lo without res");
+    a.Ho = upsample ? 2 * Hi : (stride == 2 ? Hi / 2 : Hi);
+    a.Wo = upsample ? 2 * Wi : (stride == 2 ? Wi / 2 : Wi);
+    a.taps = taps; a.stride = stride; a.upsample = upsample; a.N = N; a.w = (const f16*)w; a.bias = (const f16*)bias;
+    a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
+    a.res_lo = (const f16*)res_lo; a.out_lo = (f16*)out_lo;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_linear_x2(const void* x, const void* x_lo, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo,
+                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    IgemmArgs a{};
+    a.a0_lo = (const f16*)x_lo;
+    if (res_lo && !res) CS_FAIL(CS_E_ARG, "linear_x2: res_lo without res");
+    a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
+    a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out;
+    a.res_lo = (const f16*)res_lo; a.out_lo = (f16*)out_lo;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_group_norm_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int HW, int groups,
+                        float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream) {
+    GroupNormArgs a{};
+    a.x0 = (const f16*)x0; a.x1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = groups; a.eps = eps; a.silu = silu;
+    a.gamma = (const f16*)gamma; a.beta = (const f16*)beta; a.partial = (float*)workspace; a.out = (f16*)out;
+    a.x0_lo = (const f16*)x0_lo; a.x1_lo = (const f16*)x1_lo;
+    return launch_group_norm(a, (hipStream_t)stream);
+}
+
+int cs_op_layer_norm_x2(const void* x, const void* x_lo, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream) {
+    return launch_layer_norm((const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)out, M, C, eps, (hipStream_t)stream, (const f16*)x_lo);
+}
+
+int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
+                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, void* stream) {
+    XattnArgs a{};
+    a.h = (const f16*)h; a.out = (f16*)out; a.h_lo = (const f16*)h_lo; a.out_lo = (f16*)out_lo;
+    a.ln_g = (const f16*)ln_gamma; a.ln_b = (const f16*)ln_beta; a.ln_eps = ln_eps;
     a.wq = (const f16*)wq; a.wo = (const f16*)wo; a.bo = (const f16*)bo; a.kv = (const f16*)kv;
     a.M = M; a.HW = HW; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = scale;
     return launch_xattn_block(a, (hipStream_t)stream);

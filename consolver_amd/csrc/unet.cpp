@@ -27,6 +27,9 @@
 int g_tune_xattn_fused = 1;    // 1 (default): the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
 extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
 int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
+// CS_RESIDUAL_F16X2 only: which GEMMs that consume the residual stream DIRECTLY read hi + lo (two passes of the k loop, IgemmArgs::a0_lo) instead of the hi
+// plane: bit 0 the resnet shortcut 1x1 (default: its operand rounding is the largest single stream-level error left), bit 1 proj_out
+int g_tune_x2_split_a = 1;
 
 namespace {
 
@@ -77,6 +80,17 @@ struct Arena {
     }
 };
 
+// A residual-stream tensor.  CS_RESIDUAL_F16 (default): one fp16 plane, lo == nullptr.  CS_RESIDUAL_F16X2: value = hi + lo, two fp16 planes
+// (22 significant bits): the epilogues that add onto the stream take hi + lo in fp32 and store both planes (IgemmArgs::res_lo / out_lo), the norms
+// read hi + lo, and a GEMM that consumes the stream directly (shortcut 1x1, down / upsample conv, proj_out) reads the hi plane -- which is exactly
+// the fp16 tensor of the default mode, so no kernel's operand path changes.
+struct St {
+    f16* hi = nullptr; f16* lo = nullptr;
+    St() {}
+    St(f16* h, f16* l = nullptr) : hi(h), lo(l) {}
+    St at(size_t off) const { return St(hi + off, lo ? lo + off : nullptr); }
+};
+
 enum ProfClass { P_CONV3 = 0, P_GEMM, P_ATTN_SELF, P_ATTN_CROSS, P_GROUPNORM, P_LAYERNORM, P_MISC, P_COUNT };
 const char* kProfNames[P_COUNT] = {"conv3x3_igemm", "gemm_1x1_linear", "attention_self", "attention_cross", "groupnorm_silu", "layernorm", "misc"};
 
@@ -104,6 +118,7 @@ struct CsUNet {
     std::vector<Ev> evs; size_t ev_used = 0;
     double prof_ms[P_COUNT] = {}, prof_flops[P_COUNT] = {}, prof_bytes[P_COUNT] = {}; int prof_launches[P_COUNT] = {};
     double dry_flops = 0;
+    int residual = CS_RESIDUAL_F16;   // cs_unet_set_residual_precision
 };
 
 namespace {
@@ -277,6 +292,8 @@ struct Run {
     // execution variant, snapshotted from the process-wide knobs ONCE per forward (cs_set_tuning from another thread cannot change a forward in
     // flight; the workspace query passes its variants here instead of writing the globals)
     int v_gn_fuse = 1, v_xattn_fused = 1, v_cfg_share = 1;
+    bool split = false;            // CS_RESIDUAL_F16X2: residual-stream tensors carry a lo plane
+    int v_split_a = 1;             // snapshot of g_tune_x2_split_a
 
     f16* alloc(size_t halfs) {
         void* p = u->arena.alloc(halfs * sizeof(f16));
@@ -285,7 +302,9 @@ struct Run {
                          u->arena.peak, B);
             rc = CS_E_ARG;
         }
-        return (f16*)p;
+        // after a failed allocation nothing is launched any more (rc), but the walk goes on taking offsets from what it got: hand out a poison
+        // base that is never dereferenced instead of null (offsets from a null pointer are undefined behaviour)
+        return p ? (f16*)p : reinterpret_cast<f16*>((uintptr_t)1 << 41);
     }
     // GroupNorm statistics a producer left for a tensor (IgemmArgs::gn_stats): tensor -> partial sums, alive as long as the tensor
     struct StatRec { float* stats; int S; };
@@ -295,6 +314,9 @@ struct Run {
         if (it != stat_of.end()) { u->arena.free(it->second.stats); stat_of.erase(it); }
         u->arena.free(const_cast<void*>(p));
     }
+    // residual-stream tensors: hi plane (+ lo plane in the split mode)
+    St salloc(size_t halfs) { St t; t.hi = alloc(halfs); t.lo = split ? alloc(halfs) : nullptr; return t; }
+    void srelease(const St& t) { release(t.hi); u->arena.free(t.lo); }
     bool stats_fusable(int HW, int C) const { return v_gn_fuse != 0 && HW % 64 == 0 && C % 2 == 0; }
     // partial-sum buffer for a [Bt][HW][C] tensor about to be produced (Bt samples); registered under `out` by the caller
     float* alloc_stats(int Bt, int HW, int C) { return (float*)alloc((size_t)Bt * (HW / 64) * C * 2); }      // C/2 pairs x 2 floats = C floats = 2C halfs
@@ -316,40 +338,44 @@ struct Run {
     // want_stats: the output feeds a GroupNorm (or a skip connection that does): its statistics come out of the epilogue.
     // stats_into: write them into this (larger) buffer instead of a fresh one, nothing registered (two launches filling one tensor).
     void conv(const Conv& c, const f16* a0, int c0, const f16* a1, int c1, int Hi, int Wi, int Ho, int Wo, int stride, int up,
-              const f16* temb, const f16* res, f16* out, bool want_stats = false, float* stats_into = nullptr) {
+              const f16* temb, St res, St out, bool want_stats = false, float* stats_into = nullptr, const f16* a0_lo = nullptr, const f16* a1_lo = nullptr) {
         IgemmArgs a{};
+        a.a0_lo = a0_lo; a.a1_lo = a0_lo ? a1_lo : nullptr;
         if (stats_into) a.gn_stats = stats_into;
         else if (want_stats && stats_fusable(Ho * Wo, c.cout)) {
             a.gn_stats = alloc_stats(B, Ho * Wo, c.cout);
-            if (a.gn_stats) stat_of[out] = {a.gn_stats, Ho * Wo / 64};
+            if (a.gn_stats) stat_of[out.hi] = {a.gn_stats, Ho * Wo / 64};
         }
         a.a0 = a0; a.a1 = a1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.taps = c.taps; a.stride = stride;
-        a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res; a.out = out; a.geglu = 0;
+        a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res.hi; a.out = out.hi; a.geglu = 0;
+        a.res_lo = res.lo; a.out_lo = out.lo;
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double M = (double)B * Ho * Wo;
-        const double bytes = 2.0 * (M * (c0 + c1) * (c.taps == 9 && stride == 1 && !up ? 1.0 : 1.0) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * (res ? 2 : 1));
+        const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
         launch(c.taps == 9 ? P_CONV3 : P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
-    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, const f16* res, f16* out, int geglu) {
+    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu) {
         IgemmArgs a{};
-        a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res; a.out = out; a.geglu = geglu;
+        a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res.hi; a.out = out.hi; a.geglu = geglu;
+        a.res_lo = res.lo; a.out_lo = out.lo;
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
-        const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * (res ? 2 : 1));
+        const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
         launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
-    void group_norm(const Norm& n, const f16* x0, int c0, const f16* x1, int c1, int HW, bool silu, f16* out) {
+    void group_norm(const Norm& n, St s0, int c0, St s1, int c1, int HW, bool silu, f16* out) {
         GroupNormArgs a{};
-        a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.B = B; a.HW = HW; a.groups = u->cfg.norm_num_groups; a.eps = n.eps; a.silu = silu;
+        const f16* x0 = s0.hi; const f16* x1 = s1.hi;
+        a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.x0_lo = s0.lo; a.x1_lo = s1.lo; a.B = B; a.HW = HW; a.groups = u->cfg.norm_num_groups; a.eps = n.eps; a.silu = silu;
         a.gamma = n.g; a.beta = n.b; a.partial = gn_ws; a.out = out;
         auto i0 = stat_of.find(x0);
         if (i0 != stat_of.end()) { a.stats0 = i0->second.stats; a.S0 = i0->second.S; }
         auto i1 = x1 ? stat_of.find(x1) : stat_of.end();
         if (i1 != stat_of.end()) { a.stats1 = i1->second.stats; a.S1 = i1->second.S; }
-        const double passes = 2.0 + ((a.stats0 ? 0.0 : (double)c0) + (x1 && !a.stats1 ? (double)c1 : 0.0)) / (double)(c0 + c1);
+        const double passes = 2.0 + ((a.stats0 ? 0.0 : (double)c0) + (x1 && !a.stats1 ? (double)c1 : 0.0) + (s0.lo ? (double)c0 : 0.0) + (s1.lo ? (double)c1 : 0.0)) / (double)(c0 + c1);
         launch(P_GROUPNORM, 0, 2.0 * passes * B * HW * (double)(c0 + c1), [&] { return launch_group_norm(a, s); });
     }
-    void layer_norm(const Norm& n, const f16* x, int M, f16* out) {
-        launch(P_LAYERNORM, 0, 2.0 * 2.0 * M * (double)n.c, [&] { return launch_layer_norm(x, n.g, n.b, out, M, n.c, n.eps, s); });
+    void layer_norm(const Norm& n, St x, int M, f16* out) {
+        launch(P_LAYERNORM, 0, 2.0 * (x.lo ? 3.0 : 2.0) * M * (double)n.c, [&] { return launch_layer_norm(x.hi, n.g, n.b, out, M, n.c, n.eps, s, x.lo); });
     }
     void attention(bool cross, const f16* q, int qs, const f16* k, int ks, const f16* v, int vs, f16* out, int os, int Nq, int Nk, int C) {
         AttnArgs a{};
@@ -361,44 +387,48 @@ struct Run {
 
     // fused LN2 -> to_q -> cross attention -> to_out + residual (xattn.hip); h_in may equal h_out
     bool xattn_fusable(const Xformer& X, int HW) const { return v_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
-    void xattn_fused(const Xformer& X, const f16* h_in, f16* h_out, const f16* kvl, int HW) {
+    void xattn_fused(const Xformer& X, St h_in, St h_out, const f16* kvl, int HW) {
         XattnArgs a{};
-        a.h = h_in; a.out = h_out; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
+        a.h = h_in.hi; a.out = h_out.hi; a.h_lo = h_in.lo; a.out_lo = h_out.lo; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
         a.M = B * HW; a.HW = HW; a.Nk = u->cfg.ctx_len; a.C = X.c; a.heads = u->cfg.num_heads; a.scale = 1.0f / sqrtf((float)(X.c / u->cfg.num_heads));
         const double M = (double)B * HW, fl = 4.0 * M * X.c * X.c + 4.0 * M * u->cfg.ctx_len * X.c;
-        launch(P_ATTN_CROSS, fl, 2.0 * (3.0 * M * X.c), [&] { return launch_xattn_block(a, s); });
+        launch(P_ATTN_CROSS, fl, 2.0 * ((h_in.lo ? 5.0 : 3.0) * M * X.c), [&] { return launch_xattn_block(a, s); });
     }
 
     // x: [B,HW,Cx] (+ optional skip [B,HW,Cs]) -> new tensor [B,HW,Cout]
-    f16* resnet(const Resnet& r, const f16* x, int cx, const f16* skip, int cs, int H, int W) {
+    St resnet(const Resnet& r, St x, int cx, St skip, int cs, int H, int W) {
         const int HW = H * W; const size_t M = (size_t)B * HW;
         f16* n1 = alloc(M * (cx + cs));
         group_norm(r.n1, x, cx, skip, cs, HW, true, n1);
         f16* h1 = alloc(M * r.cout);
-        conv(r.c1, n1, cx + cs, nullptr, 0, H, W, H, W, 1, 0, tproj + r.temb_off, nullptr, h1, true);      // -> norm2
+        conv(r.c1, n1, cx + cs, nullptr, 0, H, W, H, W, 1, 0, tproj + r.temb_off, St(), St(h1), true);      // -> norm2
         release(n1);
         f16* n2 = alloc(M * r.cout);
-        group_norm(r.n2, h1, r.cout, nullptr, 0, HW, true, n2);
+        group_norm(r.n2, St(h1), r.cout, St(), 0, HW, true, n2);
         release(h1);
-        f16* out = alloc(M * r.cout);
-        const f16* res = x;
-        if (r.has_sc) { conv(r.sc, x, cx, skip, cs, H, W, H, W, 1, 0, nullptr, nullptr, out); res = out; }
+        St out = salloc(M * r.cout);
+        St res = x;
+        if (r.has_sc) {                                      // split mode: the 1x1 multiplies hi + lo of [x | skip] (two passes of its k loop over the same weights)
+            const bool sa = split && (v_split_a & 1) && x.lo && (!cs || skip.lo);
+            conv(r.sc, x.hi, cx, skip.hi, cs, H, W, H, W, 1, 0, nullptr, St(), out, false, nullptr, sa ? x.lo : nullptr, sa ? skip.lo : nullptr);
+            res = out;
+        }
         conv(r.c2, n2, r.cout, nullptr, 0, H, W, H, W, 1, 0, nullptr, res, out, true);                     // -> the next block's GroupNorm / a skip
         release(n2);
         return out;
     }
 
     // in-place on a fresh output: returns new tensor [B,HW,C]
-    f16* xformer(const Xformer& X, const f16* x, int H, int W) {
+    St xformer(const Xformer& X, St x, int H, int W) {
         const int C = X.c, HW = H * W, L = u->cfg.ctx_len; const int M = B * HW;
         f16* g = alloc((size_t)M * C);
-        group_norm(X.gn, x, C, nullptr, 0, HW, false, g);
-        f16* h = alloc((size_t)M * C);
-        conv(X.proj_in, g, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, nullptr, h);
+        group_norm(X.gn, x, C, St(), 0, HW, false, g);
+        St h = salloc((size_t)M * C);
+        conv(X.proj_in, g, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h);
         // self attention
         layer_norm(X.ln1, h, M, g);
         f16* qkv = alloc((size_t)M * 3 * C);
-        linear(g, M, C, X.wqkv, nullptr, 3 * C, nullptr, qkv, 0);
+        linear(g, M, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0);
         attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g, C, HW, HW, C);
         release(qkv);
         linear(g, M, C, X.wo1, X.bo1, C, h, h, 0);
@@ -409,7 +439,7 @@ struct Run {
         } else {
             layer_norm(X.ln2, h, M, g);
             f16* q = alloc((size_t)M * C);
-            linear(g, M, C, X.wq2, nullptr, C, nullptr, q, 0);
+            linear(g, M, C, X.wq2, nullptr, C, St(), St(q), 0);
             attention(true, q, C, kvl, 2 * C, kvl + C, 2 * C, g, C, HW, L, C);
             release(q);
             linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
@@ -417,13 +447,15 @@ struct Run {
         // feed forward (GEGLU fused into the first GEMM's epilogue)
         layer_norm(X.ln3, h, M, g);
         f16* ff = alloc((size_t)M * 4 * C);
-        linear(g, M, C, X.wff1, X.bff1, 8 * C, nullptr, ff, 1);
-        linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, h, 0);
+        linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1);
+        const bool po = split && (v_split_a & 2);
+        linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);      // the hidden after the feed-forward has one consumer, proj_out's operand: hi plane only unless proj_out reads hi + lo
         release(ff);
         // proj_out + residual with the block input
-        conv(X.proj_out, h, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x, g, true);
-        release(h);
-        return g;
+        St out(g, split ? alloc((size_t)M * C) : nullptr);
+        conv(X.proj_out, h.hi, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x, out, true, nullptr, po ? h.lo : nullptr);
+        srelease(h);
+        return out;
     }
 };
 
@@ -435,7 +467,7 @@ struct Run {
 // b and sample b + n_lat, so it is computed once at batch n_lat and the residual stream is duplicated right before the two halves
 // diverge.  Bit-identical to running the full batch (the kernels are batch-independent per sample); ~1/32 of the forward's FLOPs are
 // not executed.  `xformer_cfg_shared` is `xformer` with that split.
-f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, int W, int n_lat);
+St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int n_lat);
 
 size_t kv_cache_bytes(const CsUNet* u, int B) { return ((u->kv_halfs_per_token * (size_t)B * u->cfg.ctx_len * sizeof(f16)) + 255) & ~(size_t)255; }
 size_t sk_ws_bytes(const CsUNet*, int B) { return ((size_t)B * (8u << 20)) + (16u << 20); }
@@ -444,66 +476,70 @@ size_t gn_ws_bytes(const CsUNet* u, int B) {
     return (((size_t)B * (GN_SPLITS + 1) * cmax * 2 * sizeof(float)) + 255) & ~(size_t)255;
 }
 
-f16* Run_xformer_cfg_shared(Run& R, const Xformer& X, const f16* x_half, int H, int W, int n_lat) {
+St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int n_lat) {
     CsUNet* u = R.u;
     const int C = X.c, HW = H * W, L = u->cfg.ctx_len;
     const int Bfull = R.B, M1 = n_lat * HW, M = Bfull * HW;
     // ---- shared part at batch n_lat ----
     R.B = n_lat;
     f16* g1 = R.alloc((size_t)M1 * C);
-    R.group_norm(X.gn, x_half, C, nullptr, 0, HW, false, g1);
-    f16* h1 = R.alloc((size_t)M1 * C);
-    R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, nullptr, h1);
+    R.group_norm(X.gn, x_half, C, St(), 0, HW, false, g1);
+    St h1 = R.salloc((size_t)M1 * C);
+    R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h1);
     R.layer_norm(X.ln1, h1, M1, g1);
     f16* qkv = R.alloc((size_t)M1 * 3 * C);
-    R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, nullptr, qkv, 0);
+    R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0);
     R.attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g1, C, HW, HW, C);
     R.release(qkv);
     R.linear(g1, M1, C, X.wo1, X.bo1, C, h1, h1, 0);
     const f16* kvl = R.kv + X.kv_off * (size_t)Bfull * L;
-    f16 *h, *g;
+    St h; f16* g;
     if (R.xattn_fusable(X, HW)) {
         // the fused sub-block reads the shared residual stream and writes each half's own copy: no duplication copy, LN2 / to_q run per half
         R.release(g1);
-        h = R.alloc((size_t)M * C);
+        h = R.salloc((size_t)M * C);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half)
-            R.xattn_fused(X, h1, h + (size_t)half * M1 * C, kvl + (size_t)half * n_lat * L * 2 * C, HW);
-        R.release(h1);
+            R.xattn_fused(X, h1, h.at((size_t)half * M1 * C), kvl + (size_t)half * n_lat * L * 2 * C, HW);
+        R.srelease(h1);
         R.B = Bfull;
     } else {
         R.layer_norm(X.ln2, h1, M1, g1);
         f16* q = R.alloc((size_t)M1 * C);
-        R.linear(g1, M1, C, X.wq2, nullptr, C, nullptr, q, 0);
+        R.linear(g1, M1, C, X.wq2, nullptr, C, St(), St(q), 0);
         R.release(g1);
         // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
-        h = R.alloc((size_t)M * C);
+        h = R.salloc((size_t)M * C);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half) {
-            if (!R.dry && R.rc == CS_OK)
-                hipMemcpyAsync(h + (size_t)half * M1 * C, h1, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+            if (!R.dry && R.rc == CS_OK) {
+                hipMemcpyAsync(h.hi + (size_t)half * M1 * C, h1.hi, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+                if (h.lo) hipMemcpyAsync(h.lo + (size_t)half * M1 * C, h1.lo, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+            }
             const f16* kvh = kvl + (size_t)half * n_lat * L * 2 * C;
             R.attention(true, q, C, kvh, 2 * C, kvh + C, 2 * C, g + (size_t)half * M1 * C, C, HW, L, C);
         }
-        R.release(q); R.release(h1);
+        R.release(q); R.srelease(h1);
         R.B = Bfull;
         R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
     }
     R.layer_norm(X.ln3, h, M, g);
     f16* ff = R.alloc((size_t)M * 4 * C);
-    R.linear(g, M, C, X.wff1, X.bff1, 8 * C, nullptr, ff, 1);
-    R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, h, 0);
+    R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1);
+    const bool po = R.split && (R.v_split_a & 2);
+    R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);
     R.release(ff);
     // proj_out + residual with the block input, which exists once: one launch per half
+    St out(g, R.split ? R.alloc((size_t)M * C) : nullptr);
     float* st = R.stats_fusable(HW, C) ? R.alloc_stats(Bfull, HW, C) : nullptr;     // one statistics buffer for the full batch, filled per half
     R.B = n_lat;
     for (int half = 0; half < 2; ++half)
-        R.conv(X.proj_out, h + (size_t)half * M1 * C, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x_half, g + (size_t)half * M1 * C, false,
-               st ? st + (size_t)half * n_lat * (HW / 64) * C : nullptr);
+        R.conv(X.proj_out, h.hi + (size_t)half * M1 * C, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x_half, out.at((size_t)half * M1 * C), false,
+               st ? st + (size_t)half * n_lat * (HW / 64) * C : nullptr, po ? h.lo + (size_t)half * M1 * C : nullptr);
     R.B = Bfull;
     if (st) R.stat_of[g] = {st, HW / 64};
-    R.release(h);
-    return g;
+    R.srelease(h);
+    return out;
 }
 
 struct Variant { int gn_fuse, xattn_fused, cfg_share; };
@@ -515,9 +551,11 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     const int B = n_lat * dup;
     const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B) + sk_ws_bytes(u, B);
     if (!dry && ws_bytes < kvb + gnb) CS_FAIL(CS_E_ARG, "unet: workspace too small (%zu < %zu)", ws_bytes, kvb + gnb);
+    if (dry) ws = reinterpret_cast<char*>((uintptr_t)1 << 40);      // a base that is never dereferenced (offsets from a null pointer are undefined behaviour)
     u->arena.reset(ws + kvb + gnb, dry ? 0 : ws_bytes - kvb - gnb, dry);
     u->dry_flops = 0;
     Run R{u, s, dry, B};
+    R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -536,70 +574,70 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     if (!kv_valid) {
         auto kvproj = [&](const Xformer& X) {
             f16* dst = R.kv + X.kv_off * (size_t)B * L;
-            R.linear(ctx, B * L, c.cross_attention_dim, X.wkv2, nullptr, 2 * X.c, nullptr, dst, 0);
+            R.linear(ctx, B * L, c.cross_attention_dim, X.wkv2, nullptr, 2 * X.c, St(), St(dst), 0);
         };
         for (int i = 0; i < 4; ++i) { for (auto& X : u->down_att[i]) kvproj(X); for (auto& X : u->up_att[i]) kvproj(X); }
         kvproj(u->mid_att);
     }
 
     // ---- down path -----------------------------------------------------------------------------------
-    std::vector<std::pair<f16*, int>> skips;
-    f16* h = R.alloc((size_t)B * H * W * c0);
-    R.launch(P_MISC, 2.0 * B * H * W * 9.0 * c.in_channels * c0, 2.0 * B * H * W * c0, [&] { return launch_conv_in(latents, n_lat, B, c.in_channels, H, W, u->conv_in.w, u->conv_in.b, c0, h, s); });
+    std::vector<std::pair<St, int>> skips;
+    St h = R.salloc((size_t)B * H * W * c0);
+    R.launch(P_MISC, 2.0 * B * H * W * 9.0 * c.in_channels * c0, 2.0 * B * H * W * c0 * (h.lo ? 2 : 1), [&] { return launch_conv_in(latents, n_lat, B, c.in_channels, H, W, u->conv_in.w, u->conv_in.b, c0, h.hi, s, h.lo); });
     int ch = c0;
     skips.push_back({h, ch});
     // CFG dual batch with one timestep: the first resnet and the first transformer block up to its cross attention are shared
     const bool share = (dup == 2 && nt == 1 && c.down_has_attn[0] && R.v_cfg_share != 0 && !u->down_res[0].empty());
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->down_res[i].size(); ++j) {
-            f16* r;
+            St r;
             if (share && i == 0 && j == 0) {
                 R.B = n_lat;                                          // h holds [uncond | text] copies of the same tensor: use the first
-                f16* r1 = R.resnet(u->down_res[0][0], h, ch, nullptr, 0, H, W);
+                St r1 = R.resnet(u->down_res[0][0], h, ch, St(), 0, H, W);
                 R.B = B;
                 ch = u->down_res[0][0].cout;
                 r = Run_xformer_cfg_shared(R, u->down_att[0][0], r1, H, W, n_lat);
-                R.release(r1);
+                R.srelease(r1);
             } else {
-                r = R.resnet(u->down_res[i][j], h, ch, nullptr, 0, H, W);
+                r = R.resnet(u->down_res[i][j], h, ch, St(), 0, H, W);
                 ch = u->down_res[i][j].cout;
-                if (c.down_has_attn[i]) { f16* a = R.xformer(u->down_att[i][j], r, H, W); R.release(r); r = a; }
+                if (c.down_has_attn[i]) { St a = R.xformer(u->down_att[i][j], r, H, W); R.srelease(r); r = a; }
             }
             h = r; skips.push_back({h, ch});
         }
         if (u->has_down[i]) {
-            f16* d = R.alloc((size_t)B * (H / 2) * (W / 2) * ch);
-            R.conv(u->down_samp[i], h, ch, nullptr, 0, H, W, H / 2, W / 2, 2, 0, nullptr, nullptr, d, true);
+            St d = R.salloc((size_t)B * (H / 2) * (W / 2) * ch);
+            R.conv(u->down_samp[i], h.hi, ch, nullptr, 0, H, W, H / 2, W / 2, 2, 0, nullptr, St(), d, true);
             H /= 2; W /= 2; h = d; skips.push_back({h, ch});
         }
     }
     // ---- mid ---------------------------------------------------------------------------------------
     {
-        f16* r = R.resnet(u->mid_res[0], h, ch, nullptr, 0, H, W);   // h stays alive: it is on the skip stack
-        f16* a = R.xformer(u->mid_att, r, H, W); R.release(r);
-        f16* r2 = R.resnet(u->mid_res[1], a, ch, nullptr, 0, H, W); R.release(a);
+        St r = R.resnet(u->mid_res[0], h, ch, St(), 0, H, W);   // h stays alive: it is on the skip stack
+        St a = R.xformer(u->mid_att, r, H, W); R.srelease(r);
+        St r2 = R.resnet(u->mid_res[1], a, ch, St(), 0, H, W); R.srelease(a);
         h = r2;
     }
     // ---- up path -----------------------------------------------------------------------------------
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->up_res[i].size(); ++j) {
             auto sk = skips.back(); skips.pop_back();
-            f16* r = R.resnet(u->up_res[i][j], h, ch, sk.first, sk.second, H, W);
-            R.release(h); R.release(sk.first);
+            St r = R.resnet(u->up_res[i][j], h, ch, sk.first, sk.second, H, W);
+            R.srelease(h); R.srelease(sk.first);
             ch = u->up_res[i][j].cout;
-            if (c.up_has_attn[i]) { f16* a = R.xformer(u->up_att[i][j], r, H, W); R.release(r); r = a; }
+            if (c.up_has_attn[i]) { St a = R.xformer(u->up_att[i][j], r, H, W); R.srelease(r); r = a; }
             h = r;
         }
         if (u->has_up[i]) {
-            f16* d = R.alloc((size_t)B * (2 * H) * (2 * W) * ch);
-            R.conv(u->up_samp[i], h, ch, nullptr, 0, H, W, 2 * H, 2 * W, 1, 1, nullptr, nullptr, d, true);
-            R.release(h); H *= 2; W *= 2; h = d;
+            St d = R.salloc((size_t)B * (2 * H) * (2 * W) * ch);
+            R.conv(u->up_samp[i], h.hi, ch, nullptr, 0, H, W, 2 * H, 2 * W, 1, 1, nullptr, St(), d, true);
+            R.srelease(h); H *= 2; W *= 2; h = d;
         }
     }
     // ---- out ---------------------------------------------------------------------------------------
     f16* n = R.alloc((size_t)B * H * W * ch);
-    R.group_norm(u->norm_out, h, ch, nullptr, 0, H * W, true, n);
-    R.release(h);
+    R.group_norm(u->norm_out, h, ch, St(), 0, H * W, true, n);
+    R.srelease(h);
     R.launch(P_MISC, 2.0 * B * H * W * 9.0 * ch * c.out_channels, 2.0 * B * H * W * ch, [&] { return launch_conv_out(n, B, ch, H, W, u->conv_out.w, u->conv_out.b, c.out_channels, out, s); });
     R.release(n); R.release(tscratch); R.release(temb); R.release(tproj);
     return R.rc;
@@ -756,6 +794,14 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     }
     return rc;
 }
+
+int cs_unet_set_residual_precision(CsUNet* u, int mode) {
+    if (!u) CS_FAIL(CS_E_ARG, "unet is NULL");
+    if (mode != CS_RESIDUAL_F16 && mode != CS_RESIDUAL_F16X2) CS_FAIL(CS_E_ARG, "residual precision %d: CS_RESIDUAL_F16 (0) or CS_RESIDUAL_F16X2 (1)", mode);
+    u->residual = mode;
+    return CS_OK;
+}
+int cs_unet_get_residual_precision(const CsUNet* u) { return u ? u->residual : -1; }
 
 int cs_unet_set_profiling(CsUNet* u, int on) { if (!u) return CS_E_ARG; u->profiling = on != 0; return CS_OK; }
 int cs_unet_profile_entries(const CsUNet* u) { return u ? P_COUNT : 0; }

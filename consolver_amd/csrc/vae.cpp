@@ -179,13 +179,16 @@ struct Run {
     // normalised at most two convolutions after it was written (x -> conv1 -> conv2 (+ shortcut) -> next resnet)
     float* st_buf[3] = {nullptr, nullptr, nullptr}; const f16* st_of[3] = {nullptr, nullptr, nullptr}; int st_S[3] = {0, 0, 0}; int st_next = 0;
     size_t st_floats = 0;
+    // gn_fuse is snapshotted once per decode / encode (the process-wide knob cannot change a run in flight); the buffers are ALWAYS reserved, so the
+    // workspace size does not depend on the knob's value at query time
+    bool v_gn_fuse = true;
     void init_stats(size_t floats) {
-        if (!g_tune_gn_fuse) return;
+        v_gn_fuse = g_tune_gn_fuse != 0;
         st_floats = floats;
         for (auto& b : st_buf) b = (float*)alloc(floats * 2);           // (alloc counts halfs)
     }
     float* stats_for_output(const f16* out, int HW, int C) {
-        if (!st_buf[0] || HW % 64 || C % 2 || (size_t)B * (HW / 64) * C > st_floats) return nullptr;
+        if (!v_gn_fuse || !st_buf[0] || HW % 64 || C % 2 || (size_t)B * (HW / 64) * C > st_floats) return nullptr;
         const int k = st_next; st_next = (st_next + 1) % 3;
         st_of[k] = out; st_S[k] = HW / 64;
         return st_buf[k];
@@ -199,7 +202,7 @@ struct Run {
     f16* alloc(size_t halfs) {
         void* p = v->arena.alloc(halfs * sizeof(f16));
         if (!p && rc == CS_OK) { cs_set_error("vae: workspace too small"); rc = CS_E_ARG; }
-        return (f16*)p;
+        return p ? (f16*)p : reinterpret_cast<f16*>((uintptr_t)1 << 41);      // poison base, never dereferenced (nothing is launched once rc is set)
     }
     template <typename F> void launch(double flops, F&& f) {
         if (dry) { v->dry_flops += flops; return; }

@@ -46,6 +46,7 @@ __device__ __forceinline__ f16x8 frag_of(u32x4 v) { union { u32x4 u; f16x8 f; } 
 struct XattnParams {
     const f16* h;        // [M_in rows][320] block input (residual stream)
     f16* out;            // [M rows][320]; may alias h
+    const f16* h_lo; f16* out_lo;   // SPLIT: lo planes of the split-fp16 residual stream (XattnArgs::h_lo / out_lo)
     const f16* ln_g; const f16* ln_b; float ln_eps;
     const f16* wq;       // [320][320]
     const f16* wo; const f16* bo;
@@ -131,6 +132,9 @@ __device__ __forceinline__ void gemm_320(const f16* __restrict__ w, char* smem, 
     }
 }
 
+// SPLIT: the residual stream is split-fp16 (value = h + h_lo).  The LayerNorm reads the hi plane (its output is an fp16 MFMA operand either way: a
+// branch-level rounding); the residual add of the epilogue takes hi + lo and writes both planes, which is where the stream's precision lives.
+template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XT = smem;
@@ -339,20 +343,34 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
         }
         __syncthreads();
         // 128 rows x 40 chunks = 5120 items, 10 per thread: all residual loads of the thread first, then the patch reads, then the stores
-        f16x8 res[10];
+        f16x8 res[10], resl[SPLIT ? 10 : 1];
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
             res[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (m < p.M && !(p.debug & 16)) res[k] = *reinterpret_cast<const f16x8*>(p.h + (size_t)m * C + ch * 8);
+            if constexpr (SPLIT) {
+                resl[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M) resl[k] = *reinterpret_cast<const f16x8*>(p.h_lo + (size_t)m * C + ch * 8);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
             const f16x8 v = *reinterpret_cast<const f16x8*>(patch + row * PROW + ch * 16);
             f16x8 o;
+            if constexpr (SPLIT) {
+                f16x8 l;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)((float)v[e] + (float)res[k][e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e] + (float)res[k][e] + (float)resl[k][e];
+                    o[e] = (f16)f; l[e] = (f16)(f - (float)o[e]);
+                }
+                if (m < p.M) *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * C + ch * 8) = l;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)((float)v[e] + (float)res[k][e]);
+            }
             if (m < p.M && !(p.debug & 16)) *reinterpret_cast<f16x8*>(p.out + (size_t)m * C + ch * 8) = o;
         }
     }
@@ -368,15 +386,18 @@ int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
     if (a.M <= 0) return a.M < 0 ? CS_E_SHAPE : CS_OK;
     if (a.M % a.HW) CS_FAIL(CS_E_SHAPE, "xattn_block: M must be a whole number of samples");
     XattnParams p;
-    p.h = a.h; p.out = a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
+    if ((a.h_lo == nullptr) != (a.out_lo == nullptr)) CS_FAIL(CS_E_ARG, "xattn_block: h_lo and out_lo go together");
+    p.h = a.h; p.out = a.out; p.h_lo = a.h_lo; p.out_lo = a.out_lo; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
     p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = g_tune_debug;
     constexpr size_t lds = XT_BYTES + 2 * WST;      // 163840: XT + two weight stages (the V tile reuses the stages, the epilogue patch XT)
     static bool configured = false;
     if (!configured) {
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL(xattn_block_kernel, dim3(a.M / TM), dim3(512), lds, s, p);
+    if (a.h_lo) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(a.M / TM), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(a.M / TM), dim3(512), lds, s, p);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -82,11 +82,15 @@ def main(argv=None):
     ap.add_argument("--order-dim", type=int, default=4)
     ap.add_argument("--scaler-dim", type=int, default=0)
     ap.add_argument("--num-actions", type=int, default=11)
+    ap.add_argument("--use_conv", "--use-conv", dest="use_conv", action="store_true",
+                    help="gen_ppo.py:399: the policy also sees the cosine-similarity features of the eps history (factor_net_ppo.py:72-73,146-149)")
+    ap.add_argument("--residual", default="f16x2", choices=["f16", "f16x2", "residual_fp32"],
+                    help="residual-stream storage of the UNet executor (include/consolver_hip.h): f16x2 meets the 1e-3 latent gate, f16 is ~8 %% faster")
     args = ap.parse_args(argv)
     rank, world, local, dist = launch.init_distributed()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    unet, vae = HipUNet2DConditionModel(device=dev), HipAutoencoderKL(device=dev)
+    unet, vae = HipUNet2DConditionModel(device=dev, residual=args.residual), HipAutoencoderKL(device=dev)
     if args.synthetic:
         unet.load_state_dict(synthetic_unet_state_dict(unet.manifest()))
         vae.load_state_dict(synthetic_vae_state_dict(vae.manifest()))
@@ -98,7 +102,7 @@ def main(argv=None):
         prompts, pe, ne = load_prompt_cache(args.prompt_cache)
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
                                      order_dim=args.order_dim, scaler_dim=args.scaler_dim,
-                                     factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=args.num_actions))
+                                     factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=args.num_actions, use_conv=args.use_conv))
     if args.policy:
         sch.factor_net.load_state_dict(torch.load(args.policy, map_location="cpu"))
     sch.factor_net.to(dev)
@@ -115,6 +119,7 @@ def main(argv=None):
         print(f"{total} images in {secs:.2f} s = {total / secs:.2f} images/s on {world} GPU(s); per rank: {[c for c, _ in report]}")
     if dist is not None:
         dist.destroy_process_group()
+    return {"images": n, "use_conv": bool(sch.factor_net.use_conv), "residual": unet.residual, "seconds": secs}
 
 
 if __name__ == "__main__":

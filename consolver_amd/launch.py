@@ -75,6 +75,17 @@ def gather_report(dist, count, checksum, device="cpu"):
     return [(int(o[0].item()), float(o[1].item())) for o in out]
 
 
+def gather_rank_records(dist, values, device="cpu"):
+    """all-gather one equal-length float64 vector per rank -> list (indexed by rank) of lists.  bench.py's N > 1 `per_rank` record: rank, local
+    device, images, elapsed, shard bounds, latent checksum -- one small RCCL all-gather after the timed region."""
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if dist is None:
+        return [mine.tolist()]
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [o.tolist() for o in out]
+
+
 def average_gradients(dist, grads):
     """What DistributedDataParallel does to the policy's gradients in the PPO trainer (train_ppo.py:262-266, 8 ranks x 75 k
     parameters = one ~300 KB all-reduce): sum over ranks / world size, in place on the packed gradient vector."""

@@ -64,6 +64,85 @@ def linear(x, w, bias=None, res=None, geglu=False, out=None):
     return out
 
 
+def split_f16(x):
+    """fp32 tensor -> (hi, lo) fp16 planes with hi + lo == x to 22 bits (the split-fp16 residual-stream representation, CS_RESIDUAL_F16X2)."""
+    hi = x.to(torch.float16)
+    lo = (x.float() - hi.float()).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def conv2d_x2(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, res_lo=None, splitk=True, x0_lo=None, x1_lo=None):
+    """cs_op_conv2d_x2: returns (out_hi, out_lo); res / res_lo are the planes of a split-fp16 residual (res_lo may be None); x0_lo / x1_lo (1x1 only)
+    the lo planes of a split-fp16 A operand."""
+    _f16(x0, "x0")
+    B, Hi, Wi, c0 = x0.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    N = w_packed.shape[0]
+    Ho = 2 * Hi if upsample else (Hi // 2 if stride == 2 else Hi)
+    Wo = 2 * Wi if upsample else (Wi // 2 if stride == 2 else Wi)
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float16, device=x0.device)
+    out_lo = torch.empty_like(out)
+    tstride = 0 if (temb is None or temb.shape[0] == 1) else temb.shape[1]
+    ws = None
+    if splitk:
+        ws = _SPLITK_WS.get(x0.device)
+        if ws is None:
+            ws = _SPLITK_WS[x0.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x0.device)
+    L.check(L.lib().cs_op_conv2d_x2(L.ptr(x0), L.ptr(x0_lo), c0, L.ptr(x1), L.ptr(x1_lo), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
+                                    L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(res_lo), L.ptr(out), L.ptr(out_lo),
+                                    L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x0.device)))
+    return out, out_lo
+
+
+def linear_x2(x, w, bias=None, res=None, res_lo=None, splitk=True, want_lo=True, x_lo=None):
+    """cs_op_linear_x2: returns (out_hi, out_lo) (out_lo None with want_lo=False: the fp16 rounding of the fp32 sum only)."""
+    _f16(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    out_lo = torch.empty_like(out) if want_lo else None
+    ws = None
+    if splitk:
+        ws = _SPLITK_WS.get(x.device)
+        if ws is None:
+            ws = _SPLITK_WS[x.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().cs_op_linear_x2(L.ptr(x), L.ptr(x_lo), M, K, L.ptr(w), L.ptr(bias), N, L.ptr(res), L.ptr(res_lo), L.ptr(out), L.ptr(out_lo),
+                                    L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x.device)))
+    return out, out_lo
+
+
+def group_norm_x2(x0, x0_lo, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None, x1_lo=None):
+    _f16(x0, "x0")
+    B = x0.shape[0]
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    HW = x0.numel() // (B * c0)
+    ws = torch.empty(int(L.lib().cs_op_group_norm_workspace(B, c0 + c1)), dtype=torch.uint8, device=x0.device)
+    out = torch.empty(x0.shape[:-1] + (c0 + c1,), dtype=torch.float16, device=x0.device)
+    L.check(L.lib().cs_op_group_norm_x2(L.ptr(x0), L.ptr(x0_lo), c0, L.ptr(x1), L.ptr(x1_lo), c1, B, HW, groups, float(eps), int(silu),
+                                        L.ptr(gamma), L.ptr(beta), L.ptr(ws), L.ptr(out), L.stream_ptr(x0.device)))
+    return out
+
+
+def layer_norm_x2(x, x_lo, gamma, beta, eps=1e-5):
+    _f16(x, "x")
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    L.check(L.lib().cs_op_layer_norm_x2(L.ptr(x), L.ptr(x_lo), L.ptr(gamma), L.ptr(beta), L.ptr(out), M, Cc, float(eps), L.stream_ptr(x.device)))
+    return out
+
+
+def xattn_block_x2(h, h_lo, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None):
+    _f16(h, "h")
+    M, Cc = h.shape
+    hw = hw or M // kv.shape[0]
+    out, out_lo = torch.empty_like(h), torch.empty_like(h)
+    L.check(L.lib().cs_op_xattn_block_x2(L.ptr(h), L.ptr(h_lo), L.ptr(ln_gamma), L.ptr(ln_beta), float(eps), L.ptr(wq), L.ptr(kv), kv.shape[1],
+                                         L.ptr(wo), L.ptr(bo), M, hw, Cc, heads, float((Cc // heads) ** -0.5), L.ptr(out), L.ptr(out_lo),
+                                         L.stream_ptr(h.device)))
+    return out, out_lo
+
+
 def geglu_pack(w, b):
     """host-side permutation of a [2*Hd, K] GEGLU projection into (16 value | 16 gate) row blocks."""
     w = w.detach().to("cpu", torch.float16).contiguous()

@@ -80,7 +80,18 @@ class FMPPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         src = pretrained_model_name_or_path
         if isinstance(src, dict):
             return cls.from_config({**KONTEXT_SCHEDULER_CONFIG, **src}, return_unused_kwargs=return_unused_kwargs, **kw)
-        local = src is not None and os.path.exists(os.path.join(str(src), subfolder or "", cls.config_name))
+        local = src is not None and (os.path.exists(os.path.join(str(src), subfolder or "", cls.config_name)) or os.path.isfile(str(src)))
+        if not local and src is not None and not HAVE_DIFFUSERS:
+            # a filesystem-looking path that does not exist is a mistake, not a hub id: plausible-but-wrong shift parameters must not load silently
+            looks_like_path = os.path.isabs(str(src)) or str(src).startswith((".", "~")) or os.path.isdir(str(src)) or str(src).count("/") != 1
+            if looks_like_path:
+                raise EnvironmentError(f"{src!r}: no {cls.config_name} under {os.path.join(str(src), subfolder or '')!r}")
+            warnings.warn(f"{src!r} is taken for a hub id (no network here): using the published FLUX.1-Kontext scheduler config")
+        if local and os.path.isfile(str(src)):
+            import json
+            with open(str(src)) as f:
+                return cls.from_config({**KONTEXT_SCHEDULER_CONFIG, **{k: v for k, v in json.load(f).items() if not k.startswith("_")}},
+                                       return_unused_kwargs=return_unused_kwargs, **kw)
         if local or (HAVE_DIFFUSERS and src is not None):
             try:
                 return super().from_pretrained(src, subfolder=subfolder, return_unused_kwargs=return_unused_kwargs, **kw)

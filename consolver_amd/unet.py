@@ -7,6 +7,12 @@ by their diffusers state-dict names (``load_state_dict``) and packed once by the
 
 Extension used by the native sampling engine: ``dup=2`` runs the CFG dual batch without
 ``torch.cat([latents] * 2)`` (sample b reads latent ``b % B``).
+
+``residual``: storage of the residual stream between kernels (include/consolver_hip.h, CS_RESIDUAL_*):
+``"f16"`` (one fp16 plane: the reference pipeline's own arithmetic class) or ``"f16x2"`` (hi + lo fp16
+planes, 22 significant bits: the adds along the residual stream are fp32-class; this is the mode that meets
+the 1e-3 latent gate against an fp32 evaluation of the graph).  ``"residual_fp32"`` is accepted as an
+alias of ``"f16x2"``.  Every GEMM operand is fp16 in both modes.
 """
 import ctypes as C
 
@@ -23,7 +29,9 @@ class HipUNet2DConditionModel:
     is_consolver_hip = True
     dtype = torch.float16
 
-    def __init__(self, config=None, device="cuda:0"):
+    RESIDUAL_MODES = {"f16": 0, "f16x2": 1, "residual_fp32": 1}
+
+    def __init__(self, config=None, device="cuda:0", residual="f16"):
         cfg = dict(SD15_CONFIG)
         cfg.update(config or {})
         self.config = cfg
@@ -47,6 +55,19 @@ class HipUNet2DConditionModel:
         self._kv_batch = -1
         self._finalized = False
         self._t_buf = None
+        self.residual = "f16"
+        if residual != "f16":
+            self.set_residual_precision(residual)
+
+    def set_residual_precision(self, mode):
+        """"f16" | "f16x2" (alias "residual_fp32"); drops the workspace (its size depends on the mode) and the cached cross-attention K/V."""
+        if mode not in self.RESIDUAL_MODES:
+            raise ValueError(f"residual must be one of {sorted(self.RESIDUAL_MODES)}, got {mode!r}")
+        L.check(L.lib().cs_unet_set_residual_precision(self._h, self.RESIDUAL_MODES[mode]))
+        self.residual = "f16x2" if self.RESIDUAL_MODES[mode] else "f16"
+        self._ws, self._ws_batch = None, 0
+        self.invalidate_kv()
+        return self
 
     def __del__(self):
         try:

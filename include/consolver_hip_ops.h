@@ -73,6 +73,25 @@ int cs_op_xattn_block(const void* h, const void* ln_gamma, const void* ln_beta, 
 /* LayerNorm over the last dim of x[M,C] */
 int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
 
+/* ---- split-fp16 residual-stream forms (CS_RESIDUAL_F16X2, include/consolver_hip.h) ----------------------------------------------
+ * A stream tensor is two fp16 planes, value = hi + lo.  `res_lo` (may be NULL) is the lo plane of `res`; `out_lo` (may be NULL) receives
+ * f16(v - float(f16(v))) for the fp32 value v whose fp16 rounding goes to `out`.  The adds run in fp32 on hi + lo.  Same kernels as the plain
+ * forms (the lo planes ride in the fp32 epilogue).  x0_lo / x1_lo / x_lo (NULL = plain fp16 operand; taps = 1 only) are the lo planes of a split-fp16 A
+ * operand: the k loop runs over the hi planes and then over the lo planes against the same weights, i.e. w (hi + lo) exactly at twice the MFMA work
+ * (the resnet shortcut 1x1 over [x | skip], which consumes the residual stream directly). */
+int cs_op_conv2d_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int Hi, int Wi, int taps, int stride,
+                    int upsample, const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, const void* res_lo,
+                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cs_op_linear_x2(const void* x, const void* x_lo, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo,
+                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* GroupNorm / LayerNorm of split-fp16 sources (x*_lo may be NULL = plain fp16 source) */
+int cs_op_group_norm_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int HW, int groups,
+                        float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream);
+int cs_op_layer_norm_x2(const void* x, const void* x_lo, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
+/* cs_op_xattn_block on a split-fp16 residual stream: the residual add takes h + h_lo and writes out + out_lo */
+int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
+                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, void* stream);
+
 /* transformer GEMM (f16 / bf16, dtype = CS_F16 1 | CS_BF16 2): out[m][n] = act(x[m,:] . w[n,:] + bias[n]) (+ res, * gate);
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
 int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
@@ -120,6 +139,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "attn_qt40": query tiles per wave at head dim 40 (2 | 4, default 4);
  *   "xattn_fused": 1 (default): the cross-attention sub-block at C = 320 runs as one kernel (cs_op_xattn_block) inside cs_unet_forward;
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
+ *   "x2_split_a": CS_RESIDUAL_F16X2 only, bit mask of the GEMMs that read hi + lo of the residual stream (cs_op_conv2d_x2 x0_lo) inside cs_unet_forward:
+ *                1 (default) the resnet shortcut 1x1, 2 proj_out, 3 both, 0 none;
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
  *                cs_op_conv2d_gn, 0 always a separate statistics pass;
  *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 (BN 160: the UNet) or N % 128 == 0 (BN 128: the VAE) run on the loader-wave kernel
@@ -140,6 +161,10 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                conv3_lw_kernel, tools/conv_lw_trace.py), 32768 no staging inside the k loop, 65536 activations from the
  *                zero page, 131072 the same k step staged every time; the halo conv kernel has its own bits (csrc/igemm.hip) */
 int cs_set_tuning(const char* key, int value);
+/* values outside a knob's documented range are rejected (CS_E_ARG).  cs_get_tuning reads a knob; cs_reset_tuning restores every default
+ * (the test suite calls it after each test, so a test that fails inside a try / finally cannot leak a knob into the next one). */
+int cs_get_tuning(const char* key, int* value);
+int cs_reset_tuning(void);
 /* Timing experiments only: with cs_set_tuning("debug", 16384) every workgroup of the 256-row GEMM kernel records wall-clock stamps
  * (100 MHz) -- [slot][6] uint64: entry, first stage landed, k loop done, epilogue issued, stores drained, (XCC id << 32 | HW_ID) --
  * which this call copies to host memory (at most 8192 slots; tools/gemm_timeline.py). */

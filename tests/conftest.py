@@ -30,6 +30,16 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _restore_tuning_knobs():
+    """cs_set_tuning knobs are process globals: whatever a test set (or left set by failing inside its try / finally) is undone before the next
+    test runs.  Only touches the library if some test already loaded it."""
+    yield
+    from consolver_amd import _lib
+    if _lib._lib is not None:
+        _lib.reset_tuning()
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -191,6 +191,17 @@ def test_generate_imgs_driver_writes_sharded_files(tmp_path):
     assert img.shape == (3, 128, 128) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0 and float(img.std()) > 0.01
 
 
+def test_generate_cli_reaches_use_conv_and_residual_modes(tmp_path):
+    """gen_ppo.py:399 `--use_conv` through the package's own CLI (python -m consolver_amd.generate): the policy is built with the cosine
+    features and the fused CFG loop runs with them; full-size synthetic SD1.5 UNet + VAE, 2 prompts, 2 steps."""
+    from consolver_amd import generate as gen
+    r = gen.main(["--out", str(tmp_path / "a"), "--synthetic", "2", "--steps", "2", "--batch-size", "2", "--use_conv", "--num-actions", "11"])
+    assert r["images"] == 2 and r["use_conv"] is True and r["residual"] == "f16x2"
+    assert sorted(f for f in os.listdir(tmp_path / "a") if f.endswith(".png")) == ["0_00000000.png", "0_00000001.png"]
+    r = gen.main(["--out", str(tmp_path / "b"), "--synthetic", "2", "--steps", "2", "--batch-size", "2", "--residual", "f16"])
+    assert r["use_conv"] is False and r["residual"] == "f16" and len(os.listdir(tmp_path / "b")) == 4
+
+
 def test_pipeline_call_surface():
     """gen_ppo.py:289-312 call: pipeline(prompt_embeds=..., num_inference_steps, generator, guidance_scale, height, width).images"""
     from consolver_amd.pipeline import ConsistencySolverPipeline

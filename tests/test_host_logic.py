@@ -249,3 +249,40 @@ def test_forward_process_members_vs_reference(golden):
     np.testing.assert_allclose(f.sigmas.numpy(), g["sigmas"], rtol=2e-7)
     out = f.scale_noise(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["noise"]))
     np.testing.assert_allclose(out.numpy(), g["noisy"], rtol=1e-6, atol=1e-7)
+
+
+PUBLISHED_PARAMS = {   # parameter counts of the REAL checkpoints (literals, not derived from this repo): runwayml/stable-diffusion-v1-5 unet 859,520,964;
+    # its AutoencoderKL decoder 49,490,179 + post_quant_conv 20 (whole VAE 83,653,863 = encoder 34,163,592 + quant_conv 72 + these); openai/clip-vit-large-patch14
+    # text model 123,060,480; black-forest-labs/FLUX.1-Kontext-dev transformer 11,901,408,320
+    "sd15_unet": 859_520_964, "sd15_vae_decoder": 49_490_179 + 20, "clip_l_text": 123_060_480, "flux_kontext_dit": 11_901_408_320}
+
+
+@pytest.mark.parametrize("name", sorted(PUBLISHED_PARAMS))
+def test_weight_manifests_match_published_counts_and_committed_key_lists(name):
+    """structural pin of the third-party denoisers (their packages cannot be installed here): the executor's weight manifest
+    -- the diffusers / transformers state-dict names and shapes a real checkpoint is loaded by -- has the published parameter count and equals
+    the committed list (tools/make_manifests.py) tensor for tensor.  Host only: cs_*_create touches no GPU."""
+    import json
+    import math
+    _ensure_built()
+    from consolver_amd.unet import HipUNet2DConditionModel
+    from consolver_amd.vae import HipAutoencoderKL
+    from consolver_amd.text_encoder import HipCLIPTextModel
+    from consolver_amd.flux import HipFluxTransformer2DModel
+    ctor = {"sd15_unet": HipUNet2DConditionModel, "sd15_vae_decoder": HipAutoencoderKL, "clip_l_text": HipCLIPTextModel,
+            "flux_kontext_dit": HipFluxTransformer2DModel}[name]
+    m = ctor(device="cpu").manifest()
+    assert sum(math.prod(s) for _, s in m) == PUBLISHED_PARAMS[name]
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", name + "_manifest.json")))
+    assert want["params"] == PUBLISHED_PARAMS[name]
+    assert [[k, list(s)] for k, s in m] == want["tensors"]
+    assert len({k for k, _ in m}) == len(m)                    # no duplicate names
+    if name == "sd15_unet":
+        names = {k for k, _ in m}
+        # spot checks of names every SD1.5 checkpoint carries (diffusers UNet2DConditionModel state dict)
+        for k in ("conv_in.weight", "time_embedding.linear_1.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight",
+                  "down_blocks.2.resnets.1.time_emb_proj.bias", "mid_block.attentions.0.proj_out.weight", "up_blocks.1.upsamplers.0.conv.weight",
+                  "up_blocks.3.resnets.2.conv_shortcut.weight", "up_blocks.3.attentions.2.transformer_blocks.0.ff.net.0.proj.bias", "conv_norm_out.bias"):
+            assert k in names, k
+        assert dict(m)["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
+        assert dict(m)["up_blocks.0.resnets.0.conv1.weight"] == (1280, 2560, 3, 3)

@@ -85,13 +85,18 @@ def test_bench_launcher_branch_dry_run():
     assert rec["shards"] == [[0, 16], [16, 32]] and rec["images"] == 16 * 2 * 3
     assert rec["max_elapsed_s"] == 0.002                  # MAX over ranks (rank 1 reported the larger time)
     assert rec["cuda_initialised"] is False
+    # the self-proving N > 1 record: one row per rank, gathered by the collective (launch.gather_rank_records), distinct ranks / devices / shards
+    pr = rec["per_rank"]
+    assert len(pr) == 2 and [p["rank"] for p in pr] == [0, 1] and len({p["device"] for p in pr}) == 2
+    assert [p["prompt_shard"] for p in pr] == [[0, 16], [16, 32]] and all(p["images"] == 16 * 3 for p in pr)
+    assert max(p["elapsed_s"] for p in pr) == rec["max_elapsed_s"]
     # N > 1: nothing but the sampling loop runs around the barriers -- the CPU baseline, the sub-record extras and the vendor ceilings are N = 1 only
     sw = rec["side_work_after_timed_region"]
     assert sw["cpu_baseline"] is False and sw["extras"] is False and sw["ceilings"] is False
     # N = 1 takes the in-process path (no launcher)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     rec1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
-    assert rec1["n_gpus"] == 1 and rec1["shards"] == [[0, 16]]
+    assert rec1["n_gpus"] == 1 and rec1["shards"] == [[0, 16]] and len(rec1["per_rank"]) == 1
     assert rec1["side_work_after_timed_region"]["cpu_baseline"] is True and rec1["side_work_after_timed_region"]["extras"] is True
 
 

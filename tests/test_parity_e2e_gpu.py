@@ -1,9 +1,14 @@
 """End-to-end latent parity of configs[1] (SD1.5 + PPOScheduler, 8 steps, CFG 3, fp16) and where its error comes from.
 
-north_star gate: final latents within 1e-3 relative L2 of the reference on identical seeds / prompts.  The
+north_star gate: final latents within 1e-3 relative L2 of the reference on identical seeds / prompts (GATE below).  The
 reference pipeline is itself fp16 (gen_ppo.py:193-195): fp16 weights, fp16 activation storage between torch ops,
-fp32 accumulation inside the vendor kernels.  Its own distance from the fp32 oracle is therefore not zero, and a
-HIP path cannot be closer to "the reference" than that arithmetic class is to itself.  These tests measure
+fp32 accumulation inside the vendor kernels; its own distance from the fp32 oracle is 1.9e-3.  The HIP engine has two
+residual-stream storage modes (include/consolver_hip.h):
+  * residual="f16x2" (split-fp16 stream, hi + lo planes): asserted AGAINST THE GATE, final latents <= 1.0e-3;
+  * residual="f16"   (one plane, the reference's own arithmetic class): 1.40e-3 measured; it cannot meet the gate (every add onto the
+    stream rounds it: tools/sim_precision.py reproduces the executor's 1.56e-3 per forward from the rounding points alone), so its
+    assertions are "measured + 10 %" regression bounds and the gate is printed next to them.
+These tests measure
 
   (a) the HIP engine's 8-step trajectory on the FULL SD1.5 UNet against UNetOracle + PPOSchedulerOracle (fp32, CPU)
       with replayed action indices, with the per-step drift and the teacher-forced per-forward eps error printed;
@@ -31,6 +36,7 @@ from oracle.unet_oracle import UNetOracle
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+GATE = 1.0e-3          # north_star: latents within 1e-3 relative fp32 of the reference
 
 
 def rel_l2(a, b):
@@ -107,8 +113,8 @@ def cast32(hook):
     return f
 
 
-def build_full(seed=7):
-    u = HipUNet2DConditionModel({}, device=DEV)
+def build_full(seed=7, residual="f16"):
+    u = HipUNet2DConditionModel({}, device=DEV, residual=residual)
     sd = synthetic_unet_state_dict(u.manifest(), seed=seed)
     u.load_state_dict(sd)
     return u, sd
@@ -118,6 +124,7 @@ def build_full(seed=7):
 def test_forward_error_budget_and_class_attribution():
     """(b) + (c): one CFG dual-batch forward of the full SD1.5 UNet at three timesteps of the 8-step grid."""
     u, sd = build_full()
+    ux2, _ = build_full(residual="f16x2")
     torch.set_num_threads(16)
     orc = UNetOracle(sd, u.config)                                            # the oracle: CPU fp32
     t16 = UNetOracle(sd, u.config, device=DEV, dtype=torch.float16)          # comparator: plain torch fp16 on the GPU
@@ -132,7 +139,8 @@ def test_forward_error_budget_and_class_attribution():
         e_t16 = rel_l2(t16(torch.cat([lat] * 2), t, ctx).float(), want)
         got = u(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0]
         e_hip = rel_l2(got.float(), want)
-        row = dict(t=t, torch_fp16=e_t16, hip_executor=e_hip)
+        e_x2 = rel_l2(ux2(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float(), want)
+        row = dict(t=t, torch_fp16=e_t16, hip_executor=e_hip, hip_executor_f16x2=e_x2)
         if t == 499:
             for c in CLASSES + ["all"]:
                 hyb = UNetOracle(sd, u.config, device=DEV, dtype=torch.float16)
@@ -153,9 +161,12 @@ def test_forward_error_budget_and_class_attribution():
     for r in rows:
         print("  " + "\n    ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
     print(f"  worst HIP / torch-fp16 ratio = {worst_ratio:.3f}")
+    print(f"  gate (north_star, on the 8-step latents): {GATE:.1e}; per-forward eps error is printed for attribution, the latents are what is gated")
     for r in rows:
         assert r["hip_executor"] <= 1.25 * r["torch_fp16"], r
-        assert r["hip_executor"] < 2.05e-3, r                     # absolute bound: measured 1.49e-3 .. 1.56e-3 (round 3: one rounding per residual layer), + 30 %
+        assert r["hip_executor"] < 1.72e-3, r                     # f16 stream: regression bound = measured 1.49e-3 .. 1.56e-3 + 10 % (gate 1.0e-3 not met in this mode)
+        assert r["hip_executor_f16x2"] < 1.1e-3, r                # f16x2 stream: measured (round 4) + 10 %; the emulation of its rounding points gives 0.996e-3 at t = 499
+        assert r["hip_executor_f16x2"] < 0.72 * r["hip_executor"], r
 
 
 def _scheduler(seed=11):
@@ -184,6 +195,7 @@ def _oracle_sched(w):
 def test_eight_step_trajectory_full_unet_vs_oracle(B):
     """(a): configs[1]'s 8 steps (trailing grid 999..124, CFG 3, order 4) on the full UNet."""
     u, sd = build_full()
+    ux2, _ = build_full(residual="f16x2")
     sch, w = _scheduler()
     n, g = 8, 3.0
     idx = np.random.default_rng(6).integers(0, 11, size=(n, B, 3))
@@ -201,6 +213,15 @@ def test_eight_step_trajectory_full_unet_vs_oracle(B):
         eps = u(x, t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
         x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
         hip_traj.append(x.float().cpu().numpy())
+    # the same loop on the split-fp16 residual stream (the gated mode)
+    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+    sch.set_timesteps(n, device=DEV)
+    x = noise.to(DEV)
+    x2_traj = []
+    for i, t in enumerate(sch.timesteps):
+        eps = ux2(x, t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
+        x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
+        x2_traj.append(x.float().cpu().numpy())
     # the engine runs the same loop (ring buffers, no allocation): bit-identical final latents
     sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
     eng = SDSamplingEngine(u, sch, guidance_scale=g)
@@ -222,25 +243,32 @@ def test_eight_step_trajectory_full_unet_vs_oracle(B):
         xo_h = torch.from_numpy(xo).half()
         e_or = orc_u(torch.cat([torch.from_numpy(xo)] * 2), t, ctx.float()).numpy()     # the oracle itself stays fp32 end to end
         e_hip = u(xo_h.to(DEV), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0].float().cpu().numpy()
+        e_x2 = ux2(xo_h.to(DEV), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0].float().cpu().numpy()
         e_16 = t16_u(torch.cat([xo_h] * 2), t, ctx).float().cpu().numpy()
         # free-running pipelines
         xo = s_or.step(so.cfg_combine(e_or[:B], e_or[B:], g), t, xo, idx[i], cond_dtype="f16")["prev_sample"]
         f16 = t16_u(torch.cat([torch.from_numpy(x16).half()] * 2), t, ctx).float().cpu().numpy()
         ec = so.round_f16(so.cfg_combine(so.round_f16(f16[:B]), so.round_f16(f16[B:]), g))
         x16 = so.round_f16(s_16.step(ec, t, x16, idx[i], cond_dtype="f16")["prev_sample"])
-        rows.append(dict(step=i, t=t, fwd_hip=rel_l2(e_hip, e_or), fwd_t16=rel_l2(e_16, e_or),
-                         drift_hip=rel_l2(hip_traj[i], xo), drift_t16=rel_l2(x16, xo)))
-    print(f"\n8-step trajectory, full SD1.5 UNet, B={B}, CFG 3 (relative L2 vs the fp32 oracle):")
+        rows.append(dict(step=i, t=t, fwd_hip=rel_l2(e_hip, e_or), fwd_x2=rel_l2(e_x2, e_or), fwd_t16=rel_l2(e_16, e_or),
+                         drift_hip=rel_l2(hip_traj[i], xo), drift_x2=rel_l2(x2_traj[i], xo), drift_t16=rel_l2(x16, xo)))
+    print(f"\n8-step trajectory, full SD1.5 UNet, B={B}, CFG 3 (relative L2 vs the fp32 oracle; gate on the final latents {GATE:.1e}):")
     for r in rows:
-        print("  step {step} t={t:3d}  forward: hip {fwd_hip:.3e} torch-fp16 {fwd_t16:.3e}   "
-              "latents: hip {drift_hip:.3e} torch-fp16 {drift_t16:.3e}".format(**r))
-    final_hip, final_t16 = rows[-1]["drift_hip"], rows[-1]["drift_t16"]
-    assert np.isfinite(got).all()
+        print("  step {step} t={t:3d}  forward: f16x2 {fwd_x2:.3e} f16 {fwd_hip:.3e} torch-fp16 {fwd_t16:.3e}   "
+              "latents: f16x2 {drift_x2:.3e} f16 {drift_hip:.3e} torch-fp16 {drift_t16:.3e}".format(**r))
+    final_hip, final_x2, final_t16 = rows[-1]["drift_hip"], rows[-1]["drift_x2"], rows[-1]["drift_t16"]
+    print(f"  final latents: f16x2 {final_x2:.3e} (gate {GATE:.1e}: {'MET' if final_x2 <= GATE else 'NOT MET'}), "
+          f"f16 {final_hip:.3e} (gate not met in this mode; regression bound 1.54e-3), torch-fp16 class {final_t16:.3e}")
+    assert np.isfinite(got).all() and np.isfinite(x2_traj[-1]).all()
+    # ---- the gate: split-fp16 residual stream
+    assert final_x2 <= GATE, final_x2
+    for r in rows:
+        assert r["drift_x2"] <= GATE, r                          # at every step of the trajectory, not only the last
+    # ---- f16 stream: the reference's own arithmetic class; regression bounds = measured + 10 %
     for r in rows:
         assert r["fwd_hip"] <= 1.25 * r["fwd_t16"], r
-    # end-to-end: no worse than the fp16 arithmetic class of the reference pipeline (+25 %), and an absolute bound
     assert final_hip <= 1.25 * final_t16 + 2e-4, (final_hip, final_t16)
-    assert final_hip < 1.82e-3, final_hip                         # measured 1.40e-3 at B = 2 (torch-fp16 class: 1.94e-3), + 30 %
+    assert final_hip < 1.54e-3, final_hip                         # measured 1.40e-3 at B = 2, 1.35e-3 at B = 16 (torch-fp16 class: 1.94e-3), + 10 %
 
 
 def test_two_rollouts_with_different_prompts_do_not_share_kv():

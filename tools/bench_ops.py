@@ -18,12 +18,14 @@ def timeit(fn, iters=10):
 
 B = 32
 rows = []
+shapes = []      # per timed shape: tag + algorithmic bytes (operands read once, outputs written once); CS_SHAPES_JSON=path dumps it (tools/pmc_traffic.sh)
 def lin(M, K, N, geglu=False, res=False, tag=""):
     x, w, b = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N)
     r = rnd(M, N) if res else None
     ms = timeit(lambda: ops.linear(x, w, b, res=r, geglu=geglu))
     fl = 2.0 * M * K * N
     rows.append((f"linear{'+geglu' if geglu else ''}{'+res' if res else ''} {tag}", M, K, N, ms, fl / ms / 1e9))
+    shapes.append({"tag": rows[-1][0], "alg_bytes": 2.0 * (M * K + N * K + M * (N // 2 if geglu else N) * (2 if res else 1))})
 
 def conv(H, cin, cout, taps=9, stride=1, up=False, tag=""):
     x = rnd(B, H, H, cin); k = 3 if taps == 9 else 1
@@ -32,12 +34,14 @@ def conv(H, cin, cout, taps=9, stride=1, up=False, tag=""):
     Ho = 2 * H if up else H // stride
     fl = 2.0 * B * Ho * Ho * taps * cin * cout
     rows.append((f"conv{k}x{k} s{stride}{' up' if up else ''} {tag}", B * Ho * Ho, taps * cin, cout, ms, fl / ms / 1e9))
+    shapes.append({"tag": rows[-1][0], "alg_bytes": 2.0 * (B * H * H * cin + cout * taps * cin + B * Ho * Ho * cout)})
 
 def attn(N, C, Nk=None, tag=""):
     Nk = Nk or N
     q, k, v = rnd(B, N, C), rnd(B, Nk, C), rnd(B, Nk, C)
     ms = timeit(lambda: ops.attention(q, k, v, 8))
     rows.append((f"attention dh={C // 8} {tag}", N, Nk, C, ms, 4.0 * B * N * Nk * C / ms / 1e9))
+    shapes.append({"tag": rows[-1][0], "alg_bytes": 2.0 * B * (2 * N * C + 2 * Nk * C)})
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 for kv in os.environ.get("CS_TUNE", "").split(","):
@@ -65,6 +69,7 @@ if which in ("all", "attn"):
     qf, kf, vf = rnd(1, 8704, 3072), rnd(1, 8704, 3072), rnd(1, 8704, 3072)
     ms = timeit(lambda: ops.attention(qf, kf, vf, 24))
     rows.append(("attention dh=128 FLUX", 8704, 8704, 3072, ms, 4.0 * 8704 * 8704 * 3072 / ms / 1e9))
+    shapes.append({"tag": rows[-1][0], "alg_bytes": 2.0 * 4 * 8704 * 3072})
 if which in ("gemm2",):
     # FLUX-Kontext DiT linears (bf16, 8192 image + 512 text tokens, D = 3072) through the 256x256 transformer GEMM
     from consolver_amd import _lib as L
@@ -106,6 +111,24 @@ if which in ("xattn",):
         return ops.linear(a.view(M, C), wo, bo, res=h)
     ms = timeit(unfused)
     rows.append(("LN + to_q + attn + to_out (4 kernels)", M, Nk, C, ms, fl / ms / 1e9))
+if which in ("norm",):
+    # GroupNorm (finalize + apply on producer statistics: the executor's common case) and LayerNorm on the UNet's shapes
+    for H, c0, c1, tag in [(64, 320, 0, "L0"), (64, 640, 320, "L0 cat"), (32, 640, 0, "L1"), (32, 1280, 640, "L1 cat"), (16, 1280, 0, "L2"), (16, 1280, 1280, "L2 cat")]:
+        x0 = rnd(B, H * H, c0); x1 = rnd(B, H * H, c1) if c1 else None
+        C = c0 + c1
+        g, b = rnd(C), rnd(C)
+        s0 = torch.zeros(B, H * H // 64, c0 // 2, 2, device=dev); s1 = torch.zeros(B, H * H // 64, max(c1, 2) // 2, 2, device=dev) if c1 else None
+        ms = timeit(lambda: ops.group_norm(x0, g, b, 32, 1e-5, True, x1=x1, stats0=s0, stats1=s1))
+        rows.append((f"group_norm pre {tag}", B * H * H, C, 0, ms, 4.0 * B * H * H * C / ms / 1e9))
+        shapes.append({"tag": rows[-1][0], "alg_bytes": 4.0 * B * H * H * C})
+    for M, C, tag in [(131072, 320, "L0"), (32768, 640, "L1"), (8192, 1280, "L2")]:
+        x, g, b = rnd(M, C), rnd(C), rnd(C)
+        ms = timeit(lambda: ops.layer_norm(x, g, b))
+        rows.append((f"layer_norm {tag}", M, C, 0, ms, 4.0 * M * C / ms / 1e9))
+        shapes.append({"tag": rows[-1][0], "alg_bytes": 4.0 * M * C})
+if os.environ.get("CS_SHAPES_JSON"):
+    import json
+    json.dump(shapes, open(os.environ["CS_SHAPES_JSON"], "w"), indent=1)
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
 if which in ("convgn",):
     # cost of the GroupNorm-statistics epilogue: the same conv / 1x1 with and without gn_stats

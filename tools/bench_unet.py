@@ -1,4 +1,5 @@
 """UNet forward A/B tool: batch 32 (16 images x CFG) SD1.5 forward, mean of N runs + per-class profile.
+CS_RESIDUAL=f16|f16x2 selects the residual-stream mode (default f16x2); CS_PROFILE_JSON=path dumps the per-class profile (ms, flops, algorithmic bytes).
 CS_TUNE="key=value,..." sets library tuning knobs; CONSOLVER_HIP_LIB selects an alternative build."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +10,7 @@ dev = "cuda:0"
 for kv in os.environ.get("CS_TUNE", "").split(","):
     if "=" in kv:
         k, v = kv.split("="); ops.set_tuning(k, int(v))
-u = HipUNet2DConditionModel(device=dev); u.load_state_dict(synthetic_unet_state_dict(u.manifest()))
+u = HipUNet2DConditionModel(device=dev, residual=os.environ.get("CS_RESIDUAL", "f16x2")); u.load_state_dict(synthetic_unet_state_dict(u.manifest()))
 NL = int(os.environ.get("CS_NLAT", "16"))
 lat = torch.randn(NL, 4, 64, 64, device=dev).half()
 ctx = synthetic_prompt_embeds(2 * NL).half().to(dev)
@@ -25,3 +26,6 @@ ms = a.elapsed_time(b) / n
 print(f"forward {ms:.3f} ms  {u.flops(2 * NL) / ms / 1e9:.1f} TFLOP/s  ({u.flops(2 * NL) / ms / 1e9 / 2500 * 100:.1f} % of fp16 MFMA peak)")
 u.set_profiling(True); u(lat, t, encoder_hidden_states=ctx, dup=2, reuse_kv=True); pr = u.profile(); u.set_profiling(False)
 print("  ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()))
+if os.environ.get("CS_PROFILE_JSON"):
+    import json
+    json.dump(pr, open(os.environ["CS_PROFILE_JSON"], "w"), indent=1)
