@@ -50,11 +50,17 @@ struct IgemmParams {
     // split-fp16 A operand of a 1x1 / linear layer (IgemmArgs::a0_lo / a1_lo): k steps [0, KTh) multiply the hi planes a0 | a1, k steps [KTh, KT = 2 KTh) the lo
     // planes a0_lo | a1_lo against the SAME weight columns (the k offset into w wraps at KTh).  Without lo planes KTh == KT and nothing wraps.
     const f16* a0_lo; const f16* a1_lo; int KTh;
+    // LayerNorm folded into the GEMM that consumes it (IgemmArgs::row_stats / ln_*):
+    //   producer side: row_stats[M][N / COLS][2] = (sum, sum of squares) of every output row over each wave's COLS columns, from the fp32 values of the epilogue;
+    //   consumer side: out = rstd_m (acc - mean_m ln_s[n]) + ln_b[n] with (mean, rstd) of row m from ln_stats[M][ln_groups][2] over ln_C channels.
+    float* row_stats;
+    const float* ln_stats; int ln_groups; float ln_inv_c, ln_eps; const float* ln_s; const float* ln_b;
     int tiles_n, nblk;
     float* partial;     // split-K scratch of the generic kernel ([splits][M][N] fp32) or null
     int debug;          // timing experiments only: bit0 skip epilogue, bit1 skip the k loop
     float* gn_stats;    // GroupNorm partial sums of the output, [M / 64][N / 2][2], written by the epilogue (IgemmArgs::gn_stats) or null
     int gm;             // gemm_big_kernel tile order: bands of gm tile rows walked column-major (1 = plain row-major)
+    int pn;             // tile_of: 0 = contiguous run of tiles per XCD, > 0 = the XCDs as an (8 / pn) x pn grid over (row tiles, column tiles)
 };
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
@@ -70,6 +76,31 @@ __device__ __forceinline__ void trace_stamp(int debug, int slot, int which) {
             g_trace[slot * CS_TRACE_W + 5] = ((unsigned long long)xcc << 32) | hw;
         }
     }
+}
+
+// Workgroup -> tile.  Dispatch deals workgroups to the 8 XCDs (private L2 each) round-robin, so XCD = bid & 7 and bid >> 3 is the slot inside it.
+//   pn == 0: an XCD owns a contiguous run of tile ids (row-major; bands of gm tile rows walked column-major when gm > 1): every XCD streams ALL weight panels
+//            and 1/8 of the activation rows through its L2 -- right when the activations dominate the bytes (the 64 x 64 / 32 x 32 levels);
+//   pn  > 0: the XCDs form an (8 / pn) x pn grid over (row tiles, column tiles): an XCD streams 1/pn of the weights and pn/8 of the activations.  At the
+//            16 x 16 / 8 x 8 levels the weights ARE the bytes (1280 x 1280 x 9: 29.5 MB against 5-21 MB of activations) and the contiguous order pulled them
+//            into all eight L2s: 8.3x / 3.9x the algorithmic bytes (profiles/r04_pmc_traffic_by_kernel.txt).  The host picks pn (launch_igemm_impl).
+__device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_n, int gm, int pn, int& tm, int& tn) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    if (pn > 0) {
+        const int px = 8 / pn, sub_n = tiles_n / pn, sub_m = (nblk / tiles_n) / px;
+        const int xm = xcd / pn, xn = xcd - xm * pn;
+        const int lm = slot / sub_n, ln = slot - lm * sub_n;
+        tm = xm * sub_m + lm; tn = xn * sub_n + ln;
+        return;
+    }
+    const int q = nblk >> 3, r = nblk & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    if (gm > 1) {
+        const int tiles_m = nblk / tiles_n;
+        const int band = id / (gm * tiles_n), rem = id - band * (gm * tiles_n);
+        const int gsz = min(gm, tiles_m - band * gm);
+        tn = rem / gsz; tm = band * gm + (rem - tn * gsz);
+    } else { tm = id / tiles_n; tn = id - tm * tiles_n; }
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -143,6 +174,27 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     // the sum of squares of a channel PAIR per instruction (a group always holds whole pairs).
     const bool stats = !GEGLU && GROUP == NT && p.gn_stats != nullptr;
     float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
+    // LayerNorm folded into this GEMM (p.ln_stats): the A operand was the RAW hidden state and the weights carry gamma, so the row's (mean, rstd) enter here:
+    // value = rstd (acc - mean s[n]) + b'[n] = acc rstd + (b'[n] - (mean rstd) s[n]); the lane's MT rows are patch rows 16 j + (lane & 15)
+    constexpr bool LINEAR = std::is_same<RowMap, LinearRows>::value;      // (only linear / 1x1 layers produce or consume LayerNorm statistics: the conv kernels carry none of this code)
+    const bool lnf = LINEAR && p.ln_stats != nullptr;
+    float ln_r[MT], ln_mr[MT];
+    if (lnf) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = rows(j * 16 + i16);
+            float s1 = 0.f, s2 = 0.f;
+            if (m >= 0) {
+                const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
+                for (int g = 0; g < p.ln_groups; ++g) { const f32x2 t = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += t[0]; s2 += t[1]; }
+            }
+            const float mean = s1 * p.ln_inv_c;
+            ln_r[j] = __builtin_amdgcn_rsqf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps);
+            ln_mr[j] = mean * ln_r[j];
+        }
+    }
+    // row statistics of THIS layer's output for a LayerNorm folded into its consumer (p.row_stats; F32 path only): one (sum, sum of squares) per row and wave
+    const bool rstats = LINEAR && F32 && !GEGLU && GROUP == NT && p.row_stats != nullptr;
 #pragma unroll
     for (int grp = 0; grp < NT / GROUP; ++grp)
 #pragma unroll
@@ -153,7 +205,17 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             const int i = grp * GROUP + ii;
             const int n = n_base + i * 16 + g4;                // (GEGLU: row of the permuted weight, value half)
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
+            float sv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+            if (lnf) {                                          // folded LayerNorm: b' (fp32, holds the layer's own bias) and s = row sums of the folded weight
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.ln_b + n), u = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bv[r] = t[r]; sv[r] = u[r]; }
+                if (GEGLU) {
+                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(p.ln_b + n + 16), u2 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { bg[r] = t2[r]; sg[r] = u2[r]; }
+                }
+            } else if (p.bias) {
                 const f16x4 t = *reinterpret_cast<const f16x4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = (float)t[r];
@@ -166,19 +228,31 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
             for (int jj = 0; jj < RT; ++jj) {
                 const int j = rh * RT + jj;
+                // (folded LayerNorm: acc rstd + (b' - mean rstd s); otherwise acc + bias)
+                f32x4 av = acc[i][j];
+                float bj[4] = {bv[0], bv[1], bv[2], bv[3]};
+                if (lnf) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { av[r] *= ln_r[j]; bj[r] = bv[r] - ln_mr[j] * sv[r]; }
+                }
                 if constexpr (F32) {
-                    const f32x4 o = {acc[i][j][0] + bv[0], acc[i][j][1] + bv[1], acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]};
+                    const f32x4 o = {av[0] + bj[0], av[1] + bj[1], av[2] + bj[2], av[3] + bj[3]};
                     *reinterpret_cast<f32x4*>(wave_lds + (jj * 16 + i16) * ROWB + (ii * 16 + g4) * 4) = o;
                 } else {
                     f16x4 o;
                     if (GEGLU) {
-                        const f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
-                        const f32x2 g01 = gelu_erf2(f32x2{gt[0] + bg[0], gt[1] + bg[1]}), g23 = gelu_erf2(f32x2{gt[2] + bg[2], gt[3] + bg[3]});
-                        o[0] = (f16)((acc[i][j][0] + bv[0]) * g01[0]); o[1] = (f16)((acc[i][j][1] + bv[1]) * g01[1]);
-                        o[2] = (f16)((acc[i][j][2] + bv[2]) * g23[0]); o[3] = (f16)((acc[i][j][3] + bv[3]) * g23[1]);
+                        f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
+                        float gj[4] = {bg[0], bg[1], bg[2], bg[3]};
+                        if (lnf) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { gt[r] *= ln_r[j]; gj[r] = bg[r] - ln_mr[j] * sg[r]; }
+                        }
+                        const f32x2 g01 = gelu_erf2(f32x2{gt[0] + gj[0], gt[1] + gj[1]}), g23 = gelu_erf2(f32x2{gt[2] + gj[2], gt[3] + gj[3]});
+                        o[0] = (f16)((av[0] + bj[0]) * g01[0]); o[1] = (f16)((av[1] + bj[1]) * g01[1]);
+                        o[2] = (f16)((av[2] + bj[2]) * g23[0]); o[3] = (f16)((av[3] + bj[3]) * g23[1]);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (f16)(acc[i][j][r] + bv[r]);
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)(av[r] + bj[r]);
                     }
                     const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
                     *reinterpret_cast<f16x4*>(wave_lds + (jj * 16 + i16) * ROWB + col * 2) = o;
@@ -196,6 +270,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             if constexpr (F32) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32), v1 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32 + 16);
                 f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+                float rs1 = 0.f, rs2 = 0.f;
                 if (m >= 0) {
                     const size_t off = (size_t)m * Nout + n0 + ch * 8;
                     float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -216,6 +291,10 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
+                    if (rstats) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { rs1 += f[r]; rs2 += f[r] * f[r]; }
+                    }
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
                     if (p.out_lo) {                           // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
                         f16x8 l;
@@ -227,6 +306,9 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                 // (the fp16 values of chunk ch go where the fp32 values of chunks ch / 2 were: every lane has read its fp32 slot by now -- LDS operations of a
                 //  wave execute in order -- and later iterations read other rows)
                 if (stats) *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = o;
+                // (row statistics: the chunk's partial sums over the first bytes of the row's fp32 area, same argument; a row that straddles two iterations
+                //  is read by the next one from byte 32 ch upwards and written here below byte 8 ch)
+                if (rstats) *reinterpret_cast<f32x2*>(wave_lds + row * ROWB + ch * 8) = f32x2{rs1, rs2};
             } else {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
                 if (m >= 0) {
@@ -235,6 +317,19 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                 } else if (stats) {
                     *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
+            }
+        }
+        if constexpr (F32) {
+            if (rstats && lane < RT * 16) {                      // one lane per patch row: add the row's CH partial sums, one 8-byte store per row
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int c2 = 0; c2 < CH / 2; ++c2) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(wave_lds + lane * ROWB + c2 * 16);
+                    a1 += t[0] + t[2]; a2 += t[1] + t[3];
+                }
+                if (CH & 1) { const f32x2 t = *reinterpret_cast<const f32x2*>(wave_lds + lane * ROWB + (CH - 1) * 8); a1 += t[0]; a2 += t[1]; }
+                const int m = rows(rh * RT * 16 + lane);
+                if (m >= 0) *reinterpret_cast<f32x2*>(p.row_stats + ((size_t)m * (p.N / COLS) + n_base / COLS) * 2) = f32x2{a1, a2};
             }
         }
         if (stats && lane < COLS / 4) {
@@ -259,7 +354,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
     if constexpr (!GEGLU) {
-        if (p.temb || p.res || p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
+        if (p.temb || p.res || p.out_lo || p.row_stats) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
     }
     igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false>(p, acc, rows, n_base, lane, wave_lds);
 }
@@ -341,12 +436,8 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.e.nblk >> 3, r = p.e.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = id / p.e.tiles_n, tn = id - tm * p.e.tiles_n;
+    int tm, tn;
+    tile_of(blockIdx.x, p.e.nblk, p.e.tiles_n, 1, p.e.pn, tm, tn);
     const int n_blk = tn * BN;
     // tile -> (first image, patch origin)
     int b0, y0, x0;
@@ -652,12 +743,8 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.e.nblk >> 3, r = p.e.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = id / p.e.tiles_n, tn = id - tm * p.e.tiles_n;
+    int tm, tn;
+    tile_of(blockIdx.x, p.e.nblk, p.e.tiles_n, 1, p.e.pn, tm, tn);
     const int n_blk = tn * BN;
     int b0, y0, x0;
     if (p.PP == 1) { b0 = tm << (8 - p.trw_shift); y0 = 0; x0 = 0; }
@@ -968,18 +1055,8 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     int tm, tn;
-    if (p.gm > 1) {
-        const int tiles_m = p.nblk / p.tiles_n;
-        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
-        const int gsz = min(p.gm, tiles_m - band * p.gm);
-        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
-    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+    tile_of(blockIdx.x, p.nblk, p.tiles_n, p.gm, p.pn, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BN;
     const int KT = p.KT;
 
@@ -1128,18 +1205,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     int tm, tn;
-    if (p.gm > 1) {
-        const int tiles_m = p.nblk / p.tiles_n;
-        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
-        const int gsz = min(p.gm, tiles_m - band * p.gm);
-        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
-    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+    tile_of(blockIdx.x, p.nblk, p.tiles_n, p.gm, p.pn, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BNX;
     const int KT = p.KT;
 
@@ -1258,6 +1325,23 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
 }
 
+// row statistics of a [M][C] tensor (value = x + x_lo when x_lo != null): stats[M][1][2] = (sum, sum of squares) per row.  The fallback of IgemmArgs::row_stats
+// for the kernels whose epilogue cannot leave them (split-K forms), and cs_op_row_stats.  One wave per row.
+__global__ __launch_bounds__(256) void row_stats_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, int M, int C, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + c);
+        f16x8 t2 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (x_lo) t2 = *reinterpret_cast<const f16x8*>(x_lo + (size_t)row * C + c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float f = (float)t[k] + (float)t2[k]; s1 += f; s2 += f * f; }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { stats[2 * (size_t)row] = s1; stats[2 * (size_t)row + 1] = s2; }
+}
+
 // out = sum_s partial[s] + bias + temb + res  (8 channels per thread)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const float* __restrict__ partial, int splits) {
     const int NV = p.N >> 3;
@@ -1271,7 +1355,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
         }
-        if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
+        if (p.ln_stats) {                                      // LayerNorm folded into this GEMM (see igemm_epilogue_impl)
+            float s1 = 0.f, s2 = 0.f;
+            const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
+            for (int g = 0; g < p.ln_groups; ++g) { s1 += st[2 * g]; s2 += st[2 * g + 1]; }
+            const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps), mr = mean * rstd;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] * rstd + (p.ln_b[n + k] - mr * p.ln_s[n + k]);
+        } else if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
         if (p.temb) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n);
@@ -1315,21 +1406,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    // tile order: an XCD's ~32 resident workgroups hold consecutive ids.  Row-major order makes them 32 / tiles_n activation panels x ALL
-    // tiles_n weight panels per k step through that XCD's L2; bands of gm tile rows walked column-major make it gm x 32 / gm
-    // (the FLUX GEMM's order, csrc/gemm2.hip).
     int tm, tn;
-    if (p.gm > 1) {
-        const int tiles_m = p.nblk / p.tiles_n;
-        const int band = id / (p.gm * p.tiles_n), rem = id - band * (p.gm * p.tiles_n);
-        const int gsz = min(p.gm, tiles_m - band * p.gm);
-        tn = rem / gsz; tm = band * p.gm + (rem - tn * gsz);
-    } else { tm = id / p.tiles_n; tn = id - tm * p.tiles_n; }
+    tile_of(blockIdx.x, p.nblk, p.tiles_n, p.gm, p.pn, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BNX;
 
     const int pch = lane & 7;
@@ -1501,12 +1579,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const int wm = w >> 1, wn = w & 1;
 
     // XCD-aware, bijective tile id (blocks b and b+8 share an XCD)
-    int id;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = p.nblk >> 3, r = p.nblk & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    int tm, tn;
+    tile_of(blockIdx.x, p.nblk, p.tiles_n, 1, p.pn, tm, tn);
     const int m_blk = tm * BM, n_blk = tn * BN;
 
     // ---- per-thread staging state: 4 A rows + NBI B rows, one 16-byte chunk each ----------------
@@ -1661,6 +1735,21 @@ int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few
 int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
 int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 or N % 128 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 3: N % 160 == 0 only, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
+int g_tune_xcd_grid = 1;        // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
+
+// tile_of's pn for a launch of tiles_m x tiles_n tiles that reads a_bytes of activations and w_bytes of weights once each algorithmically: per-XCD L2s mean the
+// contiguous order fetches a + 8 w, an (8 / pn) x pn grid pn a + (8 / pn) w.  Switch only for a clear gain (the contiguous order has the banded walk, IgemmParams::gm).
+static int choose_xcd_grid(int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
+    if (!g_tune_xcd_grid) return 0;
+    int best = 0; double best_cost = 0.85 * (a_bytes + 8.0 * w_bytes);
+    for (int pn = 2; pn <= 8; pn *= 2) {
+        const int px = 8 / pn;
+        if (tiles_n % pn || tiles_m % px) continue;
+        const double cost = pn * a_bytes + px * w_bytes;
+        if (cost < best_cost) { best_cost = cost; best = pn; }
+    }
+    return best;
+}
 
 double igemm_flops(const IgemmArgs& a) {
     const double M = (double)a.B * a.Ho * a.Wo;
@@ -1685,7 +1774,8 @@ static int launch_halo_sched(const HaloParams& h, dim3 grid, size_t lds, hipStre
 template <bool UP, int BN, int KH>
 static int launch_halo(const HaloParams& h, dim3 grid, size_t lds, hipStream_t s) { return launch_halo_sched<UP, BN, KH, KH == 2 ? 2 : 0>(h, grid, lds, s); }
 
-static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done) {
+struct LaunchInfo { bool gn_done = false; int row_groups = 0; };    // what the chosen kernel's epilogue left: GroupNorm statistics / row statistics in N / row_groups-column groups
+static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) {
     const int cin = a.c0 + a.c1;
     if (!a.a0 || !a.w || !a.out) CS_FAIL(CS_E_ARG, "igemm: a0, w, out required");
     if (a.taps != 1 && a.taps != 9) CS_FAIL(CS_E_ARG, "igemm: taps must be 1 or 9");
@@ -1701,6 +1791,15 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
     p.res_lo = a.res ? a.res_lo : nullptr; p.out_lo = a.out_lo;
+    p.row_stats = a.row_stats;
+    p.ln_stats = a.ln_stats; p.ln_groups = a.ln_groups; p.ln_inv_c = 1.0f / (float)cin; p.ln_eps = a.ln_eps; p.ln_s = a.ln_s; p.ln_b = a.ln_b;
+    if (a.ln_stats) {
+        if (a.taps != 1 || a.c1 || a.temb || a.res || a.out_lo || a.row_stats || a.gn_stats)
+            CS_FAIL(CS_E_ARG, "igemm: a folded LayerNorm (ln_stats) is the epilogue of a plain linear layer (one source, no temb / residual / lo plane / statistics)");
+        if (!a.ln_s || !a.ln_b || a.ln_groups < 1) CS_FAIL(CS_E_ARG, "igemm: ln_stats needs ln_s, ln_b and ln_groups >= 1");
+    }
+    if (a.row_stats && (a.geglu || a.gn_stats)) CS_FAIL(CS_E_ARG, "igemm: row_stats excludes GEGLU and gn_stats");
+    if (a.row_stats && !a.row_stats_groups) CS_FAIL(CS_E_ARG, "igemm: row_stats needs row_stats_groups (the layout the chosen kernel wrote is returned there)");
     p.a0_lo = a.a0_lo; p.a1_lo = a.c1 ? a.a1_lo : nullptr; p.KTh = p.KT;
     const bool split_a = a.a0_lo != nullptr;
     if (split_a) {
@@ -1713,7 +1812,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
     p.gn_stats = stats_ok ? a.gn_stats : nullptr;
-    p.gm = 1;
+    p.gm = 1; p.pn = 0;
+    const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * cin, w_bytes = 2.0 * a.N * a.taps * cin;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
     if (a.N % 128 == 0) bn = 128;
@@ -1757,7 +1857,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         HaloParams h;
         h.HALO_W = tin_w + 2; h.HALO_IMG = (tin_h + 2) * (tin_w + 2); h.NHALO = IPT * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
         if ((pays || use_halo == 2 || use_halo == 3) && h.NHALO <= HALO_ROWS_MAX && h.NQ <= 64 && (PP == 1 || IPT == 1)) {
-            h.e = p; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n;
+            h.e = p; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n; h.e.row_stats = nullptr; h.e.pn = choose_xcd_grid(tiles_m, tiles_n, a_bytes, w_bytes);       // (row statistics of a conv output: the pass in launch_igemm)
             h.x = a.a0; h.w = a.w; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = NC; h.Ho = Ho; h.Wo = Wo;
             h.tw_shift = TW == 16 ? 4 : 3; h.trw_shift = 0; while ((1 << h.trw_shift) < TRW) ++h.trw_shift;
             h.PX = PX; h.PP = PP;
@@ -1800,7 +1900,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
             else rc = a.upsample ? launch_halo<true, 128, 1>(h, grid, l, s) : launch_halo<false, 128, 1>(h, grid, l, s);
             if (rc != CS_OK) return rc;
             CS_CHECK_LAUNCH();
-            *stats_done = stats_ok && splits == 1;
+            li->gn_done = stats_ok && splits == 1;
             if (splits > 1) {
                 const long total = (long)p.M * (p.N / 8);
                 int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
@@ -1814,7 +1914,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     if (g_tune_biggemm && !conv3 && a.N % 320 == 0) {
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 320;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 2) {
-            p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
+            p.tiles_n = tn; p.nblk = tiles_m * tn; p.pn = choose_xcd_grid(tiles_m, tn, a_bytes, w_bytes); li->gn_done = stats_ok; li->row_groups = a.N / 160;      // gemm_w8 / gemm_big<., 320>: 64 x 160 wave tiles
             p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
             static bool configured = false;
@@ -1847,7 +1947,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
     if (g_tune_biggemm && !conv3 && !a.geglu && a.N % 160 == 0) {       // too few 256 x 320 tiles: 256 x 160 tiles, same 8-wave structure
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 160;
         if (tiles_m * tn >= 192 || g_tune_biggemm == 3) {
-            p.tiles_n = tn; p.nblk = tiles_m * tn; *stats_done = stats_ok;
+            p.tiles_n = tn; p.nblk = tiles_m * tn; p.pn = choose_xcd_grid(tiles_m, tn, a_bytes, w_bytes); li->gn_done = stats_ok;
+            li->row_groups = (g_tune_gemm_lw && !g_tune_debug) ? a.N / 160 : a.N / 80;       // gemm_lw: 64 x 160 wave tiles; gemm_big<., 160>: 64 x 80
             p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 160 * BK * 2);
             static bool configured = false;
@@ -1873,7 +1974,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, bool* stats_done
         }
     }
 generic_tiles:
-    p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n; p.gm = 1; *stats_done = false;
+    p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n; p.gm = 1; p.pn = choose_xcd_grid(tiles_m, p.tiles_n, a_bytes, w_bytes); li->gn_done = false; li->row_groups = 0;
     if (a.geglu) {
         return launch_variant<128, false, true>(p, s);
     }
@@ -1884,18 +1985,37 @@ generic_tiles:
                (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
         if (splits > 1) p.partial = a.splitk_ws;
     }
-    *stats_done = stats_ok && splits == 1;
+    li->gn_done = stats_ok && splits == 1;
+    li->row_groups = (splits == 1 && !conv3) ? a.N / (bn / 2) : 0;          // igemm_kernel: 64 x bn / 2 wave tiles; the split-K reduce leaves no row statistics
     if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
     return conv3 ? launch_variant<160, true, false>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
 }
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-    bool stats_done = false;
-    const int rc = launch_igemm_impl(a, s, &stats_done);
-    if (rc != CS_OK || !a.gn_stats || stats_done) return rc;
+    LaunchInfo li;
+    const int rc = launch_igemm_impl(a, s, &li);
+    if (rc != CS_OK) return rc;
+    if (a.row_stats) {                              // row statistics for a LayerNorm folded into the consumer: by the epilogue, else a pass over the output
+        if (li.row_groups > 0) *a.row_stats_groups = li.row_groups;
+        else {
+            const int M = a.B * a.Ho * a.Wo;
+            hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, (const f16*)a.out, (const f16*)a.out_lo, M, a.N, a.row_stats);
+            CS_CHECK_LAUNCH();
+            *a.row_stats_groups = 1;
+        }
+    }
+    if (!a.gn_stats || li.gn_done) return rc;
     // the chosen kernel has no statistics epilogue (split-K forms) or the knob is off: a statistics pass over the output, same layout
     if (a.geglu || (a.Ho * a.Wo) % 64) CS_FAIL(CS_E_ARG, "igemm: gn_stats needs Ho * Wo %% 64 == 0 and no GEGLU");
     return launch_gn_stats64(a.out, a.B, a.Ho * a.Wo, a.N, a.gn_stats, s);
+}
+
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s) {
+    if (!x || !stats || C % 8) CS_FAIL(CS_E_ARG, "row_stats: x, stats required; C %% 8 == 0");
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x_lo, M, C, stats);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
 }
 
 // timing experiments only: copy the per-workgroup stamps of the last gemm_big_kernel launches run with debug bit 16384 to host memory

@@ -31,9 +31,20 @@ struct IgemmArgs {
     // runs the k loop twice over the same weights, hi planes then lo planes, into one accumulator: W (hi + lo) exactly, 2x the layer's MFMA work.  Used where
     // a GEMM consumes the residual stream directly and its operand rounding is a stream-level error (the resnet shortcut 1x1 over [x | skip]).
     const f16* a0_lo; const f16* a1_lo;
+    // ---- LayerNorm folded into the linear layer that consumes it (diffusers BasicTransformerBlock: norm1 -> to_q/k/v, norm2 -> attn2.to_q, norm3 -> GEGLU proj).
+    // LN(h) W^T + b = rstd (h W'^T - mean s) + b'  with  W' = W diag(gamma) (packed once, fp16),  s[n] = sum_k W'[n][k],  b' = W beta + b  (fp32).  The GEMM reads the
+    // RAW hidden state; the per-row (mean, rstd) come from partial sums its PRODUCER left:
+    //   producer: row_stats != null -> row_stats[M][G][2] = (sum, sum of squares) of every output row over G column groups, G returned in *row_stats_groups
+    //             (written by the epilogue from the fp32 values, or by a pass over the output where the chosen kernel cannot: split-K forms; then G = 1);
+    //   consumer: ln_stats (that buffer), ln_groups = G, ln_eps, ln_s, ln_b (fp32 [N]); w = W'; bias is ignored (b' holds it).  The row length is c0.
+    float* row_stats; int* row_stats_groups;
+    const float* ln_stats; int ln_groups; float ln_eps; const float* ln_s; const float* ln_b;
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);
+void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out);
+// (sum, sum of squares) per row of x [M][C] (+ x_lo): stats[M][1][2]; the statistics pass behind IgemmArgs::row_stats and after the fused cross-attention block
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s);
 
 struct AttnArgs {
     const f16* q; int q_stride;   // [B, Nq, H*dh] rows of q_stride halfs
@@ -76,6 +87,7 @@ int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out,
 struct XattnArgs {
     const f16* h; f16* out;                 // [M][C]; out may alias h
     const f16* h_lo; f16* out_lo;           // split-fp16 residual stream: lo planes of h / out (both or neither); out_lo may alias h_lo
+    float* row_stats;                       // optional: (sum, sum of squares) of every OUTPUT row, [M][1][2] (IgemmArgs::row_stats layout with one group): norm3 folded into the GEGLU GEMM
     const f16* ln_g; const f16* ln_b; float ln_eps;
     const f16* wq; const f16* wo; const f16* bo;
     const f16* kv;                          // [M / HW samples][Nk][2 C]: K | V projections of the text context

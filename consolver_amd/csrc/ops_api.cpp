@@ -21,6 +21,8 @@ extern int g_tune_gemm2_prio;
 extern int g_tune_biggemm;
 extern int g_tune_attn_qt40;
 extern int g_tune_x2_split_a;
+extern int g_tune_ln_fold;
+extern int g_tune_xcd_grid;
 
 extern "C" {
 
@@ -33,7 +35,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"gemm_big", &g_tune_biggemm, 1, 0, 3, false},   {"debug", &g_tune_debug, 0, 0, 0x7fffffff, false}, {"gemm_gm", &g_tune_gemm_gm, -1, -1, 64, false},
         {"gn_fuse", &g_tune_gn_fuse, 1, 0, 1, false},    {"xattn_fused", &g_tune_xattn_fused, 1, 0, 1, false}, {"cfg_share", &g_tune_cfg_share, 1, 0, 1, false},
         {"gemm2_prio", &g_tune_gemm2_prio, 0, -1, 1, false}, {"attn_prio", &g_tune_attn_prio, -1, -1, 1, false}, {"attn_qt40", &g_tune_attn_qt40, 4, 2, 4, true},
-        {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false},
+        {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false}, {"ln_fold", &g_tune_ln_fold, 1, 0, 1, false}, {"xcd_grid", &g_tune_xcd_grid, 1, 0, 1, false},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;
@@ -114,10 +116,10 @@ int cs_op_xattn_block(const void* h, const void* ln_gamma, const void* ln_beta, 
 
 int cs_op_conv2d_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int Hi, int Wi, int taps, int stride,
                     int upsample, const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, const void* res_lo,
-                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+                    void* out, void* out_lo, float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     IgemmArgs a{};
     a.a0 = (const f16*)x0; a.a1 = (const f16*)x1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi;
-    a.a0_lo = (const f16*)x0_lo; a.a1_lo = (const f16*)x1_lo;
+    a.a0_lo = (const f16*)x0_lo; a.a1_lo = (const f16*)x1_lo; a.row_stats = row_stats; a.row_stats_groups = row_groups;
     if (stride != 1 && stride != 2) CS_FAIL(CS_E_ARG, "conv2d: stride must be 1 or 2");
     if (res_lo && !res) CS_FAIL(CS_E_ARG, "conv2d_x2: res_lo without res");
     a.Ho = upsample ? 2 * Hi : (stride == 2 ? Hi / 2 : Hi);
@@ -130,9 +132,9 @@ int cs_op_conv2d_x2(const void* x0, const void* x0_lo, int c0, const void* x1, c
 }
 
 int cs_op_linear_x2(const void* x, const void* x_lo, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo,
-                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+                    void* out, void* out_lo, float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
     IgemmArgs a{};
-    a.a0_lo = (const f16*)x_lo;
+    a.a0_lo = (const f16*)x_lo; a.row_stats = row_stats; a.row_stats_groups = row_groups;
     if (res_lo && !res) CS_FAIL(CS_E_ARG, "linear_x2: res_lo without res");
     a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
     a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out;
@@ -156,13 +158,38 @@ int cs_op_layer_norm_x2(const void* x, const void* x_lo, const void* gamma, cons
 }
 
 int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
-                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, void* stream) {
+                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, float* row_stats,
+                         void* stream) {
     XattnArgs a{};
+    a.row_stats = row_stats;
     a.h = (const f16*)h; a.out = (f16*)out; a.h_lo = (const f16*)h_lo; a.out_lo = (f16*)out_lo;
     a.ln_g = (const f16*)ln_gamma; a.ln_b = (const f16*)ln_beta; a.ln_eps = ln_eps;
     a.wq = (const f16*)wq; a.wo = (const f16*)wo; a.bo = (const f16*)bo; a.kv = (const f16*)kv;
     a.M = M; a.HW = HW; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = scale;
     return launch_xattn_block(a, (hipStream_t)stream);
+}
+
+int cs_op_ln_fold_pack(const void* w_host, const void* bias_host, const void* gamma_host, const void* beta_host, int N, int K, void* w_out_host,
+                       float* s_out_host, float* b_out_host) {
+    if (!w_host || !gamma_host || !beta_host || !w_out_host || !s_out_host || !b_out_host || N <= 0 || K <= 0) CS_FAIL(CS_E_ARG, "ln_fold_pack: bad arguments");
+    ln_fold_pack_host((const f16*)w_host, (const f16*)bias_host, (const f16*)gamma_host, (const f16*)beta_host, N, K, (f16*)w_out_host, s_out_host, b_out_host);
+    return CS_OK;
+}
+
+int cs_op_linear_ln(const void* x, int M, int K, const void* w_folded, const float* ln_s, const float* ln_b, int N, const float* row_stats, int groups,
+                    float eps, void* out, int geglu, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
+    a.w = (const f16*)w_folded; a.out = (f16*)out; a.geglu = geglu;
+    a.ln_stats = row_stats; a.ln_groups = groups; a.ln_eps = eps; a.ln_s = ln_s; a.ln_b = ln_b;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    if (!row_stats) CS_FAIL(CS_E_ARG, "linear_ln: row_stats required");
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_row_stats(const void* x, const void* x_lo, int M, int C, float* stats, void* stream) {
+    return launch_row_stats((const f16*)x, (const f16*)x_lo, M, C, stats, (hipStream_t)stream);
 }
 
 int cs_op_geglu_pack(const void* w_host, const void* b_host, int Hd, int K, void* w_out_host, void* b_out_host) {

@@ -30,6 +30,25 @@ int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dua
 // CS_RESIDUAL_F16X2 only: which GEMMs that consume the residual stream DIRECTLY read hi + lo (two passes of the k loop, IgemmArgs::a0_lo) instead of the hi
 // plane: bit 0 the resnet shortcut 1x1 (default: its operand rounding is the largest single stream-level error left), bit 1 proj_out
 int g_tune_x2_split_a = 1;
+// 1 (default): the transformer blocks' LayerNorms are folded into the linear layers that consume them (gamma in the packed weights, (mean, rstd) applied in the
+// GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
+int g_tune_ln_fold = 1;
+
+// LN(h) W^T + b = rstd (h W'^T - mean s) + b':  W' = fp16(W diag(gamma)), s = row sums of W' (of the ROUNDED values: it cancels exactly what the MFMAs summed),
+// b' = W beta + b.  Host memory; w [N][K] fp16 rows, bias may be null.  Shared by the executor's weight packing and cs_op_ln_fold_pack.
+void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out) {
+    for (int n = 0; n < N; ++n) {
+        double s = 0.0, b = bias ? (double)(float)bias[n] : 0.0;
+        for (int k = 0; k < K; ++k) {
+            const float wk = (float)w[(size_t)n * K + k];
+            const f16 r = (f16)(wk * (float)gamma[k]);
+            w_out[(size_t)n * K + k] = r;
+            s += (double)(float)r;
+            b += (double)wk * (double)(float)beta[k];
+        }
+        s_out[n] = (float)s; b_out[n] = (float)b;
+    }
+}
 
 namespace {
 
@@ -38,8 +57,10 @@ struct HostTensor { std::vector<int64_t> shape; std::vector<f16> data; };
 struct Conv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; };
 struct Norm { f16* g = nullptr; f16* b = nullptr; int c = 0; float eps = 1e-5f; };
 struct Resnet { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; };
+struct LnLinear { f16* w = nullptr; float* s = nullptr; float* b = nullptr; };     // a linear layer with the LayerNorm in front of it folded in (IgemmArgs::ln_*)
 struct Xformer {
     Norm gn, ln1, ln2, ln3;
+    LnLinear f_qkv, f_q2, f_ff1;                                                    // norm1 -> to_q | to_k | to_v, norm2 -> attn2.to_q, norm3 -> GEGLU proj
     Conv proj_in, proj_out;
     f16 *wqkv = nullptr, *wo1 = nullptr, *bo1 = nullptr;
     f16 *wq2 = nullptr, *wkv2 = nullptr, *wo2 = nullptr, *bo2 = nullptr;
@@ -257,12 +278,32 @@ bool make_resnet(CsUNet* u, const std::string& p, Resnet& r, std::vector<f16>& t
     tpb.insert(tpb.end(), tb.data.begin(), tb.data.end());
     return ok;
 }
+float* upload_f32(CsUNet* u, const std::vector<float>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size() * sizeof(float), 256)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    u->dev_allocs.push_back(d);
+    return (float*)d;
+}
+// LN(h) W^T + b = rstd (h W'^T - mean s) + b':  W' = fp16(W diag(gamma)), s = row sums of W' (of the ROUNDED values: it cancels exactly what the MFMAs summed),
+// b' = W beta + b.  w: [N][K] fp16 rows, bias may be empty.
+bool make_ln_linear(CsUNet* u, const std::vector<f16>& w, const std::vector<f16>& bias, const HostTensor& gamma, const HostTensor& beta, int N, int K, LnLinear& out) {
+    std::vector<f16> wf((size_t)N * K);
+    std::vector<float> sv(N), bv(N);
+    ln_fold_pack_host(w.data(), bias.empty() ? nullptr : bias.data(), gamma.data.data(), beta.data.data(), N, K, wf.data(), sv.data(), bv.data());
+    out.w = upload(u, wf); out.s = upload_f32(u, sv); out.b = upload_f32(u, bv);
+    return out.w && out.s && out.b;
+}
+
 bool make_xformer(CsUNet* u, const std::string& p, Xformer& x) {
     const std::string t = p + ".transformer_blocks.0";
     bool ok = make_norm(u, p + ".norm", x.gn, 1e-6f) && make_conv(u, p + ".proj_in", x.proj_in) && make_conv(u, p + ".proj_out", x.proj_out) &&
               make_norm(u, t + ".norm1", x.ln1, 1e-5f) && make_norm(u, t + ".norm2", x.ln2, 1e-5f) && make_norm(u, t + ".norm3", x.ln3, 1e-5f);
     x.c = x.gn.c;
-    x.wqkv = upload(u, concat_rows({&T(u, t + ".attn1.to_q.weight"), &T(u, t + ".attn1.to_k.weight"), &T(u, t + ".attn1.to_v.weight")}));
+    const std::vector<f16> wqkv_h = concat_rows({&T(u, t + ".attn1.to_q.weight"), &T(u, t + ".attn1.to_k.weight"), &T(u, t + ".attn1.to_v.weight")});
+    x.wqkv = upload(u, wqkv_h);
+    ok = ok && make_ln_linear(u, wqkv_h, {}, T(u, t + ".norm1.weight"), T(u, t + ".norm1.bias"), 3 * x.c, x.c, x.f_qkv) &&
+         make_ln_linear(u, T(u, t + ".attn2.to_q.weight").data, {}, T(u, t + ".norm2.weight"), T(u, t + ".norm2.bias"), x.c, x.c, x.f_q2);
     x.wo1 = upload(u, T(u, t + ".attn1.to_out.0.weight").data); x.bo1 = upload(u, T(u, t + ".attn1.to_out.0.bias").data);
     x.wq2 = upload(u, T(u, t + ".attn2.to_q.weight").data);
     x.wkv2 = upload(u, concat_rows({&T(u, t + ".attn2.to_k.weight"), &T(u, t + ".attn2.to_v.weight")}));
@@ -278,6 +319,7 @@ bool make_xformer(CsUNet* u, const std::string& p, Xformer& x) {
             pb[32 * P + i] = b1.data[16 * P + i]; pb[32 * P + 16 + i] = b1.data[H4 + 16 * P + i];
         }
     x.wff1 = upload(u, pw); x.bff1 = upload(u, pb);
+    ok = ok && make_ln_linear(u, pw, pb, T(u, t + ".norm3.weight"), T(u, t + ".norm3.bias"), (int)(8 * C), (int)C, x.f_ff1);      // (row-wise: commutes with the GEGLU row permutation)
     x.wff2 = upload(u, T(u, t + ".ff.net.2.weight").data); x.bff2 = upload(u, T(u, t + ".ff.net.2.bias").data);
     x.kv_off = u->kv_halfs_per_token; u->kv_halfs_per_token += 2 * (size_t)x.c;
     return ok && x.wqkv && x.wo1 && x.bo1 && x.wq2 && x.wkv2 && x.wo2 && x.bo2 && x.wff1 && x.bff1 && x.wff2 && x.bff2;
@@ -294,6 +336,9 @@ struct Run {
     int v_gn_fuse = 1, v_xattn_fused = 1, v_cfg_share = 1;
     bool split = false;            // CS_RESIDUAL_F16X2: residual-stream tensors carry a lo plane
     int v_split_a = 1;             // snapshot of g_tune_x2_split_a
+    int v_ln_fold = 1;             // snapshot of g_tune_ln_fold
+    // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
+    float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
 
     f16* alloc(size_t halfs) {
         void* p = u->arena.alloc(halfs * sizeof(f16));
@@ -338,9 +383,11 @@ struct Run {
     // want_stats: the output feeds a GroupNorm (or a skip connection that does): its statistics come out of the epilogue.
     // stats_into: write them into this (larger) buffer instead of a fresh one, nothing registered (two launches filling one tensor).
     void conv(const Conv& c, const f16* a0, int c0, const f16* a1, int c1, int Hi, int Wi, int Ho, int Wo, int stride, int up,
-              const f16* temb, St res, St out, bool want_stats = false, float* stats_into = nullptr, const f16* a0_lo = nullptr, const f16* a1_lo = nullptr) {
+              const f16* temb, St res, St out, bool want_stats = false, float* stats_into = nullptr, const f16* a0_lo = nullptr, const f16* a1_lo = nullptr,
+              float* row_stats = nullptr, int* row_groups = nullptr) {
         IgemmArgs a{};
         a.a0_lo = a0_lo; a.a1_lo = a0_lo ? a1_lo : nullptr;
+        a.row_stats = row_stats; a.row_stats_groups = row_groups;
         if (stats_into) a.gn_stats = stats_into;
         else if (want_stats && stats_fusable(Ho * Wo, c.cout)) {
             a.gn_stats = alloc_stats(B, Ho * Wo, c.cout);
@@ -354,12 +401,22 @@ struct Run {
         const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
         launch(c.taps == 9 ? P_CONV3 : P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
-    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu) {
+    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu, float* row_stats = nullptr, int* row_groups = nullptr) {
         IgemmArgs a{};
+        a.row_stats = row_stats; a.row_stats_groups = row_groups;
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res.hi; a.out = out.hi; a.geglu = geglu;
         a.res_lo = res.lo; a.out_lo = out.lo;
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
+        launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
+    }
+    // out = LayerNorm(h) W^T + b with the LayerNorm folded in: x is the RAW hidden state (hi plane), stats / G what its producer left
+    void linear_ln(const f16* x, int M, int K, const LnLinear& L, const float* stats, int G, float eps, int N, f16* out, int geglu) {
+        IgemmArgs a{};
+        a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = L.w; a.out = out; a.geglu = geglu;
+        a.ln_stats = stats; a.ln_groups = G; a.ln_eps = eps; a.ln_s = L.s; a.ln_b = L.b;
+        a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
+        const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N));
         launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
     void group_norm(const Norm& n, St s0, int c0, St s1, int c1, int HW, bool silu, f16* out) {
@@ -387,8 +444,9 @@ struct Run {
 
     // fused LN2 -> to_q -> cross attention -> to_out + residual (xattn.hip); h_in may equal h_out
     bool xattn_fusable(const Xformer& X, int HW) const { return v_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
-    void xattn_fused(const Xformer& X, St h_in, St h_out, const f16* kvl, int HW) {
+    void xattn_fused(const Xformer& X, St h_in, St h_out, const f16* kvl, int HW, float* row_stats = nullptr) {
         XattnArgs a{};
+        a.row_stats = row_stats;
         a.h = h_in.hi; a.out = h_out.hi; a.h_lo = h_in.lo; a.out_lo = h_out.lo; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
         a.M = B * HW; a.HW = HW; a.Nk = u->cfg.ctx_len; a.C = X.c; a.heads = u->cfg.num_heads; a.scale = 1.0f / sqrtf((float)(X.c / u->cfg.num_heads));
         const double M = (double)B * HW, fl = 4.0 * M * X.c * X.c + 4.0 * M * u->cfg.ctx_len * X.c;
@@ -424,37 +482,40 @@ struct Run {
         f16* g = alloc((size_t)M * C);
         group_norm(X.gn, x, C, St(), 0, HW, false, g);
         St h = salloc((size_t)M * C);
-        conv(X.proj_in, g, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h);
+        // folded LayerNorms: every layer that writes the hidden state leaves its row statistics in rs (G column groups), the next LayerNorm's consumer reads them
+        const bool fold = v_ln_fold != 0;
+        float* rs = fold ? alloc_rowstats(M, C) : nullptr; int G = 1;
+        conv(X.proj_in, g, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h, false, nullptr, nullptr, nullptr, rs, &G);
         // self attention
-        layer_norm(X.ln1, h, M, g);
         f16* qkv = alloc((size_t)M * 3 * C);
-        linear(g, M, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0);
+        if (fold) linear_ln(h.hi, M, C, X.f_qkv, rs, G, X.ln1.eps, 3 * C, qkv, 0);
+        else { layer_norm(X.ln1, h, M, g); linear(g, M, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0); }
         attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g, C, HW, HW, C);
         release(qkv);
-        linear(g, M, C, X.wo1, X.bo1, C, h, h, 0);
+        linear(g, M, C, X.wo1, X.bo1, C, h, h, 0, rs, &G);
         // cross attention (K/V of the text context are cached in kv)
         const f16* kvl = kv + X.kv_off * (size_t)B * L;
         if (xattn_fusable(X, HW)) {
-            xattn_fused(X, h, h, kvl, HW);
+            xattn_fused(X, h, h, kvl, HW, rs); G = 1;        // (its own norm2 stays inside the kernel; it leaves the statistics norm3's consumer needs)
         } else {
-            layer_norm(X.ln2, h, M, g);
             f16* q = alloc((size_t)M * C);
-            linear(g, M, C, X.wq2, nullptr, C, St(), St(q), 0);
+            if (fold) linear_ln(h.hi, M, C, X.f_q2, rs, G, X.ln2.eps, C, q, 0);
+            else { layer_norm(X.ln2, h, M, g); linear(g, M, C, X.wq2, nullptr, C, St(), St(q), 0); }
             attention(true, q, C, kvl, 2 * C, kvl + C, 2 * C, g, C, HW, L, C);
             release(q);
-            linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
+            linear(g, M, C, X.wo2, X.bo2, C, h, h, 0, rs, &G);
         }
         // feed forward (GEGLU fused into the first GEMM's epilogue)
-        layer_norm(X.ln3, h, M, g);
         f16* ff = alloc((size_t)M * 4 * C);
-        linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1);
+        if (fold) linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
+        else { layer_norm(X.ln3, h, M, g); linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
         const bool po = split && (v_split_a & 2);
         linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);      // the hidden after the feed-forward has one consumer, proj_out's operand: hi plane only unless proj_out reads hi + lo
         release(ff);
         // proj_out + residual with the block input
         St out(g, split ? alloc((size_t)M * C) : nullptr);
         conv(X.proj_out, h.hi, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, x, out, true, nullptr, po ? h.lo : nullptr);
-        srelease(h);
+        srelease(h); u->arena.free(rs);
         return out;
     }
 };
@@ -485,13 +546,15 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     f16* g1 = R.alloc((size_t)M1 * C);
     R.group_norm(X.gn, x_half, C, St(), 0, HW, false, g1);
     St h1 = R.salloc((size_t)M1 * C);
-    R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h1);
-    R.layer_norm(X.ln1, h1, M1, g1);
+    const bool fold = R.v_ln_fold != 0;
+    float* rs = fold ? R.alloc_rowstats(M, C) : nullptr; int G = 1;          // (sized for the full batch: the halves' statistics land side by side later)
+    R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h1, false, nullptr, nullptr, nullptr, rs, &G);
     f16* qkv = R.alloc((size_t)M1 * 3 * C);
-    R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0);
+    if (fold) R.linear_ln(h1.hi, M1, C, X.f_qkv, rs, G, X.ln1.eps, 3 * C, qkv, 0);
+    else { R.layer_norm(X.ln1, h1, M1, g1); R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0); }
     R.attention(false, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, g1, C, HW, HW, C);
     R.release(qkv);
-    R.linear(g1, M1, C, X.wo1, X.bo1, C, h1, h1, 0);
+    R.linear(g1, M1, C, X.wo1, X.bo1, C, h1, h1, 0, rs, &G);
     const f16* kvl = R.kv + X.kv_off * (size_t)Bfull * L;
     St h; f16* g;
     if (R.xattn_fusable(X, HW)) {
@@ -500,13 +563,14 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         h = R.salloc((size_t)M * C);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half)
-            R.xattn_fused(X, h1, h.at((size_t)half * M1 * C), kvl + (size_t)half * n_lat * L * 2 * C, HW);
+            R.xattn_fused(X, h1, h.at((size_t)half * M1 * C), kvl + (size_t)half * n_lat * L * 2 * C, HW, rs ? rs + (size_t)half * M1 * 2 : nullptr);
+        G = 1;
         R.srelease(h1);
         R.B = Bfull;
     } else {
-        R.layer_norm(X.ln2, h1, M1, g1);
         f16* q = R.alloc((size_t)M1 * C);
-        R.linear(g1, M1, C, X.wq2, nullptr, C, St(), St(q), 0);
+        if (fold) R.linear_ln(h1.hi, M1, C, X.f_q2, rs, G, X.ln2.eps, C, q, 0);
+        else { R.layer_norm(X.ln2, h1, M1, g1); R.linear(g1, M1, C, X.wq2, nullptr, C, St(), St(q), 0); }
         R.release(g1);
         // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
         h = R.salloc((size_t)M * C);
@@ -521,11 +585,11 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         }
         R.release(q); R.srelease(h1);
         R.B = Bfull;
-        R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0);
+        R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0, rs, &G);
     }
-    R.layer_norm(X.ln3, h, M, g);
     f16* ff = R.alloc((size_t)M * 4 * C);
-    R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1);
+    if (fold) R.linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
+    else { R.layer_norm(X.ln3, h, M, g); R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
     const bool po = R.split && (R.v_split_a & 2);
     R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);
     R.release(ff);
@@ -538,12 +602,12 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
                st ? st + (size_t)half * n_lat * (HW / 64) * C : nullptr, po ? h.lo + (size_t)half * M1 * C : nullptr);
     R.B = Bfull;
     if (st) R.stat_of[g] = {st, HW / 64};
-    R.srelease(h);
+    R.srelease(h); u->arena.free(rs);
     return out;
 }
 
-struct Variant { int gn_fuse, xattn_fused, cfg_share; };
-static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share}; }
+struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold; };
+static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share, g_tune_ln_fold}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
                 char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant()) {
@@ -556,7 +620,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a;
-    R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share;
+    R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
     const int c0 = c.block_out_channels[0], td = 4 * c0, L = c.ctx_len;
@@ -746,8 +810,8 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
     // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
     size_t peak = 0;
-    for (int variant = 0; variant < 4; ++variant) {
-        const Variant v{variant >> 1, variant & 1, 1};
+    for (int variant = 0; variant < 8; ++variant) {
+        const Variant v{(variant >> 1) & 1, variant & 1, 1, variant >> 2};
         run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
         peak = std::max(peak, u->arena.peak);
         if (batch % 2 == 0) {

@@ -47,6 +47,7 @@ struct XattnParams {
     const f16* h;        // [M_in rows][320] block input (residual stream)
     f16* out;            // [M rows][320]; may alias h
     const f16* h_lo; f16* out_lo;   // SPLIT: lo planes of the split-fp16 residual stream (XattnArgs::h_lo / out_lo)
+    float* row_stats;    // optional [M][2]: (sum, sum of squares) of every output row (XattnArgs::row_stats)
     const f16* ln_g; const f16* ln_b; float ln_eps;
     const f16* wq;       // [320][320]
     const f16* wo; const f16* bo;
@@ -359,19 +360,34 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
             const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
             const f16x8 v = *reinterpret_cast<const f16x8*>(patch + row * PROW + ch * 16);
             f16x8 o;
+            float s1 = 0.f, s2 = 0.f;
             if constexpr (SPLIT) {
                 f16x8 l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float f = (float)v[e] + (float)res[k][e] + (float)resl[k][e];
                     o[e] = (f16)f; l[e] = (f16)(f - (float)o[e]);
+                    s1 += f; s2 += f * f;
                 }
                 if (m < p.M) *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * C + ch * 8) = l;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)((float)v[e] + (float)res[k][e]);
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e] + (float)res[k][e]; o[e] = (f16)f; s1 += f; s2 += f * f; }
             }
             if (m < p.M && !(p.debug & 16)) *reinterpret_cast<f16x8*>(p.out + (size_t)m * C + ch * 8) = o;
+            // row statistics for norm3 folded into the GEGLU GEMM: the item's partial sums go to weight stage 1 (free since the to_out GEMM's last barrier; the
+            // patch reaches 2 KB into stage 0 only), [128 rows][40 chunks] float2 = 40,960 B = one stage exactly
+            if (p.row_stats) *reinterpret_cast<float2*>(smem + XT_BYTES + WST + (row * 40 + ch) * 8) = float2{s1, s2};
+        }
+        if (p.row_stats) {                               // (uniform branch)
+            __syncthreads();
+            if (tid < TM && m_blk + tid < p.M) {
+                float a1 = 0.f, a2 = 0.f;
+                const char* src = smem + XT_BYTES + WST + tid * 320;
+#pragma unroll
+                for (int c2 = 0; c2 < 20; ++c2) { const f32x4 t = *reinterpret_cast<const f32x4*>(src + c2 * 16); a1 += t[0] + t[2]; a2 += t[1] + t[3]; }
+                *reinterpret_cast<float2*>(p.row_stats + (size_t)(m_blk + tid) * 2) = float2{a1, a2};
+            }
         }
     }
 }
@@ -387,7 +403,7 @@ int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
     if (a.M % a.HW) CS_FAIL(CS_E_SHAPE, "xattn_block: M must be a whole number of samples");
     XattnParams p;
     if ((a.h_lo == nullptr) != (a.out_lo == nullptr)) CS_FAIL(CS_E_ARG, "xattn_block: h_lo and out_lo go together");
-    p.h = a.h; p.out = a.out; p.h_lo = a.h_lo; p.out_lo = a.out_lo; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
+    p.h = a.h; p.out = a.out; p.h_lo = a.h_lo; p.out_lo = a.out_lo; p.row_stats = a.row_stats; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
     p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = g_tune_debug;
     constexpr size_t lds = XT_BYTES + 2 * WST;      // 163840: XT + two weight stages (the V tile reuses the stages, the epilogue patch XT)
     static bool configured = false;

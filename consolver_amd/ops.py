@@ -71,7 +71,8 @@ def split_f16(x):
     return hi.contiguous(), lo.contiguous()
 
 
-def conv2d_x2(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, res_lo=None, splitk=True, x0_lo=None, x1_lo=None):
+def conv2d_x2(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, temb=None, res=None, res_lo=None, splitk=True, x0_lo=None, x1_lo=None,
+              row_stats=False, want_lo=True):
     """cs_op_conv2d_x2: returns (out_hi, out_lo); res / res_lo are the planes of a split-fp16 residual (res_lo may be None); x0_lo / x1_lo (1x1 only)
     the lo planes of a split-fp16 A operand."""
     _f16(x0, "x0")
@@ -81,34 +82,84 @@ def conv2d_x2(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False
     Ho = 2 * Hi if upsample else (Hi // 2 if stride == 2 else Hi)
     Wo = 2 * Wi if upsample else (Wi // 2 if stride == 2 else Wi)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float16, device=x0.device)
-    out_lo = torch.empty_like(out)
+    out_lo = torch.empty_like(out) if want_lo else None
     tstride = 0 if (temb is None or temb.shape[0] == 1) else temb.shape[1]
     ws = None
     if splitk:
         ws = _SPLITK_WS.get(x0.device)
         if ws is None:
             ws = _SPLITK_WS[x0.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x0.device)
+    rs, G = (torch.zeros(B * Ho * Wo, N // 64, 2, dtype=torch.float32, device=x0.device), C.c_int(0)) if row_stats else (None, None)
     L.check(L.lib().cs_op_conv2d_x2(L.ptr(x0), L.ptr(x0_lo), c0, L.ptr(x1), L.ptr(x1_lo), c1, B, Hi, Wi, taps, stride, int(upsample), L.ptr(w_packed),
                                     L.ptr(bias), N, L.ptr(temb), tstride, L.ptr(res), L.ptr(res_lo), L.ptr(out), L.ptr(out_lo),
+                                    L.ptr(rs), C.byref(G) if row_stats else None,
                                     L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x0.device)))
+    if row_stats:
+        return out, out_lo, (rs, G.value)
     return out, out_lo
 
 
-def linear_x2(x, w, bias=None, res=None, res_lo=None, splitk=True, want_lo=True, x_lo=None):
-    """cs_op_linear_x2: returns (out_hi, out_lo) (out_lo None with want_lo=False: the fp16 rounding of the fp32 sum only)."""
+def linear_x2(x, w, bias=None, res=None, res_lo=None, splitk=True, want_lo=True, x_lo=None, row_stats=False, out=None, out_lo=None):
+    """cs_op_linear_x2: returns (out_hi, out_lo) (out_lo None with want_lo=False: the fp16 rounding of the fp32 sum only); row_stats=True appends
+    (stats [M, N/64, 2] fp32 of which the first G groups are valid, G): the row statistics a folded LayerNorm's consumer (linear_ln) reads."""
     _f16(x, "x")
     M, K = x.shape
     N = w.shape[0]
-    out = torch.empty(M, N, dtype=torch.float16, device=x.device)
-    out_lo = torch.empty_like(out) if want_lo else None
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+        out_lo = torch.empty_like(out) if want_lo else None
     ws = None
     if splitk:
         ws = _SPLITK_WS.get(x.device)
         if ws is None:
             ws = _SPLITK_WS[x.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x.device)
+    rs, G = (torch.zeros(M, N // 64, 2, dtype=torch.float32, device=x.device), C.c_int(0)) if row_stats else (None, None)
     L.check(L.lib().cs_op_linear_x2(L.ptr(x), L.ptr(x_lo), M, K, L.ptr(w), L.ptr(bias), N, L.ptr(res), L.ptr(res_lo), L.ptr(out), L.ptr(out_lo),
+                                    L.ptr(rs), C.byref(G) if row_stats else None,
                                     L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x.device)))
+    if row_stats:
+        return out, out_lo, (rs, G.value)
     return out, out_lo
+
+
+def ln_fold_pack(w, bias, gamma, beta):
+    """host-side folding of a LayerNorm (gamma, beta) into the linear layer w [N, K] (+ bias) that consumes it: returns (W' fp16 [N, K], s fp32 [N], b' fp32 [N])
+    on the CPU (cs_op_ln_fold_pack; the executor packs its weights with the same function)."""
+    w = w.detach().to("cpu", torch.float16).contiguous()
+    g = gamma.detach().to("cpu", torch.float16).contiguous()
+    be = beta.detach().to("cpu", torch.float16).contiguous()
+    b = bias.detach().to("cpu", torch.float16).contiguous() if bias is not None else None
+    N, K = w.shape
+    wo, so, bo = torch.empty_like(w), torch.empty(N, dtype=torch.float32), torch.empty(N, dtype=torch.float32)
+    L.check(L.lib().cs_op_ln_fold_pack(C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()) if b is not None else None, C.c_void_p(g.data_ptr()),
+                                       C.c_void_p(be.data_ptr()), N, K, C.c_void_p(wo.data_ptr()), C.c_void_p(so.data_ptr()), C.c_void_p(bo.data_ptr())))
+    return wo, so, bo
+
+
+def linear_ln(x, w_folded, ln_s, ln_b, stats, groups, eps=1e-5, geglu=False, splitk=True):
+    """out = LayerNorm(h) W^T + b with the LayerNorm folded in (cs_op_linear_ln): x is the RAW hidden state [M, K] fp16, (stats, groups) the row statistics
+    its producer left (linear_x2 / conv2d_x2 / xattn_block_x2 with row_stats=True, or row_stats())."""
+    _f16(x, "x")
+    M, K = x.shape
+    N = w_folded.shape[0]
+    out = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=x.device)
+    ws = None
+    if splitk:
+        ws = _SPLITK_WS.get(x.device)
+        if ws is None:
+            ws = _SPLITK_WS[x.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().cs_op_linear_ln(L.ptr(x), M, K, L.ptr(w_folded), L.ptr(ln_s), L.ptr(ln_b), N, L.ptr(stats), int(groups), float(eps), L.ptr(out), int(geglu),
+                                    L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x.device)))
+    return out
+
+
+def row_stats(x, x_lo=None):
+    """(sum, sum of squares) of every row of x [M, C] (+ x_lo): fp32 [M, 1, 2] (cs_op_row_stats)"""
+    _f16(x, "x")
+    M, Cc = x.shape
+    st = torch.empty(M, 1, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().cs_op_row_stats(L.ptr(x), L.ptr(x_lo), M, Cc, L.ptr(st), L.stream_ptr(x.device)))
+    return st
 
 
 def group_norm_x2(x0, x0_lo, gamma, beta, groups=32, eps=1e-5, silu=False, x1=None, x1_lo=None):
@@ -132,14 +183,19 @@ def layer_norm_x2(x, x_lo, gamma, beta, eps=1e-5):
     return out
 
 
-def xattn_block_x2(h, h_lo, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None):
+def xattn_block_x2(h, h_lo, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None, row_stats=False):
+    """h_lo=None: plain fp16 stream (out_lo is None then); row_stats=True appends the [M, 1, 2] row statistics of the output"""
     _f16(h, "h")
     M, Cc = h.shape
     hw = hw or M // kv.shape[0]
-    out, out_lo = torch.empty_like(h), torch.empty_like(h)
+    out = torch.empty_like(h)
+    out_lo = torch.empty_like(h) if h_lo is not None else None
+    rs = torch.zeros(M, 1, 2, dtype=torch.float32, device=h.device) if row_stats else None
     L.check(L.lib().cs_op_xattn_block_x2(L.ptr(h), L.ptr(h_lo), L.ptr(ln_gamma), L.ptr(ln_beta), float(eps), L.ptr(wq), L.ptr(kv), kv.shape[1],
-                                         L.ptr(wo), L.ptr(bo), M, hw, Cc, heads, float((Cc // heads) ** -0.5), L.ptr(out), L.ptr(out_lo),
+                                         L.ptr(wo), L.ptr(bo), M, hw, Cc, heads, float((Cc // heads) ** -0.5), L.ptr(out), L.ptr(out_lo), L.ptr(rs),
                                          L.stream_ptr(h.device)))
+    if row_stats:
+        return out, out_lo, rs
     return out, out_lo
 
 

@@ -81,16 +81,34 @@ int cs_op_layer_norm(const void* x, const void* gamma, const void* beta, void* o
  * (the resnet shortcut 1x1 over [x | skip], which consumes the residual stream directly). */
 int cs_op_conv2d_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int Hi, int Wi, int taps, int stride,
                     int upsample, const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, const void* res_lo,
-                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+                    void* out, void* out_lo, float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
 int cs_op_linear_x2(const void* x, const void* x_lo, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo,
-                    void* out, void* out_lo, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+                    void* out, void* out_lo, float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* row_stats (may be NULL; then row_groups too): the layer also leaves, per OUTPUT row, (sum, sum of squares) over G column groups, row_stats[M][G][2] fp32
+ * (device; room for N / 64 groups), G written to *row_groups (host) -- from the epilogue's fp32 values, or by a pass over the output where the chosen kernel has no
+ * such epilogue (split-K forms; G = 1).  Consumer: cs_op_linear_ln. */
+
+/* LayerNorm folded into the linear layer that consumes it (diffusers BasicTransformerBlock: norm1 -> to_q | to_k | to_v, norm2 -> attn2.to_q, norm3 -> GEGLU proj):
+ *   LN(h) W^T + b = rstd (h W'^T - mean s) + b',  W' = fp16(W diag(gamma)),  s[n] = sum_k W'[n][k],  b' = W beta + b.
+ * cs_op_ln_fold_pack (host memory only) builds W' (fp16 [N][K]), s and b' (fp32 [N]) from W, the optional bias, gamma and beta (fp16).
+ * cs_op_linear_ln multiplies the RAW hidden state x[M,K] (fp16; the hi plane of a split-fp16 stream) with W' and applies (mean, rstd) of each row in the epilogue,
+ * taken from the row statistics its producer left (cs_op_linear_x2 / cs_op_conv2d_x2 / cs_op_xattn_block_x2 row_stats, or cs_op_row_stats).  geglu != 0: W' rows
+ * pre-permuted with cs_op_geglu_pack BEFORE folding; out[M, N/2].  No LayerNorm kernel and no normalised copy of x exist on this path. */
+int cs_op_ln_fold_pack(const void* w_host, const void* bias_host, const void* gamma_host, const void* beta_host, int N, int K, void* w_out_host,
+                       float* s_out_host, float* b_out_host);
+int cs_op_linear_ln(const void* x, int M, int K, const void* w_folded, const float* ln_s, const float* ln_b, int N, const float* row_stats, int groups,
+                    float eps, void* out, int geglu, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+/* stats[M][1][2] = (sum, sum of squares) of every row of x[M,C] (+ x_lo[M,C] when not NULL) */
+int cs_op_row_stats(const void* x, const void* x_lo, int M, int C, float* stats, void* stream);
 /* GroupNorm / LayerNorm of split-fp16 sources (x*_lo may be NULL = plain fp16 source) */
 int cs_op_group_norm_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int HW, int groups,
                         float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream);
 int cs_op_layer_norm_x2(const void* x, const void* x_lo, const void* gamma, const void* beta, void* out, int M, int C, float eps, void* stream);
-/* cs_op_xattn_block on a split-fp16 residual stream: the residual add takes h + h_lo and writes out + out_lo */
+/* cs_op_xattn_block on a split-fp16 residual stream: the residual add takes h + h_lo and writes out + out_lo (h_lo = out_lo = NULL: plain fp16 stream);
+ * row_stats (may be NULL): [M][1][2] row statistics of the output for a folded norm3 */
 int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
-                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, void* stream);
+                         int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, float* row_stats,
+                         void* stream);
 
 /* transformer GEMM (f16 / bf16, dtype = CS_F16 1 | CS_BF16 2): out[m][n] = act(x[m,:] . w[n,:] + bias[n]) (+ res, * gate);
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
@@ -141,6 +159,10 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "cfg_share": 1 (default) evaluate the CFG halves' common prefix once (cs_unet_forward with dup = 2), 0 full dual batch;
  *   "x2_split_a": CS_RESIDUAL_F16X2 only, bit mask of the GEMMs that read hi + lo of the residual stream (cs_op_conv2d_x2 x0_lo) inside cs_unet_forward:
  *                1 (default) the resnet shortcut 1x1, 2 proj_out, 3 both, 0 none;
+ *   "xcd_grid":  1 (default) weight-heavy conv / linear launches map the 8 XCDs as a 2-D grid over (row tiles, column tiles) so that each L2 streams a part
+ *                of the weights instead of all of them, 0 contiguous tile runs per XCD always;
+ *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),
+ *                0 LayerNorm kernel + plain GEMM;
  *   "gn_fuse":   1 (default) GroupNorm statistics of conv / 1x1 outputs come from the producer's epilogue inside cs_unet_forward and
  *                cs_op_conv2d_gn, 0 always a separate statistics pass;
  *   "conv_lw":   1 (default) stride-1 3x3 convolutions with N % 160 == 0 (BN 160: the UNet) or N % 128 == 0 (BN 128: the VAE) run on the loader-wave kernel

@@ -37,10 +37,22 @@ def apply_rope(x, cos, sin):                                    # x [B, H, S, D]
     return x * cos[None, None] + rot * sin[None, None]
 
 
+class _Fp32View:
+    """mapping view that converts a tensor to CPU fp32 when it is READ: lets the oracle walk a model whose fp32 weights do not fit in host memory
+    (full-depth FLUX: 11.9 B parameters = 48 GB) -- the source mapping may hold them in 16 bits and / or on another device; one weight at a time is live."""
+
+    def __init__(self, sd):
+        self._sd = sd
+
+    def __getitem__(self, k):
+        return self._sd[k].detach().to("cpu", torch.float32)
+
+
 class FluxOracle:
-    def __init__(self, sd, config):
+    def __init__(self, sd, config, lazy=False):
+        """lazy=True: `sd` is read through on demand (see _Fp32View) instead of being converted to fp32 up front."""
         self.cfg = config
-        self.sd = {k: v.float() for k, v in sd.items()}
+        self.sd = _Fp32View(sd) if lazy else {k: v.float() for k, v in sd.items()}
         self.D = config["num_heads"] * config["head_dim"]
 
     def lin(self, x, p):
@@ -54,7 +66,11 @@ class FluxOracle:
         return x.view(B, S, self.cfg["num_heads"], self.cfg["head_dim"]).transpose(1, 2)
 
     def attn(self, q, k, v):
-        a = torch.softmax(q @ k.transpose(-1, -2) * self.cfg["head_dim"] ** -0.5, dim=-1) @ v
+        if q.shape[2] * k.shape[2] * q.shape[1] > (1 << 28):        # long sequences: one head at a time (S = 8704: 303 MB of scores per head instead of 7.3 GB)
+            a = torch.cat([torch.softmax(q[:, h:h + 1] @ k[:, h:h + 1].transpose(-1, -2) * self.cfg["head_dim"] ** -0.5, dim=-1) @ v[:, h:h + 1]
+                           for h in range(q.shape[1])], dim=1)
+        else:
+            a = torch.softmax(q @ k.transpose(-1, -2) * self.cfg["head_dim"] ** -0.5, dim=-1) @ v
         return a.transpose(1, 2).reshape(a.shape[0], a.shape[2], self.D)
 
     @torch.no_grad()

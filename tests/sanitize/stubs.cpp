@@ -12,7 +12,7 @@
 #include <cstring>
 
 int g_tune_attn_lw = 1, g_tune_attn_prio = -1, g_tune_attn_qt40 = 4, g_tune_biggemm = 1, g_tune_conv_lw = 1, g_tune_debug = 0, g_tune_gemm2_prio = 0,
-    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1;
+    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1;
 
 // ---- HIP runtime -------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -46,9 +46,12 @@ int launch_igemm(const IgemmArgs& a, hipStream_t) {
     rd(a.res, M * Nout * 2); rd(a.res_lo, M * Nout * 2);
     wr(a.out, M * Nout * 2); wr(a.out_lo, M * Nout * 2);
     if (a.gn_stats) wr(a.gn_stats, (size_t)a.B * (a.Ho * a.Wo / 64) * a.N * sizeof(float));
+    if (a.row_stats) { const int G = a.N % 160 == 0 ? a.N / 160 : a.N / 64; wr(a.row_stats, M * G * 2 * sizeof(float)); *a.row_stats_groups = G; }   // (the widest layout a kernel may pick is N / 64 groups)
+    if (a.ln_stats) { rd(a.ln_stats, M * a.ln_groups * 2 * sizeof(float)); rd(a.ln_s, (size_t)a.N * 4); rd(a.ln_b, (size_t)a.N * 4); }
     if (a.splitk_ws) wr(a.splitk_ws, a.splitk_ws_bytes);
     return CS_OK;
 }
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(stats, (size_t)M * 8); return CS_OK; }
 int launch_attention(const AttnArgs& a, hipStream_t) {
     const size_t C = (size_t)a.H * a.dh;
     rd(a.q, (((size_t)a.B * a.Nq - 1) * a.q_stride + C) * 2); rd(a.k, (((size_t)a.B * a.Nk - 1) * a.k_stride + C) * 2);
@@ -72,7 +75,7 @@ int launch_layer_norm(const f16* x, const f16* g, const f16* b, f16* out, int M,
 }
 int launch_xattn_block(const XattnArgs& a, hipStream_t) {
     const size_t n = (size_t)a.M * a.C * 2;
-    rd(a.h, n); rd(a.h_lo, n); wr(a.out, n); wr(a.out_lo, n); rd(a.kv, (size_t)(a.M / a.HW) * a.Nk * 2 * a.C * 2); rd(a.wq, (size_t)a.C * a.C * 2); rd(a.wo, (size_t)a.C * a.C * 2);
+    rd(a.h, n); rd(a.h_lo, n); wr(a.out, n); wr(a.out_lo, n); wr(a.row_stats, (size_t)a.M * 8); rd(a.kv, (size_t)(a.M / a.HW) * a.Nk * 2 * a.C * 2); rd(a.wq, (size_t)a.C * a.C * 2); rd(a.wo, (size_t)a.C * a.C * 2);
     return CS_OK;
 }
 int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, const f16*, const f16* w2, const f16*, f16* scratch, f16* out, hipStream_t) {

@@ -1,0 +1,183 @@
+"""LayerNorm folded into the linear layer that consumes it (cs_op_linear_ln; diffusers BasicTransformerBlock norm1 -> to_q | to_k | to_v,
+norm2 -> attn2.to_q, norm3 -> GEGLU proj; the third-party call at denoise_ppo.py:89-94).
+
+    LN(h) W^T + b = rstd (h W'^T - mean s) + b',   W' = fp16(W diag(gamma)),  s = rowsum(W'),  b' = W beta + b
+
+The GEMM multiplies the RAW hidden state; (mean, rstd) come from row statistics the PRODUCING layer's epilogue left (IgemmArgs::row_stats).  Checked:
+  * the row statistics against torch (every kernel family that produces a hidden state, both residual-stream modes, the fused cross-attention block);
+  * linear_ln against an fp32 evaluation of LayerNorm -> Linear on the same operands (what is left is the fp16 rounding of W' and of the output), and
+    against the two-kernel path ops.layer_norm -> ops.linear it replaces: equally far from fp32 LayerNorm -> Linear, to ~10 %;
+  * the UNet executor with the knob on / off.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from consolver_amd import ops
+from consolver_amd.synth import synthetic_prompt_embeds, synthetic_unet_state_dict
+from consolver_amd.unet import HipUNet2DConditionModel
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def stats_of(st, G):
+    return st[:, :G, 0].sum(1), st[:, :G, 1].sum(1)
+
+
+PRODUCERS = [   # M, K, N, res : every kernel family that writes a transformer hidden state
+    (8192, 320, 320, True),      # gemm_w8_kernel, 64 x 160 wave tiles (to_out at the 64 x 64 level)
+    (8192, 320, 320, False),     # proj_in (no residual: the epilogue takes the fp32 path for the statistics)
+    (4096, 640, 640, True),      # two column tiles
+    (8192, 1280, 1280, True),    # gemm_lw_kernel
+    (128, 1280, 1280, True),     # 8 x 8 level: generic tile + split-K -> the statistics pass
+    (320, 192, 128, True),       # generic 128-wide tile, ragged M
+]
+
+
+@pytest.mark.parametrize("case", PRODUCERS)
+@pytest.mark.parametrize("split", [False, True])
+def test_producer_row_statistics(case, split):
+    M, K, N, use_r = case
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    r32 = rnd(M, N, seed=4, scale=2.0, dtype=torch.float32) + 0.7 if use_r else None
+    rh, rl = ops.split_f16(r32) if use_r else (None, None)
+    oh, ol, (st, G) = ops.linear_x2(x, w, b, res=rh, res_lo=rl if split else None, want_lo=split, row_stats=True)
+    assert 1 <= G <= N // 64
+    val = x.float() @ w.float().t() + b.float()
+    if use_r:
+        val = val + (r32 if split else rh.float())
+    s1, s2 = stats_of(st, G)
+    assert rel_l2(s1, val.sum(1)) < 2e-5 and rel_l2(s2, (val * val).sum(1)) < 2e-5
+    # and the stored planes are what they were without the statistics
+    ph, pl = ops.linear_x2(x, w, b, res=rh, res_lo=rl if split else None, want_lo=split)
+    assert torch.equal(ph, oh) and (not split or torch.equal(pl, ol))
+
+
+def test_row_stats_pass_and_xattn_block_statistics():
+    M, C = 2048, 320
+    h32 = rnd(M, C, seed=1, scale=3.0, dtype=torch.float32) + 0.5
+    hh, hl = ops.split_f16(h32)
+    st = ops.row_stats(hh, hl)
+    assert rel_l2(st[:, 0, 0], h32.sum(1)) < 1e-5 and rel_l2(st[:, 0, 1], (h32 * h32).sum(1)) < 1e-5
+    st1 = ops.row_stats(hh)
+    assert rel_l2(st1[:, 0, 0], hh.float().sum(1)) < 1e-5
+    # fused cross-attention block: statistics of its output, both stream modes
+    B, HW, Nk = 2, 1024, 77
+    g, b = (1.0 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
+    wq, wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, C, seed=5, scale=C ** -0.5), rnd(C, seed=6, scale=0.1)
+    kv = rnd(B, Nk, 2 * C, seed=7)
+    for lo in (hl, None):
+        oh, ol, rs = ops.xattn_block_x2(hh, lo, g, b, wq, kv, wo, bo, hw=HW, row_stats=True)
+        val = oh.float() + (ol.float() if ol is not None else 0.0)
+        assert rel_l2(rs[:, 0, 0], val.sum(1)) < 3e-4 and rel_l2(rs[:, 0, 1], (val * val).sum(1)) < 3e-4      # (from the fp32 values before the fp16 stores)
+        plain = ops.xattn_block_x2(hh, lo, g, b, wq, kv, wo, bo, hw=HW)
+        assert torch.equal(plain[0], oh)
+
+
+CONSUMERS = [   # M, C, N, geglu, bias : the three consumers on every kernel family
+    (8192, 320, 960, False, False),      # QKV, gemm_w8_kernel
+    (8192, 320, 2560, True, True),       # GEGLU proj, gemm_w8_kernel<true>
+    (4096, 640, 640, False, False),      # attn2.to_q
+    (2048, 1280, 3840, False, False),    # QKV at the 8 x 8 level (256 x 160 tiles)
+    (2048, 1280, 1280, False, False),    # to_q at the 8 x 8 level: generic tile + split-K reduce
+    (2048, 1280, 10240, True, True),     # GEGLU proj at the 8 x 8 level
+    (320, 128, 256, True, True),         # generic GEGLU tile, ragged M
+    (320, 128, 128, False, True),        # generic tile
+]
+
+
+@pytest.mark.parametrize("case", CONSUMERS)
+def test_linear_ln_matches_layernorm_then_linear(case):
+    M, C, N, geglu, use_b = case
+    h32 = rnd(M, C, seed=1, scale=2.5, dtype=torch.float32) + 0.3          # a row mean of ~0.1 sigma, as hidden states have
+    hh, hl = ops.split_f16(h32)
+    gam, bet = (1.0 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
+    w, b = rnd(N, C, seed=4, scale=C ** -0.5), (rnd(N, seed=5, scale=0.1) if use_b else None)
+    if geglu:
+        wp, bp = ops.geglu_pack(w, b)
+        wp, bp = wp.to(DEV), bp.to(DEV)
+    else:
+        wp, bp = w, b
+    wf, sf, bf = (t.to(DEV) for t in ops.ln_fold_pack(wp, bp, gam, bet))
+    st = ops.row_stats(hh, hl)                                              # exact statistics of hi + lo (what an x2 producer leaves)
+    got = ops.linear_ln(hh, wf, sf, bf, st, 1, geglu=geglu)
+    # fp32 reference: LayerNorm(h) -> Linear (-> GEGLU) on the unfolded weights
+    y = F.layer_norm(h32, (C,), gam.float(), bet.float(), 1e-5) @ w.float().t() + (b.float() if use_b else 0.0)
+    if geglu:
+        val, gate = y.chunk(2, dim=-1)
+        y = val * F.gelu(gate)
+    # the two-kernel path this replaces
+    two = ops.linear(ops.layer_norm_x2(hh, hl, gam, bet), wp, bp, geglu=geglu)
+    e_fold, e_two = rel_l2(got.float(), y), rel_l2(two.float(), y)
+    print(f"\n{case}: folded {e_fold:.3e}, LayerNorm kernel + GEMM {e_two:.3e}")
+    assert e_fold < 1.2e-3 and e_fold < 1.5 * e_two + 1e-4, (e_fold, e_two)
+    # what is left is fp16 rounding only: against the SAME arithmetic in fp32 (raw fp16 operand, folded fp16 weights, fp32 epilogue) the kernel is exact
+    mean, var = h32.mean(1, keepdim=True), h32.var(1, unbiased=False, keepdim=True)
+    z = (hh.float() @ wf.float().t() - mean * sf[None, :]) * torch.rsqrt(var + 1e-5) + bf[None, :]
+    if geglu:
+        idx = torch.arange(N, device=DEV).view(-1, 2, 16)                   # (16 value | 16 gate) row blocks
+        v, gte = z[:, idx[:, 0].reshape(-1)], z[:, idx[:, 1].reshape(-1)]
+        z = v * F.gelu(gte)
+    assert rel_l2(got.float(), z.half().float()) < 2e-4
+
+
+def test_linear_ln_reads_grouped_statistics_from_a_producer():
+    """producer -> consumer chain as the executor runs it: to_out + residual leaves G-group statistics, the QKV GEMM of the next sub-block consumes them"""
+    M, C = 8192, 640
+    a, wo, bo = rnd(M, C, seed=1), rnd(C, C, seed=2, scale=C ** -0.5), rnd(C, seed=3, scale=0.1)
+    r32 = rnd(M, C, seed=4, scale=2.0, dtype=torch.float32)
+    rh, rl = ops.split_f16(r32)
+    hh, hl, (st, G) = ops.linear_x2(a, wo, bo, res=rh, res_lo=rl, row_stats=True)
+    assert G > 1
+    gam, bet = (1.0 + 0.1 * rnd(C, seed=5).float()).half(), rnd(C, seed=6, scale=0.1)
+    w = rnd(3 * C, C, seed=7, scale=C ** -0.5)
+    wf, sf, bf = (t.to(DEV) for t in ops.ln_fold_pack(w, None, gam, bet))
+    got = ops.linear_ln(hh, wf, sf, bf, st, G)
+    h32 = a.float() @ wo.float().t() + bo.float() + r32
+    want = F.layer_norm(h32, (C,), gam.float(), bet.float(), 1e-5) @ w.float().t()
+    assert rel_l2(got.float(), want) < 1.0e-3
+    same = ops.linear_ln(hh, wf, sf, bf, ops.row_stats(hh, hl), 1)
+    assert rel_l2(got.float(), same.float()) < 1e-4
+
+
+@pytest.mark.parametrize("residual", ["f16", "f16x2"])
+def test_unet_with_folded_layernorm_matches_the_layernorm_kernels(residual):
+    """the executor with ln_fold on (default) and off: same forward up to fp16 roundings inside the branches, and no further from the fp32 oracle"""
+    from oracle.unet_oracle import UNetOracle
+    for cfg, S in ((dict(layers_per_block=1, sample_size=16), 16), (dict(layers_per_block=1, sample_size=32), 32)):     # 32: the C = 320 level runs the fused cross-attention block
+        u = HipUNet2DConditionModel(cfg, device=DEV, residual=residual)
+        sd = synthetic_unet_state_dict(u.manifest(), seed=3)
+        u.load_state_dict(sd)
+        lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(1)).half()
+        ctx = torch.cat([synthetic_prompt_embeds(2, seed=5), synthetic_prompt_embeds(2, seed=6)]).half()
+        want = UNetOracle(sd, u.config)(torch.cat([lat.float()] * 2), 499, ctx.float())
+        run = lambda: u(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float().cpu()
+        fold = run()
+        ops.set_tuning("ln_fold", 0)
+        try:
+            plain = run()
+            ops.set_tuning("cfg_share", 0)
+            plain_full = run()
+        finally:
+            ops.set_tuning("ln_fold", 1); ops.set_tuning("cfg_share", 1)
+        ops.set_tuning("cfg_share", 0)
+        try:
+            fold_full = run()
+        finally:
+            ops.set_tuning("cfg_share", 1)
+        e_fold, e_plain = rel_l2(fold, want), rel_l2(plain, want)
+        print(f"\nsmall UNet S={S} {residual}: eps error vs fp32 oracle folded {e_fold:.3e}, LayerNorm kernels {e_plain:.3e}")
+        assert torch.equal(plain, plain_full) and torch.equal(fold, fold_full)          # the CFG shared prefix stays exact with the folded path
+        assert rel_l2(fold, plain) < 1.5e-3
+        assert e_fold < 1.15 * e_plain + 5e-5

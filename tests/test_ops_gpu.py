@@ -540,3 +540,46 @@ def test_xattn_block_fused_kernel(B, HW, Nk):
     h2 = h.clone()
     ops.xattn_block(h2, gam, bet, wq, kv, wo, bo, heads=H, hw=HW, out=h2)
     assert torch.equal(h2, got)
+
+
+XCD_GRID_CASES = [   # weight-heavy SD1.5 layers (16 x 16 / 8 x 8 levels, batch 32) where launch_igemm_impl maps the XCDs as a 2-D grid (tile_of, pn > 0)
+    ("conv", 32, 8, 1280, 1280), ("conv", 32, 8, 2560, 1280), ("conv", 32, 16, 1280, 1280), ("conv", 32, 16, 2560, 1280),
+    ("linear", 8192, 1280, 3840, False), ("linear", 8192, 1280, 10240, True), ("linear", 8192, 5120, 1280, False), ("linear", 2048, 1280, 10240, True),
+    ("linear", 2048, 1280, 1280, False),
+]
+
+
+@pytest.mark.parametrize("case", XCD_GRID_CASES)
+def test_xcd_grid_tile_order_is_a_permutation(case):
+    """the 2-D XCD grid only changes WHICH workgroup computes a tile: results are bit-identical to the contiguous order, and every tile is computed
+    (a wrong bijection leaves tiles of the poisoned output untouched)"""
+    if case[0] == "conv":
+        _, B, H, cin, N = case
+        x, w, b = rnd(B, H, H, cin, seed=1), ops.pack_conv_weight(rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5)), rnd(N, seed=3, scale=0.1)
+        run = lambda: ops.conv2d(x, w, b)
+    else:
+        _, M, K, N, geglu = case
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+        if geglu:
+            wp, bp = ops.geglu_pack(w, b)
+            w, b = wp.to(DEV), bp.to(DEV)
+        run = lambda: ops.linear(x, w, b, geglu=geglu)
+    grid = run()
+    ops.set_tuning("xcd_grid", 0)
+    try:
+        contiguous = run()
+    finally:
+        ops.set_tuning("xcd_grid", 1)
+    assert torch.isfinite(grid.float()).all() and torch.equal(grid, contiguous)
+
+
+def test_conv3x3_wider_than_the_loader_wave_zero_region_falls_back():
+    """conv3_lw_kernel's padded halo rows read g_zero_region + chunk offset, which covers 64 chunks; Cin = 4160 (65 chunks) must take the halo
+    kernels and still pad with zeros"""
+    B, H, cin, N = 1, 16, 4160, 160
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    out = ops.conv2d(x, ops.pack_conv_weight(w), b)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1)
+    assert rel_l2(nchw(out), ref) < 1e-3
+    border = torch.ones(H, H, dtype=torch.bool); border[1:-1, 1:-1] = False
+    assert rel_l2(nchw(out)[..., border], ref[..., border]) < 1e-3

@@ -69,11 +69,7 @@ def test_linear_x2(case):
         ref = ref + r32
     rh, rl = ops.split_f16(r32) if use_r else (None, None)
     if in_place:
-        L = ops.L
-        ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
-        L.check(L.lib().cs_op_linear_x2(L.ptr(x), None, M, K, L.ptr(w), L.ptr(b), N, L.ptr(rh), L.ptr(rl), L.ptr(rh), L.ptr(rl), L.ptr(ws), ws.numel(),
-                                        L.stream_ptr(x.device)))
-        oh, ol = rh, rl
+        oh, ol = ops.linear_x2(x, w, b, res=rh, res_lo=rl, out=rh, out_lo=rl)
     else:
         oh, ol = ops.linear_x2(x, w, b, res=rh, res_lo=rl)
     assert rel_l2(oh.float() + ol.float(), ref) < TOL, case

@@ -24,10 +24,35 @@ def rows_of(d):
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", "")), float(r["Counter_Value"])))
     rows.sort()
+    demangle([r[1] for r in rows])
     return rows
 
 
+_DEMANGLED = {}
+
+
+def demangle(names):
+    """rocprofv3 leaves some kernel names mangled (_ZN12_GLOBAL__N_1<len><name>I<template args>E...; binutils' c++filt does not know the _Float16 code
+    DF16_): pull the function name and the template argument codes out by hand"""
+    for n in names:
+        if n in _DEMANGLED or not n.startswith("_Z"):
+            continue
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", n)
+        if not m:
+            continue
+        ln = int(m.group(1))
+        st = m.end()
+        ident = n[st:st + ln]
+        rest = n[st + ln:]
+        targs = ""
+        if rest.startswith("I"):
+            codes = re.findall(r"L([ib])(\d+)E|(DF16_)", rest[:rest.find("EEv") + 1] if "EEv" in rest else rest[:40])
+            targs = "<" + ", ".join(("f16" if c[2] else (c[1] if c[0] == "i" else ("true" if c[1] == "1" else "false"))) for c in codes) + ">"
+        _DEMANGLED[n] = ident + targs
+
+
 def short(name):
+    name = _DEMANGLED.get(name, name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*$", "", name)
@@ -40,7 +65,7 @@ def klass(name):
         return "conv3x3_igemm"
     if n.startswith(("gemm_w8", "gemm_lw", "gemm_big", "igemm_kernel", "splitk_reduce")):
         return "gemm_1x1_linear"
-    if n.startswith(("attn", "xattn")):
+    if n.startswith(("attn", "xattn")) or "attn" in n[:24]:
         return "attention (self + cross)"
     if n.startswith("gn_"):
         return "groupnorm_silu"
@@ -55,8 +80,8 @@ for mode in ("f16", "f16x2"):
     f, w = rows_of(os.path.join(out_dir, f"fwd_{mode}_FETCH_SIZE")), rows_of(os.path.join(out_dir, f"fwd_{mode}_WRITE_SIZE"))
     if not f or not w:
         print(f"(no forward data for residual mode {mode})\n"); continue
-    # the forwards of the run: conv_out_kernel is launched exactly once per forward
-    nfwd = sum(1 for r in f if short(r[1]).startswith("conv_out_kernel")) or 1
+    # the forwards of the run: conv_in_kernel is launched exactly once per forward
+    nfwd = sum(1 for r in f if short(r[1]).startswith("conv_in_kernel")) or 1
     agg = OrderedDict()
     for rows, col in ((f, 0), (w, 1)):
         for _, name, grid, v in rows:

@@ -32,17 +32,40 @@ def r16(x):
 
 
 class Emu(UNetOracle):
-    def __init__(self, sd, cfg, stream=True, raw=True, norm=True, branch=True, raw_sc=None, raw_po=None, raw_ud=None):
+    def __init__(self, sd, cfg, stream=True, raw=True, norm=True, branch=True, raw_sc=None, raw_po=None, raw_ud=None, ln_fold=False):
         super().__init__(sd, cfg)
         ident = lambda x: x
         self.rs = r16 if stream else ident
         self.rr = r16 if raw else ident
+        self.rn = r16 if norm else ident
+        self.rb = r16 if branch else ident
         # per consumer kind (None: follow `raw`): shortcut 1x1, proj_out, down / upsample conv
         self.rr_sc = self.rr if raw_sc is None else (r16 if raw_sc else ident)
         self.rr_po = self.rr if raw_po is None else (r16 if raw_po else ident)
         self.rr_ud = self.rr if raw_ud is None else (r16 if raw_ud else ident)
-        self.rn = r16 if norm else (lambda x: x)
-        self.rb = r16 if branch else (lambda x: x)
+        self.ln_fold = ln_fold
+
+    def _ln_linear(self, h, ln_key, lin_keys, bias=True):
+        """LayerNorm -> Linear(s) as the executor would run it.  Unfolded: fp16(LN(h)) . W.  Folded (ln_fold): the GEMM multiplies the RAW fp16
+        hidden state with W' = fp16(gamma * W) and the epilogue applies rstd (acc - mean s) + b' with s = rowsum(W'), b' = W beta + b in fp32."""
+        sd = self.sd
+        g, be = sd[ln_key + ".weight"], sd[ln_key + ".bias"]
+        outs = []
+        if not self.ln_fold:
+            n = self.rn(self._ln(h, ln_key))
+            for k in lin_keys:
+                outs.append(F.linear(n, sd[k + ".weight"], sd.get(k + ".bias") if bias else None))
+            return outs
+        mean = h.mean(-1, keepdim=True)
+        rstd = torch.rsqrt(h.var(-1, unbiased=False, keepdim=True) + 1e-5)
+        hr = r16(h)
+        for k in lin_keys:
+            w = sd[k + ".weight"]
+            wp = r16(w * g[None, :])
+            s_ = wp.sum(1)
+            bp = w @ be + (sd[k + ".bias"] if (bias and (k + ".bias") in sd) else 0.0)
+            outs.append((hr @ wp.t() - mean * s_[None, None, :]) * rstd + bp)
+        return outs
 
     def _resnet(self, x, temb_silu, p):
         sd = self.sd
@@ -56,19 +79,15 @@ class Emu(UNetOracle):
             x = self.rs(self._conv(self.rr_sc(x), p + ".conv_shortcut"))
         return self.rs(x + h)
 
-    def _attn(self, x, ctx, p):
+    def _sdpa(self, q, k, v):
         H = self.cfg["num_heads"]
-        q = self.rb(self._linear(x, p + ".to_q", bias=False))
-        k = self.rb(self._linear(ctx, p + ".to_k", bias=False))
-        v = self.rb(self._linear(ctx, p + ".to_v", bias=False))
         B, N, C = q.shape
         dh = C // H
         q = q.view(B, N, H, dh).transpose(1, 2)
         k = k.view(B, -1, H, dh).transpose(1, 2)
         v = v.view(B, -1, H, dh).transpose(1, 2)
         a = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1) @ v
-        a = self.rb(a.transpose(1, 2).reshape(B, N, C))
-        return self._linear(a, p + ".to_out.0")
+        return self.rb(a.transpose(1, 2).reshape(B, N, C))
 
     def _xformer(self, x, ctx, p):
         sd = self.sd
@@ -78,12 +97,15 @@ class Emu(UNetOracle):
         h = self.rs(self._conv(h, p + ".proj_in"))
         h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
         t = p + ".transformer_blocks.0"
-        n = self.rn(self._ln(h, t + ".norm1"))
-        h = self.rs(h + self._attn(n, n, t + ".attn1"))
-        n = self.rn(self._ln(h, t + ".norm2"))
-        h = self.rs(h + self._attn(n, r16(ctx), t + ".attn2"))
-        n = self.rn(self._ln(h, t + ".norm3"))
-        pr = F.linear(n, sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
+        q, k, v = self._ln_linear(h, t + ".norm1", [t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"], bias=False)
+        a = self._sdpa(self.rb(q), self.rb(k), self.rb(v))
+        h = self.rs(h + self._linear(a, t + ".attn1.to_out.0"))
+        (q,) = self._ln_linear(h, t + ".norm2", [t + ".attn2.to_q"], bias=False)
+        cx = r16(ctx)
+        k = self.rb(self._linear(cx, t + ".attn2.to_k", bias=False)); v = self.rb(self._linear(cx, t + ".attn2.to_v", bias=False))
+        a = self._sdpa(self.rb(q), k, v)
+        h = self.rs(h + self._linear(a, t + ".attn2.to_out.0"))
+        (pr,) = self._ln_linear(h, t + ".norm3", [t + ".ff.net.0.proj"])
         val, gate = pr.chunk(2, dim=-1)
         ff = self.rb(val * F.gelu(gate))
         h = h + self._linear(ff, t + ".ff.net.2")
@@ -184,6 +206,9 @@ if __name__ == "__main__":
         ("  + down / upsample conv reads hi + lo", dict(base, raw=True, raw_ud=False)),
         ("  + proj_out and shortcut read hi + lo", dict(base, raw=True, raw_po=False, raw_sc=False)),
         ("fp32-class residual stream, every raw operand hi + lo", dict(base, raw=False)),
+        ("  shortcut hi + lo, LayerNorm folded into the consumer GEMM", dict(base, raw=True, raw_sc=False, ln_fold=True)),
+        ("  shortcut + proj_out hi + lo, LayerNorm folded", dict(base, raw=True, raw_sc=False, raw_po=False, ln_fold=True)),
+        ("fp16 executor as built + LayerNorm folded", dict(stream=True, raw=True, norm=True, branch=True, ln_fold=True)),
         ("only the residual stream fp16", dict(stream=True, raw=False, norm=False, branch=False)),
         ("only norm outputs fp16", dict(stream=False, raw=False, norm=True, branch=False)),
         ("only branch tensors fp16", dict(stream=False, raw=False, norm=False, branch=True)),
