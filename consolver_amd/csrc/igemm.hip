@@ -78,6 +78,35 @@ __device__ __forceinline__ void trace_stamp(int debug, int slot, int which) {
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Folded-LayerNorm consumer, tile prologue (gemm_w8_kernel / gemm_lw_kernel, LNM == 1): everything the epilogue needs from global memory is fetched into a
+// spare LDS region WHILE THE K LOOP RUNS -- per tile row (rstd, mean rstd) from the producer's partial sums, per weight row b' and s -- so that the epilogue
+// itself issues no loads.  (With the loads in the epilogue the QKV GEMMs, which otherwise load nothing there, paid +4.7 us per tile: a dependent global load
+// behind every CU's store burst.)  Layout: [rows][2] floats, then [tables][2][wc] floats (b' | s per column group of wc weight rows).
+__device__ __forceinline__ void ln_tile_prologue(const IgemmParams& p, char* lnx, int t, int nthreads, int m_blk, int rows, int n_blk, int wc, int tables) {
+    for (int r = t; r < rows; r += nthreads) {
+        const int m = min(m_blk + r, p.M - 1);
+        const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
+        float s1 = 0.f, s2 = 0.f;
+        for (int g = 0; g < p.ln_groups; ++g) { const f32x2 v = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += v[0]; s2 += v[1]; }
+        const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps);
+        *reinterpret_cast<f32x2*>(lnx + r * 8) = f32x2{rstd, mean * rstd};
+    }
+    float* tab = reinterpret_cast<float*>(lnx + rows * 8);
+    for (int c = t * 4; c < tables * wc; c += nthreads * 4) {
+        const int tb = c / wc, cc = c - tb * wc;
+        *reinterpret_cast<f32x4*>(tab + (tb * 2) * wc + cc) = *reinterpret_cast<const f32x4*>(p.ln_b + n_blk + c);
+        *reinterpret_cast<f32x4*>(tab + (tb * 2 + 1) * wc + cc) = *reinterpret_cast<const f32x4*>(p.ln_s + n_blk + c);
+    }
+}
+
+// The same for a plain bias (every other instantiation of those kernels): bias[n_blk .. n_blk + tables * wc) -> LDS [tables][wc] halfs behind the stages, so that
+// the epilogue's per-16-column bias loads are LDS reads (the GEGLU epilogue measured 10-30 us faster per launch that way, profiles/r04_ab_lnfold_ops.txt).
+__device__ __forceinline__ void bias_tile_prologue(const IgemmParams& p, char* tab, int t, int n_blk, int cols) {
+    if (p.bias && t * 8 < cols) *reinterpret_cast<f16x8*>(tab + t * 16) = *reinterpret_cast<const f16x8*>(p.bias + n_blk + t * 8);
+}
+
 // Workgroup -> tile.  Dispatch deals workgroups to the 8 XCDs (private L2 each) round-robin, so XCD = bid & 7 and bid >> 3 is the slot inside it.
 //   pn == 0: an XCD owns a contiguous run of tile ids (row-major; bands of gm tile rows walked column-major when gm > 1): every XCD streams ALL weight panels
 //            and 1/8 of the activation rows through its L2 -- right when the activations dominate the bytes (the 64 x 64 / 32 x 32 levels);
@@ -116,7 +145,6 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
 // product that follows.  Two values per call so that the Horner chain is v_pk_fma_f32: ~7 VALU issue slots per value and no
 // transcendental, against ~22 for the rcp + exp form (A&S 7.1.26) it replaces: the GEGLU epilogue evaluates this 168 M
 // times per L0 layer and was VALU-bound.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     f32x2 xc;
     xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f);
@@ -157,8 +185,11 @@ struct LinearRows {
 // F32 (round 3, layers with a time-embedding or residual add): the patch holds acc + bias in FP32 and the adds happen in fp32 on the way out, so the
 // output is rounded to fp16 ONCE (torch's fp16 graph -- and this epilogue until round 2 -- rounds the conv output and then the sum); half as many rows
 // per pass.  Every residual-adding layer of the UNet paid that extra 2^-11 on the residual stream.
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32>
-__device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
+// LNM: 0 = no LayerNorm code at all, 1 = consumer of a folded LayerNorm (p.ln_stats set), 2 = producer of row statistics (p.row_stats set).  Separate kernel
+// instantiations, NOT runtime branches: with both code paths compiled into gemm_w8_kernel<false> its allocation went from 240 to 256 VGPRs and every launch of
+// the class paid for it, LayerNorm or not (+0.75 ms per UNet forward, same-box A/B profiles/r04_ab_ln_codegen.txt).
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM>
+__device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
     static_assert(!(F32 && GEGLU), "the GEGLU layers add nothing after the product");
@@ -176,10 +207,23 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     float st_sum[2] = {0.f, 0.f}, st_sq[2] = {0.f, 0.f};
     // LayerNorm folded into this GEMM (p.ln_stats): the A operand was the RAW hidden state and the weights carry gamma, so the row's (mean, rstd) enter here:
     // value = rstd (acc - mean s[n]) + b'[n] = acc rstd + (b'[n] - (mean rstd) s[n]); the lane's MT rows are patch rows 16 j + (lane & 15)
-    constexpr bool LINEAR = std::is_same<RowMap, LinearRows>::value;      // (only linear / 1x1 layers produce or consume LayerNorm statistics: the conv kernels carry none of this code)
-    const bool lnf = LINEAR && p.ln_stats != nullptr;
+    constexpr bool lnf = LNM == 1 && std::is_same<RowMap, LinearRows>::value;
     float ln_r[MT], ln_mr[MT];
-    if (lnf) {
+    if (lnf && ln_rows) {
+        // the tile prologue (ln_tile_prologue) left (rstd, mean rstd) of the wave's rows and the b' / s table in LDS: no global load here
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(ln_rows + (j * 16 + i16) * 8);
+            ln_r[j] = t[0]; ln_mr[j] = t[1];
+        }
+    } else if (lnf) {
+        // (the generic tile, small shapes:) b' and s of the wave's NT * 16 weight rows through a wave-private LDS table (ln_tab, [2][NT * 16] floats), one round of
+        // global loads together with the row statistics
+        constexpr int WC = NT * 16;
+        for (int c = lane * 4; c < WC; c += 256) {
+            *reinterpret_cast<f32x4*>(ln_tab + c * 4) = *reinterpret_cast<const f32x4*>(p.ln_b + n_base + c);
+            *reinterpret_cast<f32x4*>(ln_tab + (WC + c) * 4) = *reinterpret_cast<const f32x4*>(p.ln_s + n_base + c);
+        }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int m = rows(j * 16 + i16);
@@ -189,12 +233,12 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                 for (int g = 0; g < p.ln_groups; ++g) { const f32x2 t = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += t[0]; s2 += t[1]; }
             }
             const float mean = s1 * p.ln_inv_c;
-            ln_r[j] = __builtin_amdgcn_rsqf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps);
+            ln_r[j] = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps);
             ln_mr[j] = mean * ln_r[j];
         }
     }
     // row statistics of THIS layer's output for a LayerNorm folded into its consumer (p.row_stats; F32 path only): one (sum, sum of squares) per row and wave
-    const bool rstats = LINEAR && F32 && !GEGLU && GROUP == NT && p.row_stats != nullptr;
+    constexpr bool rstats = LNM == 2 && std::is_same<RowMap, LinearRows>::value && F32 && !GEGLU && GROUP == NT;
 #pragma unroll
     for (int grp = 0; grp < NT / GROUP; ++grp)
 #pragma unroll
@@ -207,20 +251,23 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
             float sv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
             if (lnf) {                                          // folded LayerNorm: b' (fp32, holds the layer's own bias) and s = row sums of the folded weight
-                const f32x4 t = *reinterpret_cast<const f32x4*>(p.ln_b + n), u = *reinterpret_cast<const f32x4*>(p.ln_s + n);
+                constexpr int WC = NT * 16;
+                const int c = i * 16 + g4;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(ln_tab + c * 4), u = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { bv[r] = t[r]; sv[r] = u[r]; }
                 if (GEGLU) {
-                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(p.ln_b + n + 16), u2 = *reinterpret_cast<const f32x4*>(p.ln_s + n + 16);
+                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(ln_tab + (c + 16) * 4), u2 = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c + 16) * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { bg[r] = t2[r]; sg[r] = u2[r]; }
                 }
             } else if (p.bias) {
-                const f16x4 t = *reinterpret_cast<const f16x4*>(p.bias + n);
+                // (ln_tab, when the kernel has one: the wave's bias values in LDS, fetched by bias_tile_prologue under the k loop)
+                const f16x4 t = ln_tab ? *reinterpret_cast<const f16x4*>(ln_tab + (i * 16 + g4) * 2) : *reinterpret_cast<const f16x4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = (float)t[r];
                 if (GEGLU) {
-                    const f16x4 u = *reinterpret_cast<const f16x4*>(p.bias + n + 16);
+                    const f16x4 u = ln_tab ? *reinterpret_cast<const f16x4*>(ln_tab + (i * 16 + g4 + 16) * 2) : *reinterpret_cast<const f16x4*>(p.bias + n + 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bg[r] = (float)u[r];
                 }
@@ -228,31 +275,38 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
             for (int jj = 0; jj < RT; ++jj) {
                 const int j = rh * RT + jj;
-                // (folded LayerNorm: acc rstd + (b' - mean rstd s); otherwise acc + bias)
-                f32x4 av = acc[i][j];
-                float bj[4] = {bv[0], bv[1], bv[2], bv[3]};
+                // val = folded LayerNorm ? acc rstd + (b' - mean rstd s) : acc + bias.  EXPLICIT fused multiply-adds: left to -ffp-contract the compiler fused some of the
+                // unrolled (i, j) instances and not others, and a row's result depended on which 16-row tile of the wave it sat in (last-bit differences between the
+                // same sample at two batch positions; tools/dbg_rows.py)
+                f32x4 val;
                 if (lnf) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { av[r] *= ln_r[j]; bj[r] = bv[r] - ln_mr[j] * sv[r]; }
+                    for (int r = 0; r < 4; ++r) val[r] = __builtin_fmaf(acc[i][j][r], ln_r[j], __builtin_fmaf(-ln_mr[j], sv[r], bv[r]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] = acc[i][j][r] + bv[r];
                 }
                 if constexpr (F32) {
-                    const f32x4 o = {av[0] + bj[0], av[1] + bj[1], av[2] + bj[2], av[3] + bj[3]};
+                    const f32x4 o = val;
                     *reinterpret_cast<f32x4*>(wave_lds + (jj * 16 + i16) * ROWB + (ii * 16 + g4) * 4) = o;
                 } else {
                     f16x4 o;
                     if (GEGLU) {
-                        f32x4 gt = acc[i + 1 < NT ? i + 1 : i][j];
-                        float gj[4] = {bg[0], bg[1], bg[2], bg[3]};
+                        const f32x4 ga = acc[i + 1 < NT ? i + 1 : i][j];
+                        f32x4 gt;
                         if (lnf) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { gt[r] *= ln_r[j]; gj[r] = bg[r] - ln_mr[j] * sg[r]; }
+                            for (int r = 0; r < 4; ++r) gt[r] = __builtin_fmaf(ga[r], ln_r[j], __builtin_fmaf(-ln_mr[j], sg[r], bg[r]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gt[r] = ga[r] + bg[r];
                         }
-                        const f32x2 g01 = gelu_erf2(f32x2{gt[0] + gj[0], gt[1] + gj[1]}), g23 = gelu_erf2(f32x2{gt[2] + gj[2], gt[3] + gj[3]});
-                        o[0] = (f16)((av[0] + bj[0]) * g01[0]); o[1] = (f16)((av[1] + bj[1]) * g01[1]);
-                        o[2] = (f16)((av[2] + bj[2]) * g23[0]); o[3] = (f16)((av[3] + bj[3]) * g23[1]);
+                        const f32x2 g01 = gelu_erf2(f32x2{gt[0], gt[1]}), g23 = gelu_erf2(f32x2{gt[2], gt[3]});
+                        o[0] = (f16)(val[0] * g01[0]); o[1] = (f16)(val[1] * g01[1]);
+                        o[2] = (f16)(val[2] * g23[0]); o[3] = (f16)(val[3] * g23[1]);
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (f16)(av[r] + bj[r]);
+                        for (int r = 0; r < 4; ++r) o[r] = (f16)val[r];
                     }
                     const int col = GEGLU ? (ii >> 1) * 16 + g4 : ii * 16 + g4;
                     *reinterpret_cast<f16x4*>(wave_lds + (jj * 16 + i16) * ROWB + col * 2) = o;
@@ -293,7 +347,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
                     if (rstats) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { rs1 += f[r]; rs2 += f[r] * f[r]; }
+                        for (int r = 0; r < 8; ++r) { rs1 += f[r]; rs2 = __builtin_fmaf(f[r], f[r], rs2); }
                     }
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
                     if (p.out_lo) {                           // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
@@ -351,12 +405,18 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     }
 }
 
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds) {
-    if constexpr (!GEGLU) {
-        if (p.temb || p.res || p.out_lo || p.row_stats) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true>(p, acc, rows, n_base, lane, wave_lds); return; }
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab = nullptr, const char* ln_rows = nullptr) {
+    if constexpr (LNM == 2) {                           // row statistics come from the fp32 values: always the fp32-patch path
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true, 2>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+    } else if constexpr (LNM == 1) {                    // a folded LayerNorm's consumer adds nothing after the product (launch_igemm_impl checks)
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+    } else {
+        if constexpr (!GEGLU) {
+            if (p.temb || p.res || p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+        }
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     }
-    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false>(p, acc, rows, n_base, lane, wave_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1047,6 +1107,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 // With ONE tile per CU and the operands in L2 / Infinity Cache this form is latency-free; as a general GEMM it loses to the 256 x 320 tile (twice the
 // L2 -> LDS bytes per FLOP: profiles/r03_ab_gemm_lw.txt), so launch_igemm_impl uses it only where gemm_big_kernel<false, 160> used to run.
 // ------------------------------------------------------------------------------------------------
+template <int LNM = 0>
 __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
     constexpr int BMX = 256, BN = 160, NT = BN / 16, MT = 4, NWB = 3;
     constexpr int A_BYTES = BMX * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1059,10 +1120,12 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
     tile_of(blockIdx.x, p.nblk, p.tiles_n, p.gm, p.pn, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BN;
     const int KT = p.KT;
+    char* const lnx = smem + NWB * STAGE;                       // LNM == 1: 256 x (rstd, mean rstd) + one (b' | s) table of the tile's 160 weight rows, behind the stages
 
     if (w >= 4) {
         // =============================== loader waves ===============================
         const int l = w - 4;
+
         const int pch = lane & 7, lr = lane >> 3;
         // rows past M are clamped to the last row: their products are computed and never stored
         const f16* asrc0[APL]; const f16* asrc1[APL]; const f16* wsrc[WPL];
@@ -1103,6 +1166,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
         // and K(g) needs stage g + 1: everything but the 13 pieces just issued.
         issue(0, 0);
         if (KT > 1) issue(1, 1);
+        // folded LayerNorm: the tile's row statistics and b' / s table, fetched behind the first two stages (one memory round trip for all of it)
+        if constexpr (LNM == 1) ln_tile_prologue(p, lnx, tid - 256, 256, m_blk, BMX, n_blk, BN, 1);
+        else bias_tile_prologue(p, lnx, tid - 256, n_blk, BN);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                           // K(-1): stages 0 and 1 have landed
         int wb2 = 2;
@@ -1179,7 +1246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // E
-    igemm_epilogue<false, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264);
+    igemm_epilogue<false, NT, MT, NT, LinearRows, 2, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264, LNM == 1 ? lnx + BMX * 8 : lnx, LNM == 1 ? lnx + wm * 64 * 8 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1196,7 +1263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 // +20..40 % time on the multi-round K <= 2560 shapes -- twice the L2 -> LDS bytes per FLOP and that path is the bound; kept for the one-round shapes only) and the 256 x 320 tile on four 512-register waves
 // with the accumulators in AGPRs (r03_ab_gemm_w4.txt: bit-identical, +10..30 % -- half the waves for a store-bound epilogue, no k-loop gain).
 // ------------------------------------------------------------------------------------------------
-template <bool GEGLU>
+template <bool GEGLU, int LNM = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4;
     constexpr int A_BYTES = BMX * 128, B_BYTES = BNX * 128, STAGE = A_BYTES + B_BYTES;      // 32 KB + 40 KB
@@ -1209,6 +1276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     tile_of(blockIdx.x, p.nblk, p.tiles_n, p.gm, p.pn, tm, tn);
     const int m_blk = tm * BMX, n_blk = tn * BNX;
     const int KT = p.KT;
+    char* const lnx = smem + 2 * STAGE;                         // LNM == 1: 256 x (rstd, mean rstd) + two (b' | s) tables (column halves wn = 0 / 1), behind the stages
 
     // ---- staging: wave w owns activation pieces 4 w .. 4 w + 3 (rows 32 w ..) and weight pieces w, w + 8, .. w + 32 ----------------------------
     const int pch = lane & 7, lr = lane >> 3;
@@ -1273,6 +1341,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
 
     // prologue: stage 0, then what items 16..19 of a step issue (pieces 0..3 of the next stage, the next step's first fragments)
     static_for<NPC>([&](auto nc) { piece(nc, 0, 0); });
+    // folded LayerNorm: the tile's row statistics and b' / s tables, fetched behind stage 0 (one memory round trip for all of it; published by the barrier below)
+    if constexpr (LNM == 1) ln_tile_prologue(p, lnx, tid, 512, m_blk, BMX, n_blk, BNX / 2, 2);
+    else bias_tile_prologue(p, lnx, tid, n_blk, BNX);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (KT > 1) static_for<4>([&](auto nc) { piece(nc, 1, 1); });
@@ -1321,8 +1393,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // the stage buffers become the epilogue patches
-    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
-    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264);
+    char* const ln_tab = LNM == 1 ? lnx + BMX * 8 + wn * (2 * (BNX / 2) * 4) : lnx + wn * (BNX / 2) * 2;      // (LNM != 1: the wave's half of the bias table)
+    const char* const ln_rows = LNM == 1 ? lnx + wm * 64 * 8 : nullptr;
+    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
 }
 
 // row statistics of a [M][C] tensor (value = x + x_lo when x_lo != null): stats[M][1][2] = (sum, sum of squares) per row.  The fallback of IgemmArgs::row_stats
@@ -1336,7 +1410,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const f16* __restrict__ 
         f16x8 t2 = {0, 0, 0, 0, 0, 0, 0, 0};
         if (x_lo) t2 = *reinterpret_cast<const f16x8*>(x_lo + (size_t)row * C + c);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float f = (float)t[k] + (float)t2[k]; s1 += f; s2 += f * f; }
+        for (int k = 0; k < 8; ++k) { const float f = (float)t[k] + (float)t2[k]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { stats[2 * (size_t)row] = s1; stats[2 * (size_t)row + 1] = s2; }
@@ -1359,9 +1433,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
             float s1 = 0.f, s2 = 0.f;
             const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
             for (int g = 0; g < p.ln_groups; ++g) { s1 += st[2 * g]; s2 += st[2 * g + 1]; }
-            const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(s2 * p.ln_inv_c - mean * mean, 0.f) + p.ln_eps), mr = mean * rstd;
+            const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps), mr = mean * rstd;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = v[k] * rstd + (p.ln_b[n + k] - mr * p.ln_s[n + k]);
+            for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], rstd, __builtin_fmaf(-mr, p.ln_s[n + k], p.ln_b[n + k]));
         } else if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
@@ -1565,7 +1639,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     if (p.debug & 16384) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p.debug, blockIdx.x, 4); }
 }
 
-template <int BN, bool CONV3, bool GEGLU>
+template <int BN, bool CONV3, bool GEGLU, int LNM = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int NT = BN / 32;          // 16-wide n tiles per wave (wave tile = 64 x BN/2)
     constexpr int MT = 4;
@@ -1702,14 +1776,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         }
         return;
     }
-    igemm_epilogue<GEGLU, NT, MT, NT>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264);
+    igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264, LNM == 1 ? smem + 4 * 11264 + w * 1280 : nullptr);
 }
 
-template <int BN, bool CONV3, bool GEGLU>
+template <int BN, bool CONV3, bool GEGLU, int LNM = 0>
 int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
     constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
     static bool configured = false;
-    auto kfn = igemm_kernel<BN, CONV3, GEGLU>;
+    auto kfn = igemm_kernel<BN, CONV3, GEGLU, LNM>;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
@@ -1735,6 +1809,8 @@ int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few
 int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
 int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 or N % 128 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 3: N % 160 == 0 only, 0: the 8-wave halo kernels
 int g_tune_biggemm = 1;
+// extra dynamic LDS of the folded-LayerNorm consumer instantiations (ln_tile_prologue): 256 rows x 8 B + the (b' | s) tables
+constexpr size_t LN_LDS_W8 = 256 * 8 + 2 * 2 * 160 * 4, LN_LDS_LW = 256 * 8 + 2 * 160 * 4;
 int g_tune_xcd_grid = 1;        // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
 
 // tile_of's pn for a launch of tiles_m x tiles_n tiles that reads a_bytes of activations and w_bytes of weights once each algorithmically: per-XCD L2s mean the
@@ -1791,6 +1867,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
     p.res_lo = a.res ? a.res_lo : nullptr; p.out_lo = a.out_lo;
+    const bool conv3_early = a.taps == 9;
     p.row_stats = a.row_stats;
     p.ln_stats = a.ln_stats; p.ln_groups = a.ln_groups; p.ln_inv_c = 1.0f / (float)cin; p.ln_eps = a.ln_eps; p.ln_s = a.ln_s; p.ln_b = a.ln_b;
     if (a.ln_stats) {
@@ -1801,6 +1878,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     if (a.row_stats && (a.geglu || a.gn_stats)) CS_FAIL(CS_E_ARG, "igemm: row_stats excludes GEGLU and gn_stats");
     if (a.row_stats && !a.row_stats_groups) CS_FAIL(CS_E_ARG, "igemm: row_stats needs row_stats_groups (the layout the chosen kernel wrote is returned there)");
     p.a0_lo = a.a0_lo; p.a1_lo = a.c1 ? a.a1_lo : nullptr; p.KTh = p.KT;
+    const int lnm = a.ln_stats ? 1 : (a.row_stats && !conv3_early ? 2 : 0);      // epilogue instantiation: folded-LayerNorm consumer / row-statistics producer / neither
     const bool split_a = a.a0_lo != nullptr;
     if (split_a) {
         if (a.taps != 1 || a.geglu) CS_FAIL(CS_E_ARG, "igemm: a split-fp16 A operand (a0_lo) is built for 1x1 / linear layers without GEGLU");
@@ -1925,16 +2003,16 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
             }
             // round 3: the hand-scheduled k loop (gemm_w8_kernel) whenever 32-bit byte offsets reach every operand row
             const bool off32 = (double)p.M * (a.c0 > a.c1 ? a.c0 : a.c1) * 2 < 4.0e9 && (double)a.N * p.Ktot * 2 < 4.0e9;
-            if (split_a && !(g_tune_gemm_w8 && off32 && !g_tune_debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging
+            if ((split_a || lnm) && !(g_tune_gemm_w8 && off32 && !g_tune_debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging and no LayerNorm epilogues
             if (g_tune_gemm_w8 && off32 && !g_tune_debug) {
+                typedef void (*w8_fn)(IgemmParams);
+                static const w8_fn w8[5] = {gemm_w8_kernel<false, 0>, gemm_w8_kernel<true, 0>, gemm_w8_kernel<false, 1>, gemm_w8_kernel<true, 1>, gemm_w8_kernel<false, 2>};
                 static bool configured_w8 = false;
                 if (!configured_w8) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    for (w8_fn f : w8) CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + LN_LDS_W8)));
                     configured_w8 = true;
                 }
-                if (a.geglu) hipLaunchKernelGGL((gemm_w8_kernel<true>), dim3(p.nblk), dim3(512), lds, s, p);
-                else hipLaunchKernelGGL((gemm_w8_kernel<false>), dim3(p.nblk), dim3(512), lds, s, p);
+                hipLaunchKernelGGL(w8[lnm == 2 ? 4 : 2 * lnm + (a.geglu ? 1 : 0)], dim3(p.nblk), dim3(512), lds + LN_LDS_W8, s, p);
                 CS_CHECK_LAUNCH();
                 return CS_OK;
             }
@@ -1956,15 +2034,17 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            if (split_a && !(g_tune_gemm_lw && !g_tune_debug)) goto generic_tiles;
+            if ((split_a || lnm) && !(g_tune_gemm_lw && !g_tune_debug)) goto generic_tiles;
             if (g_tune_gemm_lw && !g_tune_debug) {                    // round 3: the loader-wave form (three 52 KB stages)
                 constexpr size_t lds_lw = 3 * (256 * BK * 2 + 160 * BK * 2);
+                typedef void (*lw_fn)(IgemmParams);
+                static const lw_fn lwk[3] = {gemm_lw_kernel<0>, gemm_lw_kernel<1>, gemm_lw_kernel<2>};
                 static bool configured_lw = false;
                 if (!configured_lw) {
-                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_lw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lw));
+                    for (lw_fn f : lwk) CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_lw + LN_LDS_LW)));
                     configured_lw = true;
                 }
-                hipLaunchKernelGGL(gemm_lw_kernel, dim3(p.nblk), dim3(512), lds_lw, s, p);
+                hipLaunchKernelGGL(lwk[lnm], dim3(p.nblk), dim3(512), lds_lw + LN_LDS_LW, s, p);
                 CS_CHECK_LAUNCH();
                 return CS_OK;
             }
@@ -1976,7 +2056,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
 generic_tiles:
     p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n; p.gm = 1; p.pn = choose_xcd_grid(tiles_m, p.tiles_n, a_bytes, w_bytes); li->gn_done = false; li->row_groups = 0;
     if (a.geglu) {
-        return launch_variant<128, false, true>(p, s);
+        return lnm == 1 ? launch_variant<128, false, true, 1>(p, s) : launch_variant<128, false, true>(p, s);
     }
     // few tiles and a long k loop (stride-2 convs into the 16 x 16 / 8 x 8 levels, the 8 x 8 linears): split K to fill the chip
     int splits = 1;
@@ -1987,8 +2067,10 @@ generic_tiles:
     }
     li->gn_done = stats_ok && splits == 1;
     li->row_groups = (splits == 1 && !conv3) ? a.N / (bn / 2) : 0;          // igemm_kernel: 64 x bn / 2 wave tiles; the split-K reduce leaves no row statistics
-    if (bn == 128) return conv3 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
-    return conv3 ? launch_variant<160, true, false>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
+    if (conv3) return bn == 128 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<160, true, false>(p, s, splits);
+    const int lk = splits > 1 ? 0 : lnm;            // (split-K: raw partial sums leave the main kernel; the reduce kernel applies a folded LayerNorm itself)
+    if (bn == 128) return lk == 1 ? launch_variant<128, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<128, false, false, 2>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
+    return lk == 1 ? launch_variant<160, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<160, false, false, 2>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
 }
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s) {

@@ -139,7 +139,7 @@ struct CsUNet {
     std::vector<Ev> evs; size_t ev_used = 0;
     double prof_ms[P_COUNT] = {}, prof_flops[P_COUNT] = {}, prof_bytes[P_COUNT] = {}; int prof_launches[P_COUNT] = {};
     double dry_flops = 0;
-    int residual = CS_RESIDUAL_F16;   // cs_unet_set_residual_precision
+    int residual = CS_RESIDUAL_F16X2;   // cs_unet_set_residual_precision (default: the mode that meets the 1e-3 latent gate)
 };
 
 namespace {

@@ -367,12 +367,12 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
                 for (int e = 0; e < 8; ++e) {
                     const float f = (float)v[e] + (float)res[k][e] + (float)resl[k][e];
                     o[e] = (f16)f; l[e] = (f16)(f - (float)o[e]);
-                    s1 += f; s2 += f * f;
+                    s1 += f; s2 = __builtin_fmaf(f, f, s2);
                 }
                 if (m < p.M) *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * C + ch * 8) = l;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v[e] + (float)res[k][e]; o[e] = (f16)f; s1 += f; s2 += f * f; }
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e] + (float)res[k][e]; o[e] = (f16)f; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
             }
             if (m < p.M && !(p.debug & 16)) *reinterpret_cast<f16x8*>(p.out + (size_t)m * C + ch * 8) = o;
             // row statistics for norm3 folded into the GEGLU GEMM: the item's partial sums go to weight stage 1 (free since the to_out GEMM's last barrier; the

@@ -101,8 +101,8 @@ def main(argv=None):
         vae.load_state_dict(_load_sd(args.vae))
         prompts, pe, ne = load_prompt_cache(args.prompt_cache)
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",
-                                     order_dim=args.order_dim, scaler_dim=args.scaler_dim,
-                                     factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=args.num_actions, use_conv=args.use_conv))
+                                     order_dim=args.order_dim, scaler_dim=args.scaler_dim, use_conv=args.use_conv,
+                                     factor_net_kwargs=dict(embedding_dim=32, hidden_dim=256, num_actions=args.num_actions))
     if args.policy:
         sch.factor_net.load_state_dict(torch.load(args.policy, map_location="cpu"))
     sch.factor_net.to(dev)

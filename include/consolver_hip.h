@@ -195,12 +195,13 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
 
 /* Storage precision of the UNet's RESIDUAL STREAM (resnet outputs, transformer hidden states, proj_out / down / upsample / conv_in
  * outputs) between kernels.  Every GEMM operand is fp16 in both modes (the reference pipeline's own dtype, gen_ppo.py:193-195).
- *   CS_RESIDUAL_F16   (default) one fp16 tensor per stream tensor: the arithmetic class of the reference's fp16 pipeline; the 8-step latents
- *                     land 1.4e-3 (relative L2) from an fp32 evaluation of the same graph, because every add onto the stream rounds it.
- *   CS_RESIDUAL_F16X2 two fp16 planes per stream tensor, value = hi + lo (22 significant bits): adds onto the stream are carried in fp32
- *                     (hi + lo in, hi + lo out), norms read hi + lo, GEMMs that consume the stream directly read the hi plane.  This is the
- *                     mode that meets north_star's 1e-3 latent gate against the fp32 oracle (tests/test_parity_e2e_gpu.py); it costs the
- *                     lo planes' bytes.  Switching changes cs_unet_workspace_bytes(): query it again. */
+ *   CS_RESIDUAL_F16X2 (default) two fp16 planes per stream tensor, value = hi + lo (22 significant bits): adds onto the stream are carried in fp32
+ *                     (hi + lo in, hi + lo out), norms read hi + lo, the resnet shortcut 1x1 multiplies hi + lo (two passes of its k loop), the other GEMMs
+ *                     that consume the stream directly read the hi plane.  This is the mode that meets north_star's 1e-3 latent gate against the fp32
+ *                     oracle (8-step latents 0.90e-3, tests/test_parity_e2e_gpu.py); it costs the lo planes' bytes (~9 % of the forward).
+ *   CS_RESIDUAL_F16   one fp16 tensor per stream tensor: the arithmetic class of the reference's own fp16 pipeline; the 8-step latents land 1.4e-3
+ *                     (relative L2) from an fp32 evaluation of the same graph, because every add onto the stream rounds it.
+ * Switching changes cs_unet_workspace_bytes(): query it again. */
 #define CS_RESIDUAL_F16   0
 #define CS_RESIDUAL_F16X2 1
 int cs_unet_set_residual_precision(CsUNet* u, int mode);

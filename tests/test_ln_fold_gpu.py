@@ -32,7 +32,10 @@ def rnd(*shape, seed=0, scale=1.0, dtype=torch.float16):
 
 
 def stats_of(st, G):
-    return st[:, :G, 0].sum(1), st[:, :G, 1].sum(1)
+    """the kernel's layout is [M][G][2] contiguous (row stride 2 G floats); the wrapper's buffer has room for N / 64 groups"""
+    M = st.shape[0]
+    v = st.reshape(-1)[: M * G * 2].view(M, G, 2)
+    return v[:, :, 0].sum(1), v[:, :, 1].sum(1)
 
 
 PRODUCERS = [   # M, K, N, res : every kernel family that writes a transformer hidden state
@@ -179,5 +182,6 @@ def test_unet_with_folded_layernorm_matches_the_layernorm_kernels(residual):
         e_fold, e_plain = rel_l2(fold, want), rel_l2(plain, want)
         print(f"\nsmall UNet S={S} {residual}: eps error vs fp32 oracle folded {e_fold:.3e}, LayerNorm kernels {e_plain:.3e}")
         assert torch.equal(plain, plain_full) and torch.equal(fold, fold_full)          # the CFG shared prefix stays exact with the folded path
-        assert rel_l2(fold, plain) < 1.5e-3
+        # two fp16 evaluations that round at different places sit about sqrt(2) x their common distance from the fp32 result apart
+        assert rel_l2(fold, plain) < 1.6 * max(e_fold, e_plain)
         assert e_fold < 1.15 * e_plain + 5e-5
