@@ -129,6 +129,41 @@ def parity_vs_oracle(unet, replay, guidance, dev, modes):
 PEAK_HBM_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured float4 copy)
 
 
+def live_traffic(mode, timeout_s=240):
+    """HBM-side bytes per UNet forward measured IN THIS RUN: two child processes `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/bench_unet.py 2`
+    (separate passes, counters only, the program directly after `--`; the children are started from here, nothing is exec'ed), summed over all dispatches and
+    divided by the forwards of the child (one conv_in_kernel launch each).  gfx950 corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 128-byte
+    requests at 64 bytes -> x2; WRITE_SIZE exact for 16-byte-per-lane stores; unit KB.  Returns (bytes, source) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tot, fwd = {}, {}
+    tmp = tempfile.mkdtemp(prefix="cs_pmc_", dir="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, c)
+            env = dict(os.environ, TMPDIR="/tmp", CS_RESIDUAL=mode)
+            r = subprocess.run([exe, "--pmc", c, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "bench_unet.py"), "2"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {c} failed (rc {r.returncode})"
+            t, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    t += float(row["Counter_Value"])
+                    n += "conv_in_kernel" in row["Kernel_Name"]
+            tot[c], fwd[c] = t, max(n, 1)
+        b = tot["FETCH_SIZE"] * 1024 * 2 / fwd["FETCH_SIZE"] + tot["WRITE_SIZE"] * 1024 / fwd["WRITE_SIZE"]
+        return b, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_unet.py 2 in this run, residual stream {mode}, "
+                   f"{fwd['FETCH_SIZE']} forwards; FETCH x2 (gfx950: 128-B requests counted at 64 B), KB units")
+    except Exception as e:                       # a profiler problem must not take the headline line down
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _timed_ms(fn, iters, warm=1):
     for _ in range(warm):
         fn()
@@ -330,6 +365,9 @@ def main():
                     help="residual-stream storage of the UNet executor for the headline number (include/consolver_hip.h CS_RESIDUAL_*): f16x2 "
                          "(split-fp16, meets the 1e-3 latent gate) or f16 (one plane, the reference pipeline's own arithmetic class); the other "
                          "mode is timed too and reported under `residual_modes`")
+    ap.add_argument("--traffic", default="live", choices=["live", "committed", "none"],
+                    help="roofline.traffic: 'live' (N = 1) measures FETCH_SIZE / WRITE_SIZE with two rocprofv3 --pmc child runs of tools/bench_unet.py after the "
+                         "timed region (falls back to the newest committed profiles/r*_pmc_traffic.json), 'committed' quotes that file only")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch / rendezvous / sharding / reduction path without touching a GPU")
     args = ap.parse_args()
 
@@ -466,7 +504,7 @@ def main():
     # HBM-side bytes per UNet forward: PMC counters are collected offline (separate rocprofv3 --pmc passes, tools/profile_round.sh)
     # and committed under profiles/; the newest committed measurement at this batch size is quoted here
     traffic, traffic_src = None, None
-    if eff_batch == 32:
+    if eff_batch == 32 and args.traffic != "none":
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
             try:
@@ -552,6 +590,12 @@ def main():
             except Exception as e:                      # a failing extra must not take the headline line down with it
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    if rank == 0 and world == 1 and args.traffic == "live" and eff_batch == 32:
+        live, src = live_traffic(headline_mode)
+        if live is not None:
+            roofline["traffic"], roofline["traffic_source"] = live, src
+        else:
+            roofline["traffic_source"] = f"{traffic_src} (committed; live measurement unavailable: {src})"
     if rank == 0:
         images = B * world * args.steps
         rec = {

@@ -815,10 +815,15 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     }
     const int c_per = p.NC / p.splits, c_begin = blockIdx.y * c_per, c_end = c_begin + c_per;
     const int nsteps = c_per * 9;
+    const bool btab = p.e.bias != nullptr && p.splits == 1;          // (uniform: every wave of the workgroup takes the extra barrier or none does)
 
     if (w >= 4) {
         // =============================== loader waves ===============================
         const int l = w - 4;
+        // the tile's bias values: fetched NOW into registers of loader wave 0, handed to the compute waves through LDS behind the k loop (a bias load inside the
+        // epilogue sits behind every CU's store burst; same finding as for the GEMMs, bias_tile_prologue)
+        f16x8 bias_reg = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (btab && l == 0 && lane < BN / 8) bias_reg = *reinterpret_cast<const f16x8*>(p.e.bias + n_blk + lane * 8);
         const int pch = lane & 7, lr = lane >> 3;
         const int iy_base = (UP ? (y0 >> 1) : y0) - 1, ix_base = (UP ? (x0 >> 1) : x0) - 1;    // input pixel of halo (0, 0)
         // halo piece of slot k (0..15): q = (k & 7) * 4 + l + (k >> 3) * 32 -- slice k & 7, second round for halos of more than 32 pieces
@@ -899,6 +904,11 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         }
         if (trl) { g_trace[blockIdx.x * CS_TRACE_W + 9] = tl_wait; g_trace[blockIdx.x * CS_TRACE_W + 10] = tl_bar; }
         __builtin_amdgcn_s_barrier();                                           // E: the stage buffers become the epilogue patches
+        if (btab) {                                                             // bias table behind the four compute waves' patches, then E2
+            if (l == 0 && lane < BN / 8) *reinterpret_cast<f16x8*>(smem + 4 * 11264 + lane * 16) = bias_reg;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                       // E2
+        }
         return;
     }
 
@@ -1080,9 +1090,10 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         g_trace[blockIdx.x * CS_TRACE_W + 4] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) | __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
     }
     __builtin_amdgcn_s_barrier();                                               // E
+    if (btab) __builtin_amdgcn_s_barrier();                                     // E2: loader wave 0 has put the tile's bias values into LDS
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
-        igemm_epilogue<false, NT, MT, NT, PatchRows, 2>(p.e, acc, rows, n_blk, lane, smem + w * 11264);
+        igemm_epilogue<false, NT, MT, NT, PatchRows, 2>(p.e, acc, rows, n_blk, lane, smem + w * 11264, btab ? smem + 4 * 11264 : nullptr);
     } else {
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
 #pragma unroll

@@ -83,7 +83,8 @@ class FMPPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         local = src is not None and (os.path.exists(os.path.join(str(src), subfolder or "", cls.config_name)) or os.path.isfile(str(src)))
         if not local and src is not None and not HAVE_DIFFUSERS:
             # a filesystem-looking path that does not exist is a mistake, not a hub id: plausible-but-wrong shift parameters must not load silently
-            looks_like_path = os.path.isabs(str(src)) or str(src).startswith((".", "~")) or os.path.isdir(str(src)) or str(src).count("/") != 1
+            looks_like_path = (os.path.isabs(str(src)) or str(src).startswith((".", "~")) or os.path.isdir(str(src)) or str(src).count("/") > 1
+                               or str(src).endswith(".json"))
             if looks_like_path:
                 raise EnvironmentError(f"{src!r}: no {cls.config_name} under {os.path.join(str(src), subfolder or '')!r}")
             warnings.warn(f"{src!r} is taken for a hub id (no network here): using the published FLUX.1-Kontext scheduler config")

@@ -175,6 +175,27 @@ def test_standalone_mixins_round_trip_and_cross_load(tmp_path):
     assert "OK" in out
     v = PPOScheduler.from_pretrained(str(tmp_path / "sd2"))
     assert pub(v.config) == pub(s.config)
+    # frozen, but copyable and picklable like diffusers' FrozenDict: deepcopy / pickle of a config and of a whole scheduler
+    import copy, pickle
+    c2, c3, c4 = copy.copy(s.config), copy.deepcopy(s.config), pickle.loads(pickle.dumps(s.config))
+    assert dict(c2) == dict(s.config) == dict(c3) == dict(c4) and type(c3) is type(s.config)
+    with pytest.raises(TypeError):
+        c3["order_dim"] = 9
+    s2 = copy.deepcopy(s)
+    assert pub(s2.config) == pub(s.config) and s2.factor_net is not s.factor_net
+    # FMPPOScheduler.from_pretrained without diffusers: a hub id falls back to the published Kontext config WITH a warning, a path to a JSON file is read,
+    # a filesystem-looking path that does not exist raises instead of silently yielding plausible-but-unintended shift parameters
+    with pytest.warns(UserWarning):
+        f = FMPPOScheduler.from_pretrained("black-forest-labs/FLUX.1-Kontext-dev", subfolder="scheduler", order_dim=2, scaler_dim=0, mu_dim=0,
+                                           factor_net_kwargs=dict(embedding_dim=8, hidden_dim=16, num_actions=5))
+    assert f.config.shift == 3.0 and f.config.order_dim == 2
+    f.save_pretrained(str(tmp_path / "flux" / "scheduler"))
+    g = FMPPOScheduler.from_pretrained(str(tmp_path / "flux" / "scheduler" / "scheduler_config.json"), order_dim=2, scaler_dim=0, mu_dim=0,
+                                       factor_net_kwargs=dict(embedding_dim=8, hidden_dim=16, num_actions=5))
+    assert g.config.shift == f.config.shift and g.config.get("max_shift") == f.config.get("max_shift")
+    for bad in (str(tmp_path / "no_such_dir"), "./typo/scheduler", "a/b/c"):
+        with pytest.raises(EnvironmentError):
+            FMPPOScheduler.from_pretrained(bad, subfolder="scheduler")
 
 
 @pytest.mark.gpu
