@@ -33,6 +33,9 @@ int g_tune_x2_split_a = 1;
 // 1 (default): the transformer blocks' LayerNorms are folded into the linear layers that consume them (gamma in the packed weights, (mean, rstd) applied in the
 // GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
 int g_tune_ln_fold = 1;
+// 1 (default): conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
+// GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
+int g_tune_conv_in_mfma = 1;
 
 // LN(h) W^T + b = rstd (h W'^T - mean s) + b':  W' = fp16(W diag(gamma)), s = row sums of W' (of the ROUNDED values: it cancels exactly what the MFMAs summed),
 // b' = W beta + b.  Host memory; w [N][K] fp16 rows, bias may be null.  Shared by the executor's weight packing and cs_op_ln_fold_pack.
@@ -126,6 +129,7 @@ struct CsUNet {
     bool finalized = false;
     // packed
     Conv conv_in, conv_out; Norm norm_out;
+    Conv conv_in64;                    // conv_in with the input channels zero-padded to 64 ([Cout][9][64]) for the MFMA path
     f16 *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
     f16 *tp_w = nullptr, *tp_b = nullptr; int tp_total = 0;
     std::vector<Resnet> down_res[4], up_res[4]; std::vector<Xformer> down_att[4], up_att[4];
@@ -337,6 +341,7 @@ struct Run {
     bool split = false;            // CS_RESIDUAL_F16X2: residual-stream tensors carry a lo plane
     int v_split_a = 1;             // snapshot of g_tune_x2_split_a
     int v_ln_fold = 1;             // snapshot of g_tune_ln_fold
+    int v_conv_in_mfma = 1;        // snapshot of g_tune_conv_in_mfma
     // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
     float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
 
@@ -606,8 +611,8 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     return out;
 }
 
-struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold; };
-static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share, g_tune_ln_fold}; }
+struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma; };
+static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share, g_tune_ln_fold, g_tune_conv_in_mfma}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
                 char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant()) {
@@ -620,7 +625,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a;
-    R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold;
+    R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
     const int c0 = c.block_out_channels[0], td = 4 * c0, L = c.ctx_len;
@@ -647,11 +652,32 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     // ---- down path -----------------------------------------------------------------------------------
     std::vector<std::pair<St, int>> skips;
     St h = R.salloc((size_t)B * H * W * c0);
-    R.launch(P_MISC, 2.0 * B * H * W * 9.0 * c.in_channels * c0, 2.0 * B * H * W * c0 * (h.lo ? 2 : 1), [&] { return launch_conv_in(latents, n_lat, B, c.in_channels, H, W, u->conv_in.w, u->conv_in.b, c0, h.hi, s, h.lo); });
-    int ch = c0;
-    skips.push_back({h, ch});
     // CFG dual batch with one timestep: the first resnet and the first transformer block up to its cross attention are shared
     const bool share = (dup == 2 && nt == 1 && c.down_has_attn[0] && R.v_cfg_share != 0 && !u->down_res[0].empty());
+    if (R.v_conv_in_mfma && c.in_channels <= 64 && (H * W) % 64 == 0) {
+        // latents -> NHWC-64 (n_lat samples), then the MFMA conv over them; the dual batch's second half is a copy (sample b reads latent b % n_lat)
+        f16* z = R.alloc((size_t)n_lat * H * W * 64);
+        R.launch(P_MISC, 0, 2.0 * n_lat * H * W * 64, [&] { return launch_latent_to_nhwc64(latents, nullptr, nullptr, z, n_lat, c.in_channels, H * W, 1.0f, 0.0f, s); });
+        // GroupNorm statistics of the output from the conv epilogue, in a buffer for the FULL batch: the tensor is also a skip connection that the last up block
+        // normalises at batch B, so the second half's statistics are copied along with the tensor
+        float* st = R.stats_fusable(H * W, c0) ? R.alloc_stats(B, H * W, c0) : nullptr;
+        const int Bkeep = R.B;
+        R.B = n_lat;
+        R.conv(u->conv_in64, z, 64, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h, false, st);
+        R.B = Bkeep;
+        R.release(z);
+        if (dup == 2 && !dry && R.rc == CS_OK) {
+            const size_t half = (size_t)n_lat * H * W * c0;
+            hipMemcpyAsync(h.hi + half, h.hi, half * sizeof(f16), hipMemcpyDeviceToDevice, s);
+            if (h.lo) hipMemcpyAsync(h.lo + half, h.lo, half * sizeof(f16), hipMemcpyDeviceToDevice, s);
+            if (st) { const size_t sh = (size_t)n_lat * (H * W / 64) * c0; hipMemcpyAsync(st + sh, st, sh * sizeof(float), hipMemcpyDeviceToDevice, s); }
+        }
+        if (st) R.stat_of[h.hi] = {st, H * W / 64};
+    } else {
+        R.launch(P_MISC, 2.0 * B * H * W * 9.0 * c.in_channels * c0, 2.0 * B * H * W * c0 * (h.lo ? 2 : 1), [&] { return launch_conv_in(latents, n_lat, B, c.in_channels, H, W, u->conv_in.w, u->conv_in.b, c0, h.hi, s, h.lo); });
+    }
+    int ch = c0;
+    skips.push_back({h, ch});
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->down_res[i].size(); ++j) {
             St r;
@@ -769,6 +795,15 @@ int cs_unet_finalize(CsUNet* u) {
     bool ok = true;
     std::vector<f16> tpw, tpb;
     ok = ok && make_conv(u, "conv_in", u->conv_in) && make_conv(u, "conv_out", u->conv_out) && make_norm(u, "conv_norm_out", u->norm_out, 1e-5f);
+    {   // [co][ci][3][3] -> [co][9][64], channels >= ci zero
+        const HostTensor& w = T(u, "conv_in.weight");
+        const int64_t co = w.shape[0], ci = w.shape[1];
+        std::vector<f16> o((size_t)co * 9 * 64, (f16)0.f);
+        for (int64_t n = 0; n < co; ++n) for (int64_t ch = 0; ch < ci; ++ch) for (int64_t k = 0; k < 9; ++k) o[(n * 9 + k) * 64 + ch] = w.data[(n * ci + ch) * 9 + k];
+        u->conv_in64.cout = (int)co; u->conv_in64.cin = 64; u->conv_in64.taps = 9;
+        u->conv_in64.w = upload(u, o); u->conv_in64.b = u->conv_in.b;
+        ok = ok && u->conv_in64.w;
+    }
     u->t_w1 = upload(u, T(u, "time_embedding.linear_1.weight").data); u->t_b1 = upload(u, T(u, "time_embedding.linear_1.bias").data);
     u->t_w2 = upload(u, T(u, "time_embedding.linear_2.weight").data); u->t_b2 = upload(u, T(u, "time_embedding.linear_2.bias").data);
     Topology t = topology(c);
@@ -810,13 +845,16 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
     // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
     size_t peak = 0;
-    for (int variant = 0; variant < 8; ++variant) {
-        const Variant v{(variant >> 1) & 1, variant & 1, 1, variant >> 2};
+    for (int variant = 0; variant < 16; ++variant) {         // (every knob that changes the allocation sequence: the first-fit arena's peak depends on the holes it leaves)
+        const Variant v{(variant >> 1) & 1, variant & 1, 1, (variant >> 2) & 1, variant >> 3};
         run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
         peak = std::max(peak, u->arena.peak);
         if (batch % 2 == 0) {
-            run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
-            peak = std::max(peak, u->arena.peak);
+            for (int share = 0; share < 2; ++share) {          // (first-fit: the CFG dual batch with and without the shared prefix leaves different holes)
+                Variant vs = v; vs.cfg_share = share;
+                run_forward(u, true, nullptr, batch / 2, 2, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, vs);
+                peak = std::max(peak, u->arena.peak);
+            }
         }
     }
     return kv_cache_bytes(u, batch) + gn_ws_bytes(u, batch) + sk_ws_bytes(u, batch) + peak + 4096;

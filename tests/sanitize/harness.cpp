@@ -62,7 +62,7 @@ static void unet_part() {
             std::vector<float> t(B, 499.f);
             struct K { const char* key; int v; };
             const std::vector<std::vector<K>> variants = {{}, {{"cfg_share", 0}}, {{"xattn_fused", 0}}, {{"gn_fuse", 0}}, {{"cfg_share", 0}, {"xattn_fused", 0}, {"gn_fuse", 0}},
-                                                          {{"x2_split_a", 0}}, {{"x2_split_a", 3}}, {{"ln_fold", 0}}, {{"ln_fold", 0}, {"xattn_fused", 0}, {"cfg_share", 0}}, {{"gemm_w8", 0}, {"gemm_lw", 0}, {"conv_lw", 0}}};
+                                                          {{"x2_split_a", 0}}, {{"x2_split_a", 3}}, {{"ln_fold", 0}}, {{"ln_fold", 0}, {"xattn_fused", 0}, {"cfg_share", 0}}, {{"conv_in_mfma", 0}}, {{"conv_in_mfma", 0}, {"cfg_share", 0}}, {{"gemm_w8", 0}, {"gemm_lw", 0}, {"conv_lw", 0}}};
             for (auto& var : variants) {
                 for (auto& k : var) EXPECT(cs_set_tuning(k.key, k.v) == CS_OK);
                 EXPECT(cs_unet_forward(u, lat.data(), B, 1, t.data(), 1, ctx.data(), out.data(), ws, wsb, 0, nullptr) == CS_OK);

@@ -208,3 +208,21 @@ def test_unet_at_sizes_where_only_some_levels_take_the_fused_paths(sample_size, 
     err = rel_l2(got, want)
     print(f"sample_size {sample_size}: rel l2 vs fp32 oracle {err:.3e}")
     assert torch.isfinite(got).all() and err < 2.5e-3, err
+
+
+@pytest.mark.parametrize("residual", ["f16x2", "f16"])
+def test_forward_does_not_read_uninitialised_workspace(residual):
+    """every byte the forward reads from its workspace must have been written by THIS forward (or be the cached cross-attention K/V): the workspace is
+    filled with random bytes between two runs and the outputs must be bit-identical.  (Round 4: the MFMA conv_in left GroupNorm statistics for the
+    first CFG half only, and the last up block normalised the skip connection at full batch with whatever the arena held.)"""
+    for cfg, S in ((dict(layers_per_block=1, sample_size=16), 16), (dict(layers_per_block=1, sample_size=32), 32)):
+        u = HipUNet2DConditionModel(cfg, device=DEV, residual=residual)
+        u.load_state_dict(synthetic_unet_state_dict(u.manifest(), seed=3))
+        lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(1)).half().to(DEV)
+        ctx = synthetic_prompt_embeds(4, seed=11).half().to(DEV)
+        for dup, c in ((2, ctx), (1, ctx[:2].contiguous())):
+            a = u(lat, 749, encoder_hidden_states=c, dup=dup, reuse_kv=False)[0].clone()
+            for fill in (0xFF, 0x7B):                                    # 0xFFFF halfs are NaNs, 0x7B7B large finite values
+                u._ws.fill_(fill)
+                b = u(lat, 749, encoder_hidden_states=c, dup=dup, reuse_kv=False)[0].clone()
+                assert torch.isfinite(b.float()).all() and torch.equal(a, b), (S, dup, fill)
