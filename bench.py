@@ -132,7 +132,7 @@ PEAK_HBM_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s m
 def live_traffic(mode, timeout_s=240):
     """HBM-side bytes per UNet forward measured IN THIS RUN: two child processes `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 tools/bench_unet.py 2`
     (separate passes, counters only, the program directly after `--`; the children are started from here, nothing is exec'ed), summed over all dispatches and
-    divided by the forwards of the child (one conv_in_kernel launch each).  gfx950 corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 128-byte
+    divided by the forwards of the child (conv_in runs once per forward: `conv_in_kernel`, or `latent_to_nhwc64_kernel` when it is on the MFMA conv).  gfx950 corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE counts 128-byte
     requests at 64 bytes -> x2; WRITE_SIZE exact for 16-byte-per-lane stores; unit KB.  Returns (bytes, source) or (None, reason)."""
     import csv, glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3")
@@ -153,8 +153,10 @@ def live_traffic(mode, timeout_s=240):
             for f in files:
                 for row in csv.DictReader(open(f)):
                     t += float(row["Counter_Value"])
-                    n += "conv_in_kernel" in row["Kernel_Name"]
-            tot[c], fwd[c] = t, max(n, 1)
+                    n += ("conv_in_kernel" in row["Kernel_Name"]) or ("latent_to_nhwc64_kernel" in row["Kernel_Name"])
+            if n == 0:
+                return None, "no conv_in dispatch in the counter file: cannot count the forwards"
+            tot[c], fwd[c] = t, n
         b = tot["FETCH_SIZE"] * 1024 * 2 / fwd["FETCH_SIZE"] + tot["WRITE_SIZE"] * 1024 / fwd["WRITE_SIZE"]
         return b, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_unet.py 2 in this run, residual stream {mode}, "
                    f"{fwd['FETCH_SIZE']} forwards; FETCH x2 (gfx950: 128-B requests counted at 64 B), KB units")

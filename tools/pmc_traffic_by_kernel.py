@@ -80,8 +80,10 @@ for mode in ("f16", "f16x2"):
     f, w = rows_of(os.path.join(out_dir, f"fwd_{mode}_FETCH_SIZE")), rows_of(os.path.join(out_dir, f"fwd_{mode}_WRITE_SIZE"))
     if not f or not w:
         print(f"(no forward data for residual mode {mode})\n"); continue
-    # the forwards of the run: conv_in_kernel is launched exactly once per forward
-    nfwd = sum(1 for r in f if short(r[1]).startswith("conv_in_kernel")) or 1
+    # the forwards of the run: conv_in runs exactly once per forward (conv_in_kernel, or latent_to_nhwc64_kernel when it is served by the MFMA conv)
+    nfwd = sum(1 for r in f if short(r[1]).startswith(("conv_in_kernel", "latent_to_nhwc64_kernel")))
+    if nfwd == 0:
+        print(f"(no conv_in dispatch found for residual mode {mode}: cannot count forwards)\n"); continue
     agg = OrderedDict()
     for rows, col in ((f, 0), (w, 1)):
         for _, name, grid, v in rows:
