@@ -615,21 +615,33 @@ __global__ __launch_bounds__(512) void attn40_lw_kernel(AttnParams p) {
         }
         return as_frag<f16>(v);
     };
+    if constexpr (!K16) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        qf[t][0] = load_qf(t, 0);
-        if constexpr (!K16) { qf[t][1] = load_qf(t, 1); qh[t] = u32x2{0, 0}; }
-        else {
+        for (int t = 0; t < 4; ++t) { qf[t][0] = load_qf(t, 0); qf[t][1] = load_qf(t, 1); qh[t] = u32x2{0, 0}; }
+    } else {
+        // all eight loads of the wave's Q rows in one go, branch-free (a load under `if (d < DH)` came out as load, s_waitcnt vmcnt(0), convert -- four memory round
+        // trips one behind the other in front of the first MFMA): lanes past the head dim read a clamped address and drop the value
+        u32x4 ra[4]; u32x2 rb[4];
+        const int dh = 32 + 4 * g, dhc = dh < DH ? dh : DH - 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f16* qp = p.q + ((size_t)(b * p.Nq + q0 + t * 16 + i16) * p.q_stride + h * DH);
+            ra[t] = *reinterpret_cast<const u32x4*>(qp + 8 * g);
+            rb[t] = *reinterpret_cast<const u32x2*>(qp + dhc);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 v = ra[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = pack2<f16>(El<f16>::tof((u16)(v[e] & 0xffff)) * p.c, El<f16>::tof((u16)(v[e] >> 16)) * p.c);
+            qf[t][0] = as_frag<f16>(v);
             qf[t][1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            const int qrow = q0 + t * 16 + i16, d = 32 + 4 * g;
-            u32x2 v = {0, 0};
-            if (d < DH) {
-                v = *reinterpret_cast<const u32x2*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+            u32x2 u = rb[t];
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    v[e] = pack2<f16>(El<f16>::tof((u16)(v[e] & 0xffff)) * p.c, El<f16>::tof((u16)(v[e] >> 16)) * p.c);
-            }
-            qh[t] = v;
+            for (int e = 0; e < 2; ++e)
+                u[e] = dh < DH ? pack2<f16>(El<f16>::tof((u16)(u[e] & 0xffff)) * p.c, El<f16>::tof((u16)(u[e] >> 16)) * p.c) : 0u;
+            qh[t] = u;
         }
     }
 #pragma unroll

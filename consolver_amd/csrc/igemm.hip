@@ -61,7 +61,9 @@ struct IgemmParams {
     float* gn_stats;    // GroupNorm partial sums of the output, [M / 64][N / 2][2], written by the epilogue (IgemmArgs::gn_stats) or null
     int gm;             // gemm_big_kernel tile order: bands of gm tile rows walked column-major (1 = plain row-major)
     int pn;             // tile_of: 0 = contiguous run of tiles per XCD, > 0 = the XCDs as an (8 / pn) x pn grid over (row tiles, column tiles)
+    int epi_fast;       // knob epi_fast: the FAST forms of the fp32-patch epilogue (igemm_epilogue_f32)
 };
+__device__ __forceinline__ bool g_epi_fast_on(const IgemmParams& p) { return p.epi_fast != 0; }
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
 #define CS_TRACE_SLOTS 8192
@@ -178,6 +180,7 @@ struct LinearRows {
     __device__ __forceinline__ int operator()(int row) const { const int m = m_base + row; return m < M ? m : -1; }
     // index of the wave's 64-row block in the [B][HoWo / 64] statistics grid (rows are sample-major and HoWo % 64 == 0), or -1
     __device__ __forceinline__ int stat_slot(int) const { return m_base < M ? m_base >> 6 : -1; }
+    __device__ __forceinline__ bool all_valid() const { return m_base + 64 <= M; }      // every one of the wave's 64 rows exists
 };
 
 // RSPLIT > 1 trades column groups for row groups: the patch holds 64 / RSPLIT rows x ALL the wave's columns, so a pass stores
@@ -188,7 +191,12 @@ struct LinearRows {
 // LNM: 0 = no LayerNorm code at all, 1 = consumer of a folded LayerNorm (p.ln_stats set), 2 = producer of row statistics (p.row_stats set).  Separate kernel
 // instantiations, NOT runtime branches: with both code paths compiled into gemm_w8_kernel<false> its allocation went from 240 to 256 VGPRs and every launch of
 // the class paid for it, LayerNorm or not (+0.75 ms per UNet forward, same-box A/B profiles/r04_ab_ln_codegen.txt).
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM>
+// FAST (round 4; F32 only, every row of the wave valid): 1 = residual, 2 = residual + its lo plane and a lo plane out, 3 = time embedding -- and nothing else.  The
+// generic code loads what it adds where it adds it: load, s_waitcnt vmcnt(0), add -- and vmcnt counts the stores of the previous iteration too, so every one of a
+// wave's 20 iterations waited a full memory round trip (two with a lo plane) plus the acknowledgement of its predecessor's stores: 28 us of the 71 us a
+// 256 x 320 x 1280 tile took, 43 us in f16x2 mode (from the ISA: tools/README.md, round 4).  Here a pass issues ALL its loads in one go, branch-free, so that
+// the compiler's own counted waits work: one round trip per pass.
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM, int FAST = 0>
 __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
@@ -239,6 +247,29 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     }
     // row statistics of THIS layer's output for a LayerNorm folded into its consumer (p.row_stats; F32 path only): one (sum, sum of squares) per row and wave
     constexpr bool rstats = LNM == 2 && std::is_same<RowMap, LinearRows>::value && F32 && !GEGLU && GROUP == NT;
+    // FAST: within a pass the loads run PD phase-2 iterations ahead of their use (iteration g = pass * NI + k): three iterations in flight, 24 registers with a
+    // lo plane.  (All loads of a pass at once: 40 registers and spills; running ahead ACROSS the passes, the first loads of a pass under its phase 1: spills in the
+    // row-statistics forms, and where it fitted the UNet forward did not move: 29.28 vs 29.29 ms.)  Branch-free, so that the compiler's own counted waits work.
+    constexpr int NI = RT * 16 * CH / 64;                     // phase-2 iterations of a pass
+    constexpr int NG = (NT / GROUP) * RSPLIT * NI;            // ... of the wave
+    constexpr int PD = NI < 3 ? NI : 3;
+    f16x8 pa[FAST ? PD : 1], pb[FAST == 2 ? PD : 1];
+    auto prefetch = [&](int g) {
+        if constexpr (FAST != 0) {
+            static_assert(!FAST || (F32 && !GEGLU), "FAST is a form of the fp32-patch path");
+            const int pass = g / NI, k = g - pass * NI, grp2 = pass / RSPLIT, rh2 = pass - grp2 * RSPLIT;
+            const int n0p = n_base + grp2 * GROUP * 16;
+            const int idx = lane + 64 * k;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int m = rows(rh2 * RT * 16 + row);
+            if constexpr (FAST == 3) pa[g % PD] = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n0p + ch * 8);
+            else {
+                const size_t off = (size_t)m * Nout + n0p + ch * 8;
+                pa[g % PD] = *reinterpret_cast<const f16x8*>(p.res + off);
+                if constexpr (FAST == 2) pb[g % PD] = *reinterpret_cast<const f16x8*>(p.res_lo + off);
+            }
+        }
+    };
 #pragma unroll
     for (int grp = 0; grp < NT / GROUP; ++grp)
 #pragma unroll
@@ -314,10 +345,17 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             }
         }
         // ---- phase 2: LDS patch -> global, 16 bytes per lane, + temb + residual ------------------------------
+        if constexpr (FAST != 0) {
+            // (behind phase 1: the pass's accumulators are dead, their registers hold the loads)
+#pragma unroll
+            for (int k = 0; k < PD; ++k) prefetch((grp * RSPLIT + rh) * NI + k);
+            __builtin_amdgcn_sched_barrier(0);                   // (all of them out before the first is waited for)
+        }
         const int n0 = GEGLU ? ((n_base + grp * GROUP * 16) >> 1) : n_base + grp * GROUP * 16;
         static_assert((RT * 16 * CH) % 64 == 0, "patch items must fill whole wave passes");
 #pragma unroll
         for (int k = 0; k < RT * 16 * CH / 64; ++k) {
+            const int g = (grp * RSPLIT + rh) * NI + k;
             const int idx = lane + 64 * k;
             const int row = idx / CH, ch = idx - row * CH;
             const int m = rows(rh * RT * 16 + row);
@@ -325,9 +363,18 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32), v1 = *reinterpret_cast<const f32x4*>(wave_lds + row * ROWB + ch * 32 + 16);
                 f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
                 float rs1 = 0.f, rs2 = 0.f;
-                if (m >= 0) {
+                if (FAST != 0 || m >= 0) {
                     const size_t off = (size_t)m * Nout + n0 + ch * 8;
                     float f[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if constexpr (FAST != 0) {                // (the same additions in the same order as below, from the registers loaded in front of phase 1)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) f[r] += (float)pa[g % PD][r];
+                        if constexpr (FAST == 2) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) f[r] += (float)pb[g % PD][r];
+                        }
+                        if (k + PD < NI) prefetch(g + PD);        // (into the registers just consumed)
+                    } else {
                     if (p.temb) {
                         const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n0 + ch * 8);
 #pragma unroll
@@ -343,6 +390,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                             for (int r = 0; r < 8; ++r) f[r] += (float)t2[r];
                         }
                     }
+                    }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (f16)f[r];
                     if (rstats) {
@@ -350,7 +398,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                         for (int r = 0; r < 8; ++r) { rs1 += f[r]; rs2 = __builtin_fmaf(f[r], f[r], rs2); }
                     }
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
-                    if (p.out_lo) {                           // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
+                    if (FAST == 2 || (FAST == 0 && p.out_lo)) {   // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
                         f16x8 l;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) l[r] = (f16)(f[r] - (float)o[r]);
@@ -405,15 +453,29 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     }
 }
 
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0>
+// the fp32-patch path: the FAST forms where the layer adds exactly what one of them covers (EFAST: the kernel wants them compiled), else the generic code
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RS2, int LNM, bool EFAST>
+__device__ __forceinline__ void igemm_epilogue_f32(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
+    if constexpr (EFAST) {
+        if (g_epi_fast_on(p) && rows.all_valid()) {
+            if (p.res && !p.temb) {
+                if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+                if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+            } else if (p.temb && !p.res && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 3>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+        }
+    }
+    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+}
+
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0, bool EFAST = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab = nullptr, const char* ln_rows = nullptr) {
     if constexpr (LNM == 2) {                           // row statistics come from the fp32 values: always the fp32-patch path
-        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true, 2>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+        igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else if constexpr (LNM == 1) {                    // a folded LayerNorm's consumer adds nothing after the product (launch_igemm_impl checks)
         igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else {
         if constexpr (!GEGLU) {
-            if (p.temb || p.res || p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, true, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+            if (p.temb || p.res || p.out_lo) { igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
         }
         igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     }
@@ -465,6 +527,7 @@ struct PatchRows {          // tile-local pixel -> output row
         const int b = b0 + img;
         return b < B ? (b * Ho + y0 + fy) * Wo + x0 + fx : -1;
     }
+    __device__ __forceinline__ bool all_valid() const { return b0 + ((o_base + 63) >> trw_shift) < B; }
     // the wave's 64 pixels are a quarter of a 16 x 16 patch (or a whole 8 x 8 image / a part of a small image): any bijection of the
     // (patch, quarter) pairs of an image onto [0, HoWo / 64) serves as the block index
     __device__ __forceinline__ int stat_slot(int HoWo) const {
@@ -1093,7 +1156,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     if (btab) __builtin_amdgcn_s_barrier();                                     // E2: loader wave 0 has put the tile's bias values into LDS
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
-        igemm_epilogue<false, NT, MT, NT, PatchRows, 2>(p.e, acc, rows, n_blk, lane, smem + w * 11264, btab ? smem + 4 * 11264 : nullptr);
+        igemm_epilogue<false, NT, MT, NT, PatchRows, 2, 0, true>(p.e, acc, rows, n_blk, lane, smem + w * 11264, btab ? smem + 4 * 11264 : nullptr);
     } else {
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
 #pragma unroll
@@ -1257,7 +1320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // E
-    igemm_epilogue<false, NT, MT, NT, LinearRows, 2, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264, LNM == 1 ? lnx + BMX * 8 : lnx, LNM == 1 ? lnx + wm * 64 * 8 : nullptr);
+    igemm_epilogue<false, NT, MT, NT, LinearRows, 2, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264, LNM == 1 ? lnx + BMX * 8 : lnx, LNM == 1 ? lnx + wm * 64 * 8 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1274,6 +1337,10 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 // +20..40 % time on the multi-round K <= 2560 shapes -- twice the L2 -> LDS bytes per FLOP and that path is the bound; kept for the one-round shapes only) and the 256 x 320 tile on four 512-register waves
 // with the accumulators in AGPRs (r03_ab_gemm_w4.txt: bit-identical, +10..30 % -- half the waves for a store-bound epilogue, no k-loop gain).
 // ------------------------------------------------------------------------------------------------
+// (Round 4 tried this kernel as a PERSISTENT one -- one workgroup per CU walking the tiles, stage 0 of the next tile issued in front of the current tile's epilogue:
+// bit-identical, 0 .. -4 % per launch, UNet forward unchanged (profiles/r04_ab_gemm_persist.txt), removed.  Two things ate the prologue it was meant to hide: hipcc
+// puts s_waitcnt vmcnt(0) in front of the epilogue's first LDS access while an LDS-DMA it knows of is in flight (it cannot tell the patch from the stage), and the wait
+// for the prefetched stage at the top of the next tile also waits for the epilogue's stores -- vmcnt counts loads, stores and LDS-DMA together, in issue order.)
 template <bool GEGLU, int LNM = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4;
@@ -1406,8 +1473,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     __builtin_amdgcn_s_barrier();                                               // the stage buffers become the epilogue patches
     char* const ln_tab = LNM == 1 ? lnx + BMX * 8 + wn * (2 * (BNX / 2) * 4) : lnx + wn * (BNX / 2) * 2;      // (LNM != 1: the wave's half of the bias table)
     const char* const ln_rows = LNM == 1 ? lnx + wm * 64 * 8 : nullptr;
-    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
-    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
+    if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
 }
 
 // row statistics of a [M][C] tensor (value = x + x_lo when x_lo != null): stats[M][1][2] = (sum, sum of squares) per row.  The fallback of IgemmArgs::row_stats
@@ -1822,6 +1889,7 @@ int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 or N 
 int g_tune_biggemm = 1;
 // extra dynamic LDS of the folded-LayerNorm consumer instantiations (ln_tile_prologue): 256 rows x 8 B + the (b' | s) tables
 constexpr size_t LN_LDS_W8 = 256 * 8 + 2 * 2 * 160 * 4, LN_LDS_LW = 256 * 8 + 2 * 160 * 4;
+int g_tune_epi_fast = 1;        // 1: the FAST forms of the fp32-patch epilogue (all loads of a pass in front of its phase 1) in conv3_lw / gemm_w8 / gemm_lw, 0: the generic code
 int g_tune_xcd_grid = 1;        // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
 
 // tile_of's pn for a launch of tiles_m x tiles_n tiles that reads a_bytes of activations and w_bytes of weights once each algorithmically: per-XCD L2s mean the
@@ -1901,7 +1969,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
     p.gn_stats = stats_ok ? a.gn_stats : nullptr;
-    p.gm = 1; p.pn = 0;
+    p.gm = 1; p.pn = 0; p.epi_fast = g_tune_epi_fast;
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * cin, w_bytes = 2.0 * a.N * a.taps * cin;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;

@@ -161,6 +161,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                1 (default) the resnet shortcut 1x1, 2 proj_out, 3 both, 0 none;
  *   "xcd_grid":  1 (default) weight-heavy conv / linear launches map the 8 XCDs as a 2-D grid over (row tiles, column tiles) so that each L2 streams a part
  *                of the weights instead of all of them, 0 contiguous tile runs per XCD always;
+ *   "epi_fast":  1 (default) conv / linear epilogues that add a residual (+ its lo plane) or a time embedding issue those loads ahead of their use, branch-free
+ *                (igemm_epilogue_impl FAST), 0 the generic load-where-added code; bit-identical, see profiles/r04_ab_epi_fast_*.txt;
  *   "conv_in_mfma": 1 (default) the UNet's conv_in runs on the MFMA conv kernel over latents zero-padded to 64 channels, 0 the scalar conv_in kernel;
  *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),
  *                0 LayerNorm kernel + plain GEMM;

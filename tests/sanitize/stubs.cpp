@@ -12,7 +12,7 @@
 #include <cstring>
 
 int g_tune_attn_lw = 1, g_tune_attn_prio = -1, g_tune_attn_qt40 = 4, g_tune_biggemm = 1, g_tune_conv_lw = 1, g_tune_debug = 0, g_tune_gemm2_prio = 0,
-    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1;
+    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1, g_tune_epi_fast = 1;
 
 // ---- HIP runtime -------------------------------------------------------------------------------------------------------
 extern "C" {

@@ -573,6 +573,55 @@ def test_xcd_grid_tile_order_is_a_permutation(case):
     assert torch.isfinite(grid.float()).all() and torch.equal(grid, contiguous)
 
 
+EPI_FAST_CASES = [   # (kind, rows / image side, K / Cin, N, what the epilogue adds)
+    ("linear", 131072, 320, 320, "res"), ("linear", 131072, 320, 320, "res_x2"), ("linear", 32768, 2560, 640, "res_x2"), ("linear", 8192, 1280, 1280, "res"),
+    ("linear", 8192 - 40, 1280, 1280, "res_x2"),                       # ragged M: the last row tile takes the generic code
+    ("conv", 64, 320, 320, "temb"), ("conv", 64, 320, 320, "res_x2"), ("conv", 16, 1280, 1280, "res"), ("conv", 8, 1280, 1280, "temb"),
+]
+
+
+@pytest.mark.parametrize("case", EPI_FAST_CASES)
+def test_fp32_patch_epilogue_fast_forms_are_bit_identical(case):
+    """knob epi_fast: the FAST forms of the fp32-patch epilogue (residual / residual + lo plane / time-embedding loads issued ahead of their use) perform the
+    same additions in the same order as the generic code: every output plane and the row statistics are bit-identical"""
+    kind, M, K, N, adds = case
+    if kind == "linear":
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+        rh, rl = ops.split_f16(torch.randn(M, N, device=DEV, generator=torch.Generator(DEV).manual_seed(4)) * 2)
+        if adds == "res":
+            run = lambda: ops.linear_x2(x, w, b, res=rh, want_lo=False, row_stats=True)
+        else:
+            run = lambda: ops.linear_x2(x, w, b, res=rh, res_lo=rl, want_lo=True, row_stats=True)
+    else:
+        B, H = 8, M
+        x, w, b = rnd(B, H, H, K, seed=1), ops.pack_conv_weight(rnd(N, K, 3, 3, seed=2, scale=(9 * K) ** -0.5)), rnd(N, seed=3, scale=0.1)
+        rh, rl = ops.split_f16(torch.randn(B, H, H, N, device=DEV, generator=torch.Generator(DEV).manual_seed(4)) * 2)
+        temb = rnd(B, N, seed=5)
+        if adds == "temb":
+            run = lambda: ops.conv2d(x, w, b, temb=temb, gn_stats=True)
+        elif adds == "res":
+            run = lambda: ops.conv2d(x, w, b, res=rh)
+        else:
+            run = lambda: ops.conv2d_x2(x, w, b, res=rh, res_lo=rl)
+
+    def flat(o, acc):
+        if isinstance(o, (tuple, list)):
+            for q in o:
+                flat(q, acc)
+        elif torch.is_tensor(o):
+            acc.append(o.clone())
+        return acc
+    fast = flat(run(), [])
+    ops.set_tuning("epi_fast", 0)
+    try:
+        generic = flat(run(), [])
+    finally:
+        ops.set_tuning("epi_fast", 1)
+    assert len(fast) == len(generic) and len(fast) >= 1
+    for a, g in zip(fast, generic):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, g)
+
+
 def test_conv3x3_wider_than_the_loader_wave_zero_region_falls_back():
     """conv3_lw_kernel's padded halo rows read g_zero_region + chunk offset, which covers 64 chunks; Cin = 4160 (65 chunks) must take the halo
     kernels and still pad with zeros"""
