@@ -754,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(HaloParams p) {
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
         __syncthreads();                           // group B's last reads are consumed; the stage buffers become the epilogue patches
-        igemm_epilogue<false, NT, MT, NT, PatchRows, KH>(p.e, acc, rows, n_blk + wn * (BN / 2), lane, smem + w * 11264);
+        igemm_epilogue<false, NT, MT, NT, PatchRows, KH>(p.e, acc, rows, n_blk + wn * (BN / 2), lane, smem + w * 11264);      // (no FAST forms: the BN = 320 instantiation spills already)
     } else {
         // split-K: raw fp32 partial sums, 16-byte stores (4 consecutive channels per lane)
         float* dst = p.partial + (size_t)blockIdx.y * p.e.M * p.e.N;
@@ -1854,6 +1854,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         }
         return;
     }
+    // (no FAST forms of the fp32-patch epilogue here: their registers cost this kernel a wave of occupancy per SIMD, 4 -> 3 / 3 -> 2)
     igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264, LNM == 1 ? smem + 4 * 11264 + w * 1280 : nullptr);
 }
 
