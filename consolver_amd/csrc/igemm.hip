@@ -82,6 +82,27 @@ __device__ __forceinline__ void trace_stamp(int debug, int slot, int which) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// (sum, sum of squares) of one row from its G partial pairs st[G][2], added in group order.  The pairs of a row are contiguous: G = 2 / 4 / 8 (C = 320 / 640 /
+// 1280 behind 160-column wave tiles) come in as one / two / four 16-byte loads issued together.  As a loop of 8-byte loads hipcc waits for each load before it
+// issues the next (load, s_waitcnt vmcnt(0), add): G memory round trips one behind the other in front of the tile's first barrier, 4 us at G = 8.
+__device__ __forceinline__ void ln_row_moments(const float* __restrict__ st, int G, float& s1, float& s2) {
+    s1 = 0.f; s2 = 0.f;
+    if (G == 8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st), b = *reinterpret_cast<const f32x4*>(st + 4), c = *reinterpret_cast<const f32x4*>(st + 8),
+                    d = *reinterpret_cast<const f32x4*>(st + 12);
+        s1 += a[0]; s2 += a[1]; s1 += a[2]; s2 += a[3]; s1 += b[0]; s2 += b[1]; s1 += b[2]; s2 += b[3];
+        s1 += c[0]; s2 += c[1]; s1 += c[2]; s2 += c[3]; s1 += d[0]; s2 += d[1]; s1 += d[2]; s2 += d[3];
+    } else if (G == 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st), b = *reinterpret_cast<const f32x4*>(st + 4);
+        s1 += a[0]; s2 += a[1]; s1 += a[2]; s2 += a[3]; s1 += b[0]; s2 += b[1]; s1 += b[2]; s2 += b[3];
+    } else if (G == 2) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st);
+        s1 += a[0]; s2 += a[1]; s1 += a[2]; s2 += a[3];
+    } else {
+        for (int g = 0; g < G; ++g) { const f32x2 v = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += v[0]; s2 += v[1]; }
+    }
+}
+
 // Folded-LayerNorm consumer, tile prologue (gemm_w8_kernel / gemm_lw_kernel, LNM == 1): everything the epilogue needs from global memory is fetched into a
 // spare LDS region WHILE THE K LOOP RUNS -- per tile row (rstd, mean rstd) from the producer's partial sums, per weight row b' and s -- so that the epilogue
 // itself issues no loads.  (With the loads in the epilogue the QKV GEMMs, which otherwise load nothing there, paid +4.7 us per tile: a dependent global load
@@ -90,8 +111,8 @@ __device__ __forceinline__ void ln_tile_prologue(const IgemmParams& p, char* lnx
     for (int r = t; r < rows; r += nthreads) {
         const int m = min(m_blk + r, p.M - 1);
         const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
-        float s1 = 0.f, s2 = 0.f;
-        for (int g = 0; g < p.ln_groups; ++g) { const f32x2 v = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += v[0]; s2 += v[1]; }
+        float s1, s2;
+        ln_row_moments(st, p.ln_groups, s1, s2);
         const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps);
         *reinterpret_cast<f32x2*>(lnx + r * 8) = f32x2{rstd, mean * rstd};
     }
@@ -238,7 +259,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             float s1 = 0.f, s2 = 0.f;
             if (m >= 0) {
                 const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
-                for (int g = 0; g < p.ln_groups; ++g) { const f32x2 t = *reinterpret_cast<const f32x2*>(st + 2 * g); s1 += t[0]; s2 += t[1]; }
+                ln_row_moments(st, p.ln_groups, s1, s2);
             }
             const float mean = s1 * p.ln_inv_c;
             ln_r[j] = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps);
@@ -1510,7 +1531,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const
         if (p.ln_stats) {                                      // LayerNorm folded into this GEMM (see igemm_epilogue_impl)
             float s1 = 0.f, s2 = 0.f;
             const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
-            for (int g = 0; g < p.ln_groups; ++g) { s1 += st[2 * g]; s2 += st[2 * g + 1]; }
+            ln_row_moments(st, p.ln_groups, s1, s2);
             const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps), mr = mean * rstd;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], rstd, __builtin_fmaf(-mr, p.ln_s[n + k], p.ln_b[n + k]));

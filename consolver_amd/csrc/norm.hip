@@ -91,12 +91,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     extern __shared__ __attribute__((aligned(16))) float ss[];    // [Ctot][2]
     const int Ctot = c0 + c1, CV = Ctot >> 3;
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * Ctot; i += blockDim.x) ss[i] = scale_shift[(size_t)b * Ctot * 2 + i];
+    {   // the sample's (scale, shift) table -> LDS: 16-byte loads, four per lane issued together (clamped index, branch-free).  As a loop of 4-byte loads this was
+        // load, s_waitcnt vmcnt(0), ds_write per element: 2 Ctot / 256 memory round trips one behind the other in front of the barrier (20 at Ctot = 2560)
+        const f32x4* src = reinterpret_cast<const f32x4*>(scale_shift + (size_t)b * Ctot * 2);
+        const int nv = Ctot >> 1;                                      // (Ctot is a multiple of 8)
+        for (int i0 = threadIdx.x; i0 < nv; i0 += 4 * (int)blockDim.x) {
+            f32x4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * (int)blockDim.x; t[u] = src[i < nv ? i : nv - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * (int)blockDim.x; if (i < nv) reinterpret_cast<f32x4*>(ss)[i] = t[u]; }
+        }
+    }
     __syncthreads();
     const int rows_per_blk = (HW + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_blk;
     const int r1 = min(HW, r0 + rows_per_blk);
     const int nvec = (r1 - r0) * CV;
+    // (Round 4 tried the batches software-pipelined -- batch n + 1 loaded in front of batch n's stores, the first batch in front of the table's barrier: 124 VGPRs
+    //  instead of 60, half the waves per SIMD, GroupNorm class 1.86 -> 2.21 ms per forward (profiles/r04_ab_gn_pipeline_unet.txt).  Occupancy hides this kernel's latency.)
     for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * (int)blockDim.x) {      // four independent 16-byte loads in flight per lane
         f16x8 v[4], vl[4]; int cc[4]; size_t oo[4];
 #pragma unroll
