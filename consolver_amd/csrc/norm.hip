@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     const int r1 = min(HW, r0 + rows_per_blk);
     const int nvec = (r1 - r0) * CV;
     // (Round 4 tried the batches software-pipelined -- batch n + 1 loaded in front of batch n's stores, the first batch in front of the table's barrier: 124 VGPRs
-    //  instead of 60, half the waves per SIMD, GroupNorm class 1.86 -> 2.21 ms per forward (profiles/r04_ab_gn_pipeline_unet.txt).  Occupancy hides this kernel's latency.)
+    //  instead of 58-82, 4 waves per SIMD instead of 5-8, GroupNorm class 1.86 -> 2.21 ms per forward (profiles/r04_ab_gn_pipeline_unet.txt).  Occupancy hides this kernel's latency.)
     for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * (int)blockDim.x) {      // four independent 16-byte loads in flight per lane
         f16x8 v[4], vl[4]; int cc[4]; size_t oo[4];
 #pragma unroll
