@@ -185,6 +185,25 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     q = q * u + 3.989399076e-01f;
     return x * (xc * q + 0.5f);
 }
+// Two pairs at once, their Horner chains interleaved statement by statement: one chain alone is a string of DEPENDENT v_pk_fma_f32, and hipcc put an s_nop between
+// every two of them (240 s_nop per wave in the GEGLU epilogue); with a second chain in between the dependent distance is two instructions and the nops go away.
+__device__ __forceinline__ void gelu_erf4(f32x2 xa, f32x2 xb, f32x2& ga, f32x2& gb) {
+    f32x2 ca, cb;
+    ca[0] = __builtin_amdgcn_fmed3f(xa[0], -4.5f, 4.5f); ca[1] = __builtin_amdgcn_fmed3f(xa[1], -4.5f, 4.5f);
+    cb[0] = __builtin_amdgcn_fmed3f(xb[0], -4.5f, 4.5f); cb[1] = __builtin_amdgcn_fmed3f(xb[1], -4.5f, 4.5f);
+    const f32x2 ua = ca * ca, ub = cb * cb;
+    f32x2 qa = f32x2{-2.092490677e-12f, -2.092490677e-12f}, qb = qa;
+    qa = qa * ua + 2.374692942e-10f;  qb = qb * ub + 2.374692942e-10f;
+    qa = qa * ua + -1.199396227e-08f; qb = qb * ub + -1.199396227e-08f;
+    qa = qa * ua + 3.595010583e-07f;  qb = qb * ub + 3.595010583e-07f;
+    qa = qa * ua + -7.229871699e-06f; qb = qb * ub + -7.229871699e-06f;
+    qa = qa * ua + 1.050455248e-04f;  qb = qb * ub + 1.050455248e-04f;
+    qa = qa * ua + -1.158194733e-03f; qb = qb * ub + -1.158194733e-03f;
+    qa = qa * ua + 9.930972010e-03f;  qb = qb * ub + 9.930972010e-03f;
+    qa = qa * ua + -6.646580249e-02f; qb = qb * ub + -6.646580249e-02f;
+    qa = qa * ua + 3.989399076e-01f;  qb = qb * ub + 3.989399076e-01f;
+    ga = xa * (ca * qa + 0.5f); gb = xb * (cb * qb + 0.5f);
+}
 
 
 // Epilogue.  After the MFMAs a lane holds, per (nt, mt) tile, pixel m = ..+(lane&15) and channels
@@ -353,7 +372,8 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
                             for (int r = 0; r < 4; ++r) gt[r] = ga[r] + bg[r];
                         }
-                        const f32x2 g01 = gelu_erf2(f32x2{gt[0], gt[1]}), g23 = gelu_erf2(f32x2{gt[2], gt[3]});
+                        f32x2 g01, g23;
+                        gelu_erf4(f32x2{gt[0], gt[1]}, f32x2{gt[2], gt[3]}, g01, g23);
                         o[0] = (f16)(val[0] * g01[0]); o[1] = (f16)(val[1] * g01[1]);
                         o[2] = (f16)(val[2] * g23[0]); o[3] = (f16)(val[3] * g23[1]);
                     } else {
