@@ -236,7 +236,7 @@ struct LinearRows {
 // wave's 20 iterations waited a full memory round trip (two with a lo plane) plus the acknowledgement of its predecessor's stores: 28 us of the 71 us a
 // 256 x 320 x 1280 tile took, 43 us in f16x2 mode (from the ISA: tools/README.md, round 4).  Here a pass issues ALL its loads in one go, branch-free, so that
 // the compiler's own counted waits work: one round trip per pass.
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM, int FAST = 0>
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM, int FAST = 0, bool LTAB = false>
 __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
@@ -333,12 +333,21 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                     for (int r = 0; r < 4; ++r) { bg[r] = t2[r]; sg[r] = u2[r]; }
                 }
             } else if (p.bias) {
-                // (ln_tab, when the kernel has one: the wave's bias values in LDS, fetched by bias_tile_prologue under the k loop)
-                const f16x4 t = ln_tab ? *reinterpret_cast<const f16x4*>(ln_tab + (i * 16 + g4) * 2) : *reinterpret_cast<const f16x4*>(p.bias + n);
+                // LTAB (a template parameter: gemm_w8 / gemm_lw / conv3_lw): the wave's bias values are in LDS (ln_tab), fetched under the k loop.  NOT a runtime
+                // `ln_tab ? *lds : *global`: hipcc turns a select of pointers into flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) -- 180 of them per kernel, one in front
+                // of every phase-1 LDS write, each also waiting for the previous pass's global stores to be acknowledged (it merges an if / else into the same).
+                f16x4 t, u = {0, 0, 0, 0};
+                if constexpr (LTAB) {
+                    const __attribute__((address_space(3))) char* lt = (const __attribute__((address_space(3))) char*)ln_tab;
+                    t = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + (i * 16 + g4) * 2);
+                    if (GEGLU) u = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + (i * 16 + g4 + 16) * 2);
+                } else {
+                    t = *reinterpret_cast<const f16x4*>(p.bias + n);
+                    if (GEGLU) u = *reinterpret_cast<const f16x4*>(p.bias + n + 16);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[r] = (float)t[r];
                 if (GEGLU) {
-                    const f16x4 u = ln_tab ? *reinterpret_cast<const f16x4*>(ln_tab + (i * 16 + g4 + 16) * 2) : *reinterpret_cast<const f16x4*>(p.bias + n + 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) bg[r] = (float)u[r];
                 }
@@ -500,25 +509,26 @@ __device__ __forceinline__ void igemm_epilogue_f32(const IgemmParams& p, f32x4 (
     if constexpr (EFAST) {
         if (g_epi_fast_on(p) && rows.all_valid()) {
             if (p.res && !p.temb) {
-                if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
-                if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
-            } else if (p.temb && !p.res && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 3>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+                if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+                if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+            } else if (p.temb && !p.res && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 3, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
         }
     }
-    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
 }
 
+// EFAST: the kernel (gemm_w8 / gemm_lw / conv3_lw) hands its bias through an LDS table (LTAB) and wants the FAST forms of the fp32-patch path compiled
 template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0, bool EFAST = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab = nullptr, const char* ln_rows = nullptr) {
     if constexpr (LNM == 2) {                           // row statistics come from the fp32 values: always the fp32-patch path
         igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else if constexpr (LNM == 1) {                    // a folded LayerNorm's consumer adds nothing after the product (launch_igemm_impl checks)
-        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 1, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else {
         if constexpr (!GEGLU) {
             if (p.temb || p.res || p.out_lo) { igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
         }
-        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 0>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 0, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     }
 }
 
