@@ -257,14 +257,14 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     // value = rstd (acc - mean s[n]) + b'[n] = acc rstd + (b'[n] - (mean rstd) s[n]); the lane's MT rows are patch rows 16 j + (lane & 15)
     constexpr bool lnf = LNM == 1 && std::is_same<RowMap, LinearRows>::value;
     float ln_r[MT], ln_mr[MT];
-    if (lnf && ln_rows) {
+    if constexpr (lnf && LTAB) {
         // the tile prologue (ln_tile_prologue) left (rstd, mean rstd) of the wave's rows and the b' / s table in LDS: no global load here
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const f32x2 t = *reinterpret_cast<const f32x2*>(ln_rows + (j * 16 + i16) * 8);
             ln_r[j] = t[0]; ln_mr[j] = t[1];
         }
-    } else if (lnf) {
+    } else if constexpr (lnf) {
         // (the generic tile, small shapes:) b' and s of the wave's NT * 16 weight rows through a wave-private LDS table (ln_tab, [2][NT * 16] floats), one round of
         // global loads together with the row statistics
         constexpr int WC = NT * 16;
@@ -315,6 +315,18 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
     for (int rh = 0; rh < RSPLIT; ++rh) {
         // ---- phase 1: registers -> LDS patch [RT * 16 rows][COLS] fp16 (F32: fp32) --------------------------
+        // LTAB: the bias values of the NEXT 16 columns are read from the LDS table while this step's are used (one wave per SIMD runs the epilogues of conv3_lw /
+        // gemm_lw: nothing else hides an LDS round trip there; all of a pass's values at once cost 20 registers and spilled)
+        constexpr int BSTEP = GEGLU ? 2 : 1;
+        f16x4 bt_t = {0, 0, 0, 0}, bt_u = {0, 0, 0, 0};
+        auto bias_read = [&](int ii2, f16x4& t2, f16x4& u2) {
+            if constexpr (LTAB && !lnf) {
+                const __attribute__((address_space(3))) char* lt = (const __attribute__((address_space(3))) char*)ln_tab;
+                t2 = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + ((grp * GROUP + ii2) * 16 + g4) * 2);
+                if (GEGLU) u2 = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + ((grp * GROUP + ii2) * 16 + g4 + 16) * 2);
+            }
+        };
+        if constexpr (LTAB && !lnf) { if (p.bias) bias_read(0, bt_t, bt_u); }
 #pragma unroll
         for (int ii = 0; ii < GROUP; ii += (GEGLU ? 2 : 1)) {
             const int i = grp * GROUP + ii;
@@ -338,9 +350,8 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                 // of every phase-1 LDS write, each also waiting for the previous pass's global stores to be acknowledged (it merges an if / else into the same).
                 f16x4 t, u = {0, 0, 0, 0};
                 if constexpr (LTAB) {
-                    const __attribute__((address_space(3))) char* lt = (const __attribute__((address_space(3))) char*)ln_tab;
-                    t = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + (i * 16 + g4) * 2);
-                    if (GEGLU) u = *reinterpret_cast<const __attribute__((address_space(3))) f16x4*>(lt + (i * 16 + g4 + 16) * 2);
+                    t = bt_t; u = bt_u;
+                    if (ii + BSTEP < GROUP) bias_read(ii + BSTEP, bt_t, bt_u);
                 } else {
                     t = *reinterpret_cast<const f16x4*>(p.bias + n);
                     if (GEGLU) u = *reinterpret_cast<const f16x4*>(p.bias + n + 16);
