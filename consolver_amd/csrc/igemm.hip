@@ -327,6 +327,21 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             }
         };
         if constexpr (LTAB && !lnf) { if (p.bias) bias_read(0, bt_t, bt_u); }
+        f32x4 ln_t = {0.f, 0.f, 0.f, 0.f}, ln_u = ln_t, ln_t2 = ln_t, ln_u2 = ln_t;
+        auto ln_read = [&](int ii2) {
+            if constexpr (LTAB && lnf) {
+                constexpr int WC = NT * 16;
+                const __attribute__((address_space(3))) char* lt = (const __attribute__((address_space(3))) char*)ln_tab;
+                const int c = (grp * GROUP + ii2) * 16 + g4;
+                ln_t = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lt + c * 4);
+                ln_u = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lt + (WC + c) * 4);
+                if (GEGLU) {
+                    ln_t2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lt + (c + 16) * 4);
+                    ln_u2 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(lt + (WC + c + 16) * 4);
+                }
+            }
+        };
+        if constexpr (LTAB && lnf) ln_read(0);
 #pragma unroll
         for (int ii = 0; ii < GROUP; ii += (GEGLU ? 2 : 1)) {
             const int i = grp * GROUP + ii;
@@ -334,13 +349,19 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             float bv[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
             float sv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
             if (lnf) {                                          // folded LayerNorm: b' (fp32, holds the layer's own bias) and s = row sums of the folded weight
-                constexpr int WC = NT * 16;
-                const int c = i * 16 + g4;
-                const f32x4 t = *reinterpret_cast<const f32x4*>(ln_tab + c * 4), u = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c) * 4);
+                f32x4 t, u, t2 = {0.f, 0.f, 0.f, 0.f}, u2 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (LTAB) {                           // (read one step ahead, like the bias values below)
+                    t = ln_t; u = ln_u; t2 = ln_t2; u2 = ln_u2;
+                    if (ii + BSTEP < GROUP) ln_read(ii + BSTEP);
+                } else {
+                    constexpr int WC = NT * 16;
+                    const int c = i * 16 + g4;
+                    t = *reinterpret_cast<const f32x4*>(ln_tab + c * 4); u = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c) * 4);
+                    if (GEGLU) { t2 = *reinterpret_cast<const f32x4*>(ln_tab + (c + 16) * 4); u2 = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c + 16) * 4); }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { bv[r] = t[r]; sv[r] = u[r]; }
                 if (GEGLU) {
-                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(ln_tab + (c + 16) * 4), u2 = *reinterpret_cast<const f32x4*>(ln_tab + (WC + c + 16) * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { bg[r] = t2[r]; sg[r] = u2[r]; }
                 }
