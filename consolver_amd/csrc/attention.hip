@@ -118,21 +118,33 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     for (int o = tid * 16; o < 2 * KBUF + 2 * VBUF; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
 
     // ---- Q fragments (B operand: lane = query column i16, k = 8g + j) ---------------------------
+    // (all QT * KSTEPS loads issued together, branch-free: rows / head dims past the end read a clamped address and are zeroed afterwards.  Under
+    //  `if (qrow < p.Nq && d < DH)` every load came out as load, s_waitcnt vmcnt(0), convert: 5-8 memory round trips one behind the other per workgroup)
     frag qf[QT][KSTEPS];
+    {
+        u32x4 raw[QT][KSTEPS];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        const int qrow = q0 + t * 16 + i16;
+        for (int t = 0; t < QT; ++t) {
+            const int qrow = q0 + t * 16 + i16, qr = qrow < p.Nq ? qrow : p.Nq - 1;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int d = ks * 32 + 8 * g;
-            u32x4 v = {0, 0, 0, 0};
-            if (qrow < p.Nq && d < DH) {
-                v = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qrow) * p.q_stride + h * DH + d));
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int d = ks * 32 + 8 * g, dc = d < DH ? d : 0;
+                raw[t][ks] = *reinterpret_cast<const u32x4*>(p.q + ((size_t)(b * p.Nq + qr) * p.q_stride + h * DH + dc));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int qrow = q0 + t * 16 + i16;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                const int d = ks * 32 + 8 * g;
+                const bool ok = qrow < p.Nq && d < DH;
+                u32x4 v = raw[t][ks];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)      // fold scale*log2(e) into Q
-                    v[e] = pack2<T>(El<T>::tof((u16)(v[e] & 0xffff)) * p.c, El<T>::tof((u16)(v[e] >> 16)) * p.c);
+                    v[e] = ok ? pack2<T>(El<T>::tof((u16)(v[e] & 0xffff)) * p.c, El<T>::tof((u16)(v[e] >> 16)) * p.c) : 0u;
+                qf[t][ks] = as_frag<T>(v);
             }
-            qf[t][ks] = as_frag<T>(v);
         }
     }
 
