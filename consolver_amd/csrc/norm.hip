@@ -3,6 +3,12 @@
 // wave-shuffle + LDS, deterministic (no atomics).
 #include "ops.h"
 
+// 16-byte vectors per thread of gn_apply_kernel: 4 = exactly one batch of four loads per lane.  Same-box A/B of the UNet forward (f16x2): 32 -> 29.73 ms, 16 -> 29.54,
+// 8 -> 29.52 / 30.60 (two boxes), 4 -> 30.45, 2 -> 30.42: the more workgroups, the better -- and a second batch's loads would queue behind the first batch's stores.
+#ifndef GN_VPT
+#define GN_VPT 4
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------------------- GroupNorm
@@ -249,7 +255,7 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
     if (!a.c1) { p1 = p0; S1 = 0; }
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s,
                        p0, S0, a.c0, p1, S1, a.c1, a.groups, a.HW, a.eps, a.gamma, a.beta, scale_shift);
-    int chunks = (a.HW * (Ctot / 8) + 256 * 8 - 1) / (256 * 8);      // ~8 vectors per thread
+    int chunks = (a.HW * (Ctot / 8) + 256 * GN_VPT - 1) / (256 * GN_VPT);      // ~GN_VPT vectors per thread
     if (chunks < 1) chunks = 1;
     if (chunks > a.HW) chunks = a.HW;
     const size_t lds = (size_t)2 * Ctot * sizeof(float);
