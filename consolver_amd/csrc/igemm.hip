@@ -63,7 +63,6 @@ struct IgemmParams {
     int pn;             // tile_of: 0 = contiguous run of tiles per XCD, > 0 = the XCDs as an (8 / pn) x pn grid over (row tiles, column tiles)
     int epi_fast;       // knob epi_fast: the FAST forms of the fp32-patch epilogue (igemm_epilogue_f32)
 };
-__device__ __forceinline__ bool g_epi_fast_on(const IgemmParams& p) { return p.epi_fast != 0; }
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
 #define CS_TRACE_SLOTS 8192
@@ -168,24 +167,7 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
 // product that follows.  Two values per call so that the Horner chain is v_pk_fma_f32: ~7 VALU issue slots per value and no
 // transcendental, against ~22 for the rcp + exp form (A&S 7.1.26) it replaces: the GEGLU epilogue evaluates this 168 M
 // times per L0 layer and was VALU-bound.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    f32x2 xc;
-    xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f);
-    xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f);
-    const f32x2 u = xc * xc;
-    f32x2 q = f32x2{-2.092490677e-12f, -2.092490677e-12f};
-    q = q * u + 2.374692942e-10f;
-    q = q * u + -1.199396227e-08f;
-    q = q * u + 3.595010583e-07f;
-    q = q * u + -7.229871699e-06f;
-    q = q * u + 1.050455248e-04f;
-    q = q * u + -1.158194733e-03f;
-    q = q * u + 9.930972010e-03f;
-    q = q * u + -6.646580249e-02f;
-    q = q * u + 3.989399076e-01f;
-    return x * (xc * q + 0.5f);
-}
-// Two pairs at once, their Horner chains interleaved statement by statement: one chain alone is a string of DEPENDENT v_pk_fma_f32, and hipcc put an s_nop between
+// Two pairs per call, their Horner chains interleaved statement by statement: one chain alone is a string of DEPENDENT v_pk_fma_f32, and hipcc put an s_nop between
 // every two of them (240 s_nop per wave in the GEGLU epilogue); with a second chain in between the dependent distance is two instructions and the nops go away.
 __device__ __forceinline__ void gelu_erf4(f32x2 xa, f32x2 xb, f32x2& ga, f32x2& gb) {
     f32x2 ca, cb;
@@ -539,7 +521,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RS2, int LNM, bool EFAST>
 __device__ __forceinline__ void igemm_epilogue_f32(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
     if constexpr (EFAST) {
-        if (g_epi_fast_on(p) && rows.all_valid()) {
+        if (p.epi_fast != 0 && rows.all_valid()) {
             if (p.res && !p.temb) {
                 if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
                 if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
