@@ -48,7 +48,9 @@ def cpu_baseline(sd, cfg, steps_total=8, guidance=3.0, budget_s=40.0, vae_sd=Non
     from oracle.unet_oracle import UNetOracle
     from oracle import solver_oracle as so
     from consolver_amd.synth import synthetic_prompt_embeds
-    cores = usable_cores()
+    # at most 16 threads: the same reduction order on every box of the pool with >= 16 usable cores (the fp32 oracle's own rounding noise, amplified over 8
+    # free-running steps, moved `parity` by ~1 % between boxes in round 4)
+    cores = min(usable_cores(), 16)
     torch.set_num_threads(cores)
     # weights rounded to fp16 once, arithmetic fp32: the reference pipeline's weights ARE fp16 (gen_ppo.py:193-195), and with them the latents this
     # leg produces are the fp32 reference the HIP engine's latents are gated against (`parity` in the JSON line).  Same CPU time either way.
@@ -103,7 +105,10 @@ def parity_vs_oracle(unet, replay, guidance, dev, modes):
     import numpy as np
     n_done, n = replay["steps_done"], replay["steps_total"]
     out = {"gate": 1e-3, "config": f"configs[0] inputs (1 prompt, CFG 3, replayed action indices), {n_done} of {n} solver steps, "
-                                   "fp16 HIP engine vs the fp32 CPU oracle (relative L2 of the latents)"}
+                                   "fp16 HIP engine vs the fp32 CPU oracle (relative L2 of the latents)",
+           "reference": "oracle/unet_oracle.py + oracle/solver_oracle.py in fp32 on the host, weights rounded to fp16 ONCE (the reference pipeline's weights are "
+                        "fp16, gen_ppo.py:193-195), fp16-representable noise / prompt embeddings, conds in fp16 as scheduler_ppo.py:207 produces them; "
+                        "<= 16 oracle threads (reduction order pinned)"}
     want = torch.from_numpy(replay["latents"]).double()
     keep = unet.residual
     for mode in modes:
@@ -331,10 +336,11 @@ def dry_run(args):
     # the same per-rank record main() gathers over RCCL (rank, local rank, device stand-in, images, elapsed, shard, checksum stand-in)
     from consolver_amd.launch import gather_rank_records
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    rows = gather_rank_records(dist, [rank, local, local, B * args.steps, 0.001 * (rank + 1), lo, hi, float(lo + hi)])
+    import socket, zlib
+    rows = gather_rank_records(dist, [rank, local, local, B * args.steps, 0.001 * (rank + 1), lo, hi, float(lo + hi), float(zlib.crc32(socket.gethostname().encode()))])
     assert len(rows) == world
     per_rank = [{"rank": int(r[0]), "local_rank": int(r[1]), "device": int(r[2]), "images": int(r[3]), "elapsed_s": r[4],
-                 "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7]} for r in rows]
+                 "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7], "host_id": int(r[8])} for r in rows]
     # what main() runs OUTSIDE the timed region on this launch: the cpu_baseline leg and the sub-record extras are N = 1 only (same conditions as in
     # main()), so an 8-GPU timed region and its barriers see nothing but the sampling loop
     side_work = {"cpu_baseline": world == 1 and not args.no_cpu_baseline, "extras": world == 1 and bool(args.extras),
@@ -342,6 +348,7 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
                           "images": B * world * args.steps, "max_elapsed_s": elapsed, "shards": bounds, "per_rank": per_rank,
+                          "per_rank_distinct_devices": len({(p["host_id"], p["device"]) for p in per_rank}),
                           "local_rank_env": os.environ.get("LOCAL_RANK"), "cuda_initialised": torch.cuda.is_initialized(),
                           "side_work_after_timed_region": side_work}))
     if dist is not None:
@@ -408,7 +415,10 @@ def main():
     headline_mode = "f16x2" if args.residual in ("f16x2", "residual_fp32") else "f16"
     other_mode = "f16" if headline_mode == "f16x2" else "f16x2"
     unet = HipUNet2DConditionModel(device=dev, residual=headline_mode)
-    sd = synthetic_unet_state_dict(unet.manifest(), seed=20251226)
+    # seeded synthetic weights generated ON THIS RANK'S GPU (860 M values: every rank of an 8-GPU launch synthesising them on the shared host cores was the
+    # start-up cost of the N > 1 run); same seed on every rank -> identical weights, and the host copies below are what the CPU oracle legs read
+    sd = synthetic_unet_state_dict(unet.manifest(), seed=20251226, device=dev)
+    sd = {k: v.cpu() for k, v in sd.items()}
     unet.load_state_dict(sd)
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                                      timestep_spacing="trailing", order_dim=4, scaler_dim=0,
@@ -463,13 +473,17 @@ def main():
     per_rank = None
     if dist is not None:
         from consolver_amd.launch import gather_rank_records
+        import socket, zlib
+        host_id = float(zlib.crc32(socket.gethostname().encode()))       # (exact in a double; the local device index alone repeats across nodes)
         mine = [float(rank), float(local), float(torch.cuda.current_device()), float(B * args.steps), float(elapsed_local), float(lo), float(hi),
-                float(out.float().abs().sum().item())]
+                float(out.float().abs().sum().item()), host_id]
         rows = gather_rank_records(dist, mine, dev)
         assert len(rows) == world, (len(rows), world)
         per_rank = [{"rank": int(r[0]), "local_rank": int(r[1]), "device": int(r[2]), "images": int(r[3]), "elapsed_s": r[4],
-                     "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7]} for r in rows]
-        assert sorted(p["rank"] for p in per_rank) == list(range(world)) and len({p["device"] for p in per_rank}) == world, per_rank
+                     "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7], "host_id": int(r[8])} for r in rows]
+        assert sorted(p["rank"] for p in per_rank) == list(range(world)), per_rank
+        # one rank per (host, device): recorded, not asserted -- a launch with two ranks per GPU is legal and must still print its line
+        distinct = len({(p["host_id"], p["device"]) for p in per_rank})
 
     # ---- roofline of the dominant unit: the UNet forward (MFMA bound), HIP events on the launch stream -------
     eff_batch = 2 * B if args.guidance > 1 else B
@@ -547,15 +561,32 @@ def main():
                      "the stream, meets the 1e-3 latent gate; f16 = one plane, the reference fp16 pipeline's own arithmetic class, 1.4e-3.  GEMM operands are "
                      "fp16 in both.")
 
-    kernels = None
-    if args.profile_kernels and rank == 0:
+    # per-kernel-class HIP-event profile of one forward, in BOTH residual-stream modes (N = 1): what the lo planes cost per class is visible on the driver's box.
+    # The executor's byte model of the `f16` mode (one fp16 plane per tensor) is the reference graph's ALGORITHMIC traffic: `traffic_ratio` below is quoted on it,
+    # whatever mode the headline runs in (the lo planes are a representation cost, not algorithmic work).
+    kernels, kernels_other, algo_bytes_one_plane = None, None, None
+
+    def _profile_pass():
         unet.set_profiling(True)
         unet(noise, torch.tensor([499.0], device=dev), encoder_hidden_states=torch.cat([ne, pe]), dup=2, reuse_kv=False)
         prof = unet.profile()
         unet.set_profiling(False)
-        kernels = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
-                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
-                       "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None} for k, v in prof.items()}
+        return ({k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None,
+                     "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None} for k, v in prof.items()},
+                sum(v["bytes"] for v in prof.values()))
+    if args.profile_kernels and rank == 0:
+        kernels, b_head = _profile_pass()
+        if headline_mode == "f16":
+            algo_bytes_one_plane = b_head
+        if world == 1 and not args.graph:
+            unet.set_residual_precision(other_mode)
+            kernels_other, b_other = _profile_pass()
+            if other_mode == "f16":
+                algo_bytes_one_plane = b_other
+            unet.set_residual_precision(headline_mode)
+            one(); torch.cuda.synchronize()
+    roofline["traffic_algorithmic_one_plane"] = algo_bytes_one_plane
 
     # ---- same-run measured ceilings (makes the fraction of the spec-sheet peak auditable): what the vendor GEMM library and a
     # plain device copy reach on THIS box, on random data.  Reference points only - nothing on the product path uses hipBLASLt or torch math.
@@ -613,12 +644,18 @@ def main():
         }
         if per_rank is not None:
             rec["per_rank"] = per_rank
+            rec["per_rank_distinct_devices"] = distinct
         if decode_ms is not None:
             rec["pixel_images_per_s"] = images / pixel_elapsed          # latents + AutoencoderKL decode (row f-1), own timed loop
             rec["vae_decode"] = {"ms_per_batch": decode_ms, "tflops": vae.flops(B) / (decode_ms * 1e-3) / 1e12,
                                  "frac_of_mfma_peak": vae.flops(B) / (decode_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS}
         if kernels:
             rec["roofline_kernels"] = kernels
+        if kernels_other:
+            rec["roofline_kernels_" + other_mode] = kernels_other
+        if roofline.get("traffic") and roofline.get("traffic_algorithmic_one_plane"):
+            # measured HBM-side bytes of the headline mode over the reference graph's algorithmic bytes (one fp16 plane per tensor): lo planes count as excess
+            roofline["traffic_ratio"] = roofline["traffic"] / roofline["traffic_algorithmic_one_plane"]
         if extras:
             rec.update({k: v for k, v in extras.items() if v is not None})
         if ceilings:
@@ -632,6 +669,7 @@ def main():
                 par = parity_vs_oracle(unet, replay, args.guidance, dev, [headline_mode, other_mode])
                 par["latent_rel_l2"] = par[headline_mode]
                 par["gate_met"] = bool(par[headline_mode] <= par["gate"])
+                par["margin"] = 1.0 - par[headline_mode] / par["gate"]          # fraction of the gate left (negative: not met)
                 rec["parity"] = par
             except Exception as e:
                 rec["parity"] = {"error": f"{type(e).__name__}: {e}"}

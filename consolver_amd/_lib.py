@@ -220,7 +220,11 @@ def lib():
     if l.cs_abi_version() != 2:
         raise RuntimeError("libconsolver_hip.so ABI version mismatch")
     _lib = l
-    apply_env_tuning()
+    try:
+        apply_env_tuning()
+    except Exception:
+        _lib = None          # a malformed CS_TUNE raises on EVERY call, not only the first (the library must not come up with the remaining knobs silently unapplied)
+        raise
     return l
 
 

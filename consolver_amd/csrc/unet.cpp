@@ -104,10 +104,10 @@ struct Arena {
     }
 };
 
-// A residual-stream tensor.  CS_RESIDUAL_F16 (default): one fp16 plane, lo == nullptr.  CS_RESIDUAL_F16X2: value = hi + lo, two fp16 planes
+// A residual-stream tensor.  CS_RESIDUAL_F16: one fp16 plane, lo == nullptr.  CS_RESIDUAL_F16X2 (the default): value = hi + lo, two fp16 planes
 // (22 significant bits): the epilogues that add onto the stream take hi + lo in fp32 and store both planes (IgemmArgs::res_lo / out_lo), the norms
 // read hi + lo, and a GEMM that consumes the stream directly (shortcut 1x1, down / upsample conv, proj_out) reads the hi plane -- which is exactly
-// the fp16 tensor of the default mode, so no kernel's operand path changes.
+// the fp16 tensor of the one-plane mode, so no kernel's operand path changes.
 struct St {
     f16* hi = nullptr; f16* lo = nullptr;
     St() {}
@@ -342,6 +342,7 @@ struct Run {
     int v_split_a = 1;             // snapshot of g_tune_x2_split_a
     int v_ln_fold = 1;             // snapshot of g_tune_ln_fold
     int v_conv_in_mfma = 1;        // snapshot of g_tune_conv_in_mfma
+    bool count_executed = false;   // dry run behind cs_unet_flops_executed: count what is ISSUED (padding included), not the reference graph's FLOPs
     // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
     float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
 
@@ -389,7 +390,7 @@ struct Run {
     // stats_into: write them into this (larger) buffer instead of a fresh one, nothing registered (two launches filling one tensor).
     void conv(const Conv& c, const f16* a0, int c0, const f16* a1, int c1, int Hi, int Wi, int Ho, int Wo, int stride, int up,
               const f16* temb, St res, St out, bool want_stats = false, float* stats_into = nullptr, const f16* a0_lo = nullptr, const f16* a1_lo = nullptr,
-              float* row_stats = nullptr, int* row_groups = nullptr) {
+              float* row_stats = nullptr, int* row_groups = nullptr, double algo_flops = -1.0) {
         IgemmArgs a{};
         a.a0_lo = a0_lo; a.a1_lo = a0_lo ? a1_lo : nullptr;
         a.row_stats = row_stats; a.row_stats_groups = row_groups;
@@ -404,7 +405,9 @@ struct Run {
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double M = (double)B * Ho * Wo;
         const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
-        launch(c.taps == 9 ? P_CONV3 : P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
+        // algo_flops: the REFERENCE graph's count for this layer where the executed form pads it (conv_in on the MFMA conv runs 64 input channels for 4):
+        // cs_unet_flops is the algorithmic count of SURVEY 8(d), independent of how a layer is executed
+        launch(c.taps == 9 ? P_CONV3 : P_GEMM, (algo_flops >= 0 && !count_executed) ? algo_flops : igemm_flops(a) * ((count_executed && a.a0_lo) ? 2.0 : 1.0), bytes, [&] { return launch_igemm(a, s); });
     }
     void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu, float* row_stats = nullptr, int* row_groups = nullptr) {
         IgemmArgs a{};
@@ -615,7 +618,7 @@ struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma; };
 static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share, g_tune_ln_fold, g_tune_conv_in_mfma}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
-                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant()) {
+                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant(), bool count_executed = false) {
     const CsUNetConfig& c = u->cfg;
     const int B = n_lat * dup;
     const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B) + sk_ws_bytes(u, B);
@@ -624,7 +627,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->arena.reset(ws + kvb + gnb, dry ? 0 : ws_bytes - kvb - gnb, dry);
     u->dry_flops = 0;
     Run R{u, s, dry, B};
-    R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a;
+    R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a; R.count_executed = count_executed;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -635,8 +638,10 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     f16* tscratch = R.alloc((size_t)nt * (c0 + td));
     f16* temb = R.alloc((size_t)nt * td);
     f16* tproj = R.alloc((size_t)nt * u->tp_total);
-    R.launch(P_MISC, 2.0 * nt * ((double)c0 * td + (double)td * td), 0, [&] { return launch_time_embedding(t, nt, c0, td, u->t_w1, u->t_b1, u->t_w2, u->t_b2, tscratch, temb, s); });
-    R.launch(P_MISC, 2.0 * nt * (double)td * u->tp_total, 2.0 * td * u->tp_total, [&] { return launch_rowvec_linear(temb, nt, td, u->tp_w, u->tp_b, u->tp_total, tproj, 0, s); });
+    // (algorithmic count: the reference graph broadcasts the timestep to the batch and runs the time MLP and every time_emb_proj per SAMPLE; executed: per distinct timestep)
+    const double nt_fl = count_executed ? (double)nt : (double)B;
+    R.launch(P_MISC, 2.0 * nt_fl * ((double)c0 * td + (double)td * td), 0, [&] { return launch_time_embedding(t, nt, c0, td, u->t_w1, u->t_b1, u->t_w2, u->t_b2, tscratch, temb, s); });
+    R.launch(P_MISC, 2.0 * nt_fl * (double)td * u->tp_total, 2.0 * td * u->tp_total, [&] { return launch_rowvec_linear(temb, nt, td, u->tp_w, u->tp_b, u->tp_total, tproj, 0, s); });
     R.tproj = tproj; R.tstride = (nt == 1) ? 0 : u->tp_total;
 
     // ---- cross-attention K/V of the context (cached across solver steps) --------------------------
@@ -663,7 +668,8 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
         float* st = R.stats_fusable(H * W, c0) ? R.alloc_stats(B, H * W, c0) : nullptr;
         const int Bkeep = R.B;
         R.B = n_lat;
-        R.conv(u->conv_in64, z, 64, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h, false, st);
+        R.conv(u->conv_in64, z, 64, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h, false, st, nullptr, nullptr, nullptr, nullptr,
+               2.0 * Bkeep * H * W * 9.0 * c.in_channels * c0);      // (the graph's conv_in: 4 input channels, full batch -- as the conv_in_kernel branch counts it)
         R.B = Bkeep;
         R.release(z);
         if (dup == 2 && !dry && R.rc == CS_OK) {
@@ -863,7 +869,7 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
 double cs_unet_flops_executed(const CsUNet* cu, int n_lat, int dup) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || n_lat <= 0 || (dup != 1 && dup != 2)) return 0;
-    run_forward(u, true, nullptr, n_lat, dup, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr);
+    run_forward(u, true, nullptr, n_lat, dup, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, current_variant(), true);
     return u->dry_flops;
 }
 

@@ -6,19 +6,21 @@ activations stay O(1) through the GroupNorms so fp16 neither overflows nor under
 import torch
 
 
-def synthetic_unet_state_dict(manifest, seed=20251226):
-    g = torch.Generator().manual_seed(seed)
+def synthetic_unet_state_dict(manifest, seed=20251226, device="cpu"):
+    """``device``: where the values are drawn (the CPU and the GPU generators give different streams for one seed: the tests and their committed numbers use the
+    CPU stream, bench.py draws on each rank's own GPU)."""
+    g = torch.Generator(device=device).manual_seed(seed)
     sd = {}
     for name, shape in manifest:
         if name.endswith(".weight") and len(shape) >= 2:
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            w = torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+            w = torch.randn(shape, generator=g, device=device) * (1.0 / fan_in) ** 0.5
         elif ("norm" in name) and name.endswith(".weight"):
-            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
         else:
-            w = 0.05 * torch.randn(shape, generator=g)
+            w = 0.05 * torch.randn(shape, generator=g, device=device)
         sd[name] = w
     return sd
 

@@ -176,7 +176,8 @@ const char* cs_unet_weight_name(const CsUNet* u, int i, int64_t* shape4, int* nd
 /* all weights present? pack; must be called once before forward */
 int cs_unet_finalize(CsUNet* u);
 size_t cs_unet_workspace_bytes(const CsUNet* u, int batch);
-/* FLOPs of one forward at `batch` samples (algorithmic, 2*MAC) */
+/* FLOPs of one forward at `batch` samples: the REFERENCE GRAPH's algorithmic count (2*MAC; SURVEY 8(d): batch x 803.27 GFLOP for SD1.5), independent of
+ * every execution knob (conv_in is counted at its 4 input channels even when it runs zero-padded on the MFMA conv; the time MLP per sample) */
 double cs_unet_flops(const CsUNet* u, int batch);
 /* FLOPs actually executed by cs_unet_forward(n_lat, dup): with dup = 2 and one timestep the layers in front of the first
  * cross attention are evaluated once for both CFG halves (same latents, same timestep; bit-identical results), so this is

@@ -90,9 +90,22 @@ def test_bench_launcher_branch_dry_run():
     assert len(pr) == 2 and [p["rank"] for p in pr] == [0, 1] and len({p["device"] for p in pr}) == 2
     assert [p["prompt_shard"] for p in pr] == [[0, 16], [16, 32]] and all(p["images"] == 16 * 3 for p in pr)
     assert max(p["elapsed_s"] for p in pr) == rec["max_elapsed_s"]
+    assert rec["per_rank_distinct_devices"] == 2 and len({p["host_id"] for p in pr}) == 1      # one node: same host id, distinct (host, device) pairs
     # N > 1: nothing but the sampling loop runs around the barriers -- the CPU baseline, the sub-record extras and the vendor ceilings are N = 1 only
     sw = rec["side_work_after_timed_region"]
     assert sw["cpu_baseline"] is False and sw["extras"] is False and sw["ceilings"] is False
+    # the per-rank shards tile [0, 16 N) exactly as gen_ppo.py:349-357 cuts the prompt list (contiguous, in rank order, last rank takes the remainder) -- at the
+    # world sizes the driver's scaling run uses, through the same launch path
+    for N in (4, 8):
+        rN = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--steps", "1", "--warmup", "0", "--dry-run"],
+                            capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert rN.returncode == 0, rN.stdout + rN.stderr
+        recN = json.loads([l for l in rN.stdout.splitlines() if l.startswith("{")][0])
+        shards = [p["prompt_shard"] for p in sorted(recN["per_rank"], key=lambda p: p["rank"])]
+        per = (16 * N) // N
+        assert shards == [[r * per, (r + 1) * per if r < N - 1 else 16 * N] for r in range(N)], shards
+        assert shards[0][0] == 0 and shards[-1][1] == 16 * N and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+        assert recN["n_gpus"] == N and recN["images"] == 16 * N and recN["per_rank_distinct_devices"] == N
     # N = 1 takes the in-process path (no launcher)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     rec1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])

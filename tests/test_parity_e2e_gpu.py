@@ -33,10 +33,12 @@ from consolver_amd.synth import synthetic_prompt_embeds, synthetic_unet_state_di
 from consolver_amd.unet import HipUNet2DConditionModel
 from oracle import solver_oracle as so
 from oracle.unet_oracle import UNetOracle
+from tests._models import get_unet, get_oracle, drop
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GATE = 1.0e-3          # north_star: latents within 1e-3 relative fp32 of the reference
+FWD_X2_BOUND = 0.98e-3  # per-forward eps error of the f16x2 stream on random latents: measured + 10 % (re-stated each round; the 8-step latents are what the gate is on)
 
 
 def rel_l2(a, b):
@@ -114,49 +116,51 @@ def cast32(hook):
 
 
 def build_full(seed=7, residual="f16"):
-    u = HipUNet2DConditionModel({}, device=DEV, residual=residual)
-    sd = synthetic_unet_state_dict(u.manifest(), seed=seed)
-    u.load_state_dict(sd)
-    return u, sd
+    """the full SD1.5 UNet on seeded synthetic weights: ONE handle per seed and pytest process (tests/_models.py), switched between the residual-stream modes"""
+    return get_unet({}, seed=seed, residual=residual)
 
 
 @pytest.mark.timeout(1800)
 def test_forward_error_budget_and_class_attribution():
     """(b) + (c): one CFG dual-batch forward of the full SD1.5 UNet at three timesteps of the 8-step grid."""
-    u, sd = build_full()
-    ux2, _ = build_full(residual="f16x2")
-    torch.set_num_threads(16)
-    orc = UNetOracle(sd, u.config)                                            # the oracle: CPU fp32
+    u, sd = build_full(residual="f16")
+    orc = get_oracle({}, seed=7)                                              # the oracle: CPU fp32
     t16 = UNetOracle(sd, u.config, device=DEV, dtype=torch.float16)          # comparator: plain torch fp16 on the GPU
     hooks = HipHooks()
     g = torch.Generator().manual_seed(5)
     rows = []
+    inputs = []
     worst_ratio = 0.0
     for t in (999, 499, 124):
         lat = torch.randn(1, 4, 64, 64, generator=g).half()
         ctx = synthetic_prompt_embeds(2, seed=13 + t).half()
         want = orc(torch.cat([lat.float()] * 2), t, ctx.float())
+        inputs.append((lat, ctx, want))
         e_t16 = rel_l2(t16(torch.cat([lat] * 2), t, ctx).float(), want)
         got = u(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0]
         e_hip = rel_l2(got.float(), want)
-        e_x2 = rel_l2(ux2(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float(), want)
-        row = dict(t=t, torch_fp16=e_t16, hip_executor=e_hip, hip_executor_f16x2=e_x2)
+        row = dict(t=t, torch_fp16=e_t16, hip_executor=e_hip)
         if t == 499:
             for c in CLASSES + ["all"]:
                 hyb = UNetOracle(sd, u.config, device=DEV, dtype=torch.float16)
                 for k in (CLASSES if c == "all" else [c]):
                     hyb.ops[k] = getattr(hooks, k)
                 row["hybrid_" + c] = rel_l2(hyb(torch.cat([lat] * 2), t, ctx).float(), want)
+                del hyb
             # the reverse attribution: an fp32 torch graph on the GPU with ONE class computed by the fp16 HIP kernel
             g32 = UNetOracle(sd, u.config, device=DEV, dtype=torch.float32)
             row["gpu_fp32_graph"] = rel_l2(g32(torch.cat([lat.float()] * 2), t, ctx.float()), want)
             for c in CLASSES + ["all"]:
-                h32 = UNetOracle(sd, u.config, device=DEV, dtype=torch.float32)
-                for k in (CLASSES if c == "all" else [c]):
-                    h32.ops[k] = cast32(getattr(hooks, k))
-                row["f32+hip_" + c] = rel_l2(h32(torch.cat([lat.float()] * 2), t, ctx.float()), want)
+                for k in CLASSES:
+                    g32.ops[k] = cast32(getattr(hooks, k)) if (c == "all" or k == c) else None
+                row["f32+hip_" + c] = rel_l2(g32(torch.cat([lat.float()] * 2), t, ctx.float()), want)
+            del g32
         rows.append(row)
         worst_ratio = max(worst_ratio, e_hip / e_t16)
+    # the same three forwards on the split-fp16 residual stream (the same handle, switched)
+    ux2, _ = build_full(residual="f16x2")
+    for row, (lat, ctx, want) in zip(rows, inputs):
+        row["hip_executor_f16x2"] = rel_l2(ux2(lat.to(DEV), row["t"], encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float(), want)
     print("\nper-forward eps error vs the fp32 oracle (relative L2), full SD1.5 UNet, CFG dual batch:")
     for r in rows:
         print("  " + "\n    ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in r.items()))
@@ -165,7 +169,7 @@ def test_forward_error_budget_and_class_attribution():
     for r in rows:
         assert r["hip_executor"] <= 1.25 * r["torch_fp16"], r
         assert r["hip_executor"] < 1.72e-3, r                     # f16 stream: regression bound = measured 1.49e-3 .. 1.56e-3 + 10 % (gate 1.0e-3 not met in this mode)
-        assert r["hip_executor_f16x2"] < 0.98e-3, r               # f16x2 stream: measured 0.81e-3 .. 0.88e-3 (round 4; tools/sim_precision.py predicted 0.83e-3 at t = 499) + 10 %
+        assert r["hip_executor_f16x2"] < FWD_X2_BOUND, r          # f16x2 stream: measured + 10 % (see FWD_X2_BOUND)
         assert r["hip_executor_f16x2"] < 0.72 * r["hip_executor"], r
 
 
@@ -188,78 +192,83 @@ def _oracle_sched(w):
     return s
 
 
+def _hip_trajectory(unet, sch, idx, noise, ctx_d, B, n, g):
+    """the product's loop, step by step (per-step latents kept for the drift table)"""
+    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+    sch.set_timesteps(n, device=DEV)
+    x = noise.to(DEV)
+    traj = []
+    for i, t in enumerate(sch.timesteps):
+        eps = unet(x, t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
+        x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
+        traj.append(x.float().cpu().numpy())
+    return traj
+
+
 # B = 16 is configs[1]'s own batch: ~10 minutes of fp32 CPU oracle on the GPU box, so it runs on request (CS_PARITY_B16=1; its output is kept
 # under profiles/) and the default suite keeps B = 2 -- the per-sample arithmetic does not depend on the batch.
 @pytest.mark.timeout(6000)
 @pytest.mark.parametrize("B", [2] + ([16] if os.environ.get("CS_PARITY_B16") == "1" else []))
 def test_eight_step_trajectory_full_unet_vs_oracle(B):
     """(a): configs[1]'s 8 steps (trailing grid 999..124, CFG 3, order 4) on the full UNet."""
-    u, sd = build_full()
-    ux2, _ = build_full(residual="f16x2")
     sch, w = _scheduler()
     n, g = 8, 3.0
     idx = np.random.default_rng(6).integers(0, 11, size=(n, B, 3))
     pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
     noise = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(43)).half()
     ctx = torch.cat([ne, pe])
-
-    # --- the product: device-resident loop, per-step latents kept for the drift table
-    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
-    sch.set_timesteps(n, device=DEV)
-    x = noise.to(DEV)
     ctx_d = ctx.to(DEV)
-    hip_traj = []
-    for i, t in enumerate(sch.timesteps):
-        eps = u(x, t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
-        x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
-        hip_traj.append(x.float().cpu().numpy())
-    # the same loop on the split-fp16 residual stream (the gated mode)
-    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
-    sch.set_timesteps(n, device=DEV)
-    x = noise.to(DEV)
-    x2_traj = []
-    for i, t in enumerate(sch.timesteps):
-        eps = ux2(x, t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
-        x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
-        x2_traj.append(x.float().cpu().numpy())
-    # the engine runs the same loop (ring buffers, no allocation): bit-identical final latents
-    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
-    eng = SDSamplingEngine(u, sch, guidance_scale=g)
-    got = eng.generate(pe.to(DEV), ne.to(DEV), latents=noise.to(DEV), num_inference_steps=n).float().cpu().numpy()
-    assert np.array_equal(got, hip_traj[-1])
 
-    # --- the oracle (fp32 CPU) and the torch-fp16 comparator pipeline (fp16 UNet graph + fp16-rounded solver arithmetic)
-    torch.set_num_threads(16)
-    orc_u = UNetOracle(sd, u.config)
+    # --- the oracle (fp32 CPU) and the torch-fp16 comparator pipeline (fp16 UNet graph + fp16-rounded solver arithmetic); the oracle's per-step latents are
+    #     kept for the teacher-forced per-forward errors below
+    u, sd = build_full(residual="f16")
+    orc_u = get_oracle({}, seed=7)
     t16_u = UNetOracle(sd, u.config, device=DEV, dtype=torch.float16)
     s_or, s_16 = _oracle_sched(w), _oracle_sched(w)
     s_or.set_timesteps(n); s_16.set_timesteps(n)
     xo = noise.float().numpy()
     x16 = noise.float().numpy()
-    rows = []
+    orc_in, orc_eps, orc_traj, t16_traj, fwd_t16 = [], [], [], [], []
     for i, t in enumerate(s_or.timesteps):
         t = int(t)
-        # teacher-forced per-forward error: HIP UNet and torch-fp16 UNet on the ORACLE's latents of this step
-        xo_h = torch.from_numpy(xo).half()
+        orc_in.append(xo)
         e_or = orc_u(torch.cat([torch.from_numpy(xo)] * 2), t, ctx.float()).numpy()     # the oracle itself stays fp32 end to end
-        e_hip = u(xo_h.to(DEV), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0].float().cpu().numpy()
-        e_x2 = ux2(xo_h.to(DEV), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0].float().cpu().numpy()
-        e_16 = t16_u(torch.cat([xo_h] * 2), t, ctx).float().cpu().numpy()
-        # free-running pipelines
+        orc_eps.append(e_or)
+        fwd_t16.append(rel_l2(t16_u(torch.cat([torch.from_numpy(xo).half()] * 2), t, ctx).float().cpu().numpy(), e_or))
         xo = s_or.step(so.cfg_combine(e_or[:B], e_or[B:], g), t, xo, idx[i], cond_dtype="f16")["prev_sample"]
         f16 = t16_u(torch.cat([torch.from_numpy(x16).half()] * 2), t, ctx).float().cpu().numpy()
         ec = so.round_f16(so.cfg_combine(so.round_f16(f16[:B]), so.round_f16(f16[B:]), g))
         x16 = so.round_f16(s_16.step(ec, t, x16, idx[i], cond_dtype="f16")["prev_sample"])
-        rows.append(dict(step=i, t=t, fwd_hip=rel_l2(e_hip, e_or), fwd_x2=rel_l2(e_x2, e_or), fwd_t16=rel_l2(e_16, e_or),
-                         drift_hip=rel_l2(hip_traj[i], xo), drift_x2=rel_l2(x2_traj[i], xo), drift_t16=rel_l2(x16, xo)))
+        orc_traj.append(xo); t16_traj.append(x16)
+    del t16_u
+
+    # --- the product in both residual-stream modes: free-running trajectory + teacher-forced forwards on the ORACLE's latents of each step
+    res = {}
+    for mode in ("f16", "f16x2"):
+        un, _ = build_full(residual=mode)
+        traj = _hip_trajectory(un, sch, idx, noise, ctx_d, B, n, g)
+        if mode == "f16":      # the engine runs the same loop (ring buffers, no allocation): bit-identical final latents
+            sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+            eng = SDSamplingEngine(un, sch, guidance_scale=g)
+            got = eng.generate(pe.to(DEV), ne.to(DEV), latents=noise.to(DEV), num_inference_steps=n).float().cpu().numpy()
+            assert np.array_equal(got, traj[-1])
+        fwd = []
+        for i, t in enumerate(s_or.timesteps):
+            e = un(torch.from_numpy(orc_in[i]).half().to(DEV), int(t), encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0].float().cpu().numpy()
+            fwd.append(rel_l2(e, orc_eps[i]))
+        res[mode] = (traj, fwd)
+    rows = []
+    for i, t in enumerate(s_or.timesteps):
+        rows.append(dict(step=i, t=int(t), fwd_hip=res["f16"][1][i], fwd_x2=res["f16x2"][1][i], fwd_t16=fwd_t16[i],
+                         drift_hip=rel_l2(res["f16"][0][i], orc_traj[i]), drift_x2=rel_l2(res["f16x2"][0][i], orc_traj[i]), drift_t16=rel_l2(t16_traj[i], orc_traj[i])))
     print(f"\n8-step trajectory, full SD1.5 UNet, B={B}, CFG 3 (relative L2 vs the fp32 oracle; gate on the final latents {GATE:.1e}):")
     for r in rows:
         print("  step {step} t={t:3d}  forward: f16x2 {fwd_x2:.3e} f16 {fwd_hip:.3e} torch-fp16 {fwd_t16:.3e}   "
               "latents: f16x2 {drift_x2:.3e} f16 {drift_hip:.3e} torch-fp16 {drift_t16:.3e}".format(**r))
     final_hip, final_x2, final_t16 = rows[-1]["drift_hip"], rows[-1]["drift_x2"], rows[-1]["drift_t16"]
-    print(f"  final latents: f16x2 {final_x2:.3e} (gate {GATE:.1e}: {'MET' if final_x2 <= GATE else 'NOT MET'}), "
+    print(f"  final latents: f16x2 {final_x2:.3e} (gate {GATE:.1e}: {'MET' if final_x2 <= GATE else 'NOT MET'}, margin {100 * (1 - final_x2 / GATE):.1f} %), "
           f"f16 {final_hip:.3e} (gate not met in this mode; regression bound 1.54e-3), torch-fp16 class {final_t16:.3e}")
-    assert np.isfinite(got).all() and np.isfinite(x2_traj[-1]).all()
+    assert np.isfinite(res["f16"][0][-1]).all() and np.isfinite(res["f16x2"][0][-1]).all()
     # ---- the gate: split-fp16 residual stream
     assert final_x2 <= GATE, final_x2
     for r in rows:
@@ -271,13 +280,41 @@ def test_eight_step_trajectory_full_unet_vs_oracle(B):
     assert final_hip < 1.54e-3, final_hip                         # measured 1.40e-3 at B = 2, 1.35e-3 at B = 16 (torch-fp16 class: 1.94e-3), + 10 %
 
 
+# the step counts the reference publishes besides 8 (readme.md:158-163: 5 / 8 / 10 / 12; train_ppo.py:345 draws 2..15) and a second weight seed: the gated mode only,
+# B = 1 (the per-sample arithmetic does not depend on the batch), every step of every trajectory against the gate
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("n,wseed", [(4, 7), (12, 7), (8, 8)])
+def test_gate_holds_at_other_step_counts_and_weights(n, wseed):
+    B, g = 1, 3.0
+    sch, w = _scheduler()
+    idx = np.random.default_rng(60 + n).integers(0, 11, size=(n, B, 3))
+    pe, ne = synthetic_prompt_embeds(B, seed=2001 + n).half(), synthetic_prompt_embeds(B, seed=2002 + n).half()
+    noise = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(143 + wseed)).half()
+    ctx = torch.cat([ne, pe])
+    ux2, sd = build_full(seed=wseed, residual="f16x2")
+    traj = _hip_trajectory(ux2, sch, idx, noise, ctx.to(DEV), B, n, g)
+    orc_u = get_oracle({}, seed=wseed)
+    s_or = _oracle_sched(w)
+    s_or.set_timesteps(n)
+    xo = noise.float().numpy()
+    drift = []
+    for i, t in enumerate(s_or.timesteps):
+        e_or = orc_u(torch.cat([torch.from_numpy(xo)] * 2), int(t), ctx.float()).numpy()
+        xo = s_or.step(so.cfg_combine(e_or[:B], e_or[B:], g), int(t), xo, idx[i], cond_dtype="f16")["prev_sample"]
+        drift.append(rel_l2(traj[i], xo))
+    print(f"\n{n}-step trajectory, weight seed {wseed}, f16x2: latents vs the fp32 oracle per step " + " ".join(f"{d:.3e}" for d in drift) +
+          f"  -> final {drift[-1]:.3e}, gate {GATE:.1e}, margin {100 * (1 - max(drift) / GATE):.1f} %")
+    if wseed != 7:
+        drop({}, seed=wseed)                                      # (3.4 GB of host weights + the oracle's copy)
+    assert np.isfinite(traj[-1]).all()
+    assert max(drift) <= GATE, drift
+
+
 def test_two_rollouts_with_different_prompts_do_not_share_kv():
     """regression: the cross-attention K/V cache must not survive into a rollout with other prompts (a fresh torch.cat
     of the same size lands on the freed address of the previous one)."""
     from consolver_amd.rollout import denoise_diffusion
-    u = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
-    sd = synthetic_unet_state_dict(u.manifest(), seed=3)
-    u.load_state_dict(sd)
+    u, sd = get_unet(dict(layers_per_block=1, sample_size=16), seed=3)
     sch, _ = _scheduler()
     B, n = 2, 3
     noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half().to(DEV)
@@ -388,8 +425,7 @@ def test_rollout_shares_denoiser_calls_for_identical_inputs():
     rollout evaluates steps 0 and 1 (scaler_dim = 0) for one row and broadcasts; records and latents equal the full-batch rollout to
     fp16 rounding (the one-row denoiser call may pick other tile / split-K shapes than the batch-B call)."""
     from consolver_amd.rollout import denoise_diffusion
-    u = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
-    u.load_state_dict(synthetic_unet_state_dict(u.manifest(), seed=3))
+    u, _ = get_unet(dict(layers_per_block=1, sample_size=16), seed=3)
     sch, _ = _scheduler()
     B, n = 4, 5
     noise = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half().to(DEV).repeat(B, 1, 1, 1)

@@ -97,9 +97,8 @@ def test_collect_rollout_reduced_networks():
     from consolver_amd.synth import synthetic_unet_state_dict, synthetic_vae_state_dict, synthetic_prompt_embeds
     from oracle.unet_oracle import UNetOracle
     from oracle import vae_oracle
-    unet = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
-    usd = synthetic_unet_state_dict(unet.manifest(), seed=5)
-    unet.load_state_dict(usd)
+    from tests._models import get_unet
+    unet, usd = get_unet(dict(layers_per_block=1, sample_size=16), seed=5)
     vae = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
     vsd = synthetic_vae_state_dict(vae.manifest(), seed=6)
     vae.load_state_dict(vsd)
@@ -265,8 +264,8 @@ def test_train_iteration_reduced_networks_improves_reward_direction():
     from consolver_amd.vae import HipAutoencoderKL
     from consolver_amd.synth import synthetic_unet_state_dict, synthetic_vae_state_dict, synthetic_prompt_embeds
     import random
-    unet = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV)
-    unet.load_state_dict(synthetic_unet_state_dict(unet.manifest(), seed=5))
+    from tests._models import get_unet
+    unet, _ = get_unet(dict(layers_per_block=1, sample_size=16), seed=5)
     vae = HipAutoencoderKL(dict(layers_per_block=1, sample_size=16), device=DEV)
     vae.load_state_dict(synthetic_vae_state_dict(vae.manifest(), seed=6))
     sch = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing",

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from consolver_amd import ops
 from consolver_amd.synth import synthetic_prompt_embeds, synthetic_unet_state_dict
 from consolver_amd.unet import HipUNet2DConditionModel
+from tests._models import get_unet, get_oracle
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -216,22 +217,20 @@ def test_xattn_block_x2_residual_is_fp32_class():
 
 def _small_unet(residual):
     cfg = dict(layers_per_block=1, sample_size=16)
-    u = HipUNet2DConditionModel(cfg, device=DEV, residual=residual)
-    sd = synthetic_unet_state_dict(u.manifest(), seed=3)
-    u.load_state_dict(sd)
-    return u, sd
+    return get_unet(cfg, seed=3, residual=residual)
 
 
 def test_unet_x2_mode_is_closer_to_the_fp32_oracle_and_api_round_trips():
     from oracle.unet_oracle import UNetOracle
     u16, sd = _small_unet("f16")
-    ux2, _ = _small_unet("residual_fp32")
+    ux2 = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=16), device=DEV, residual="residual_fp32")   # a second handle on the same weights, created through the alias
+    ux2.load_state_dict(sd)
     assert ux2.residual == "f16x2" and u16.residual == "f16"
     with pytest.raises(ValueError):
         u16.set_residual_precision("fp64")
     lat = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1)).half()
     ctx = torch.cat([synthetic_prompt_embeds(2, seed=5), synthetic_prompt_embeds(2, seed=6)]).half()
-    want = UNetOracle(sd, u16.config)(torch.cat([lat.float()] * 2), 499, ctx.float())
+    want = get_oracle(dict(layers_per_block=1, sample_size=16), seed=3)(torch.cat([lat.float()] * 2), 499, ctx.float())
     e16 = rel_l2(u16(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float().cpu(), want)
     ex2 = rel_l2(ux2(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float().cpu(), want)
     print(f"\nsmall UNet eps error vs fp32 oracle: f16 stream {e16:.3e}, f16x2 stream {ex2:.3e}")
@@ -251,8 +250,7 @@ def test_unet_x2_execution_variants_agree(knobs):
     """CFG shared prefix on / off is bit-identical in the split mode too; the unfused cross-attention block and the statistics-pass GroupNorm
     differ from the default by fp16 roundings inside a branch only."""
     u, _ = _small_unet("f16x2")
-    u64 = HipUNet2DConditionModel(dict(layers_per_block=1, sample_size=32), device=DEV, residual="f16x2")   # 32 x 32: the C = 320 level is fusable (HW % 128 == 0)
-    u64.load_state_dict(synthetic_unet_state_dict(u64.manifest(), seed=3))
+    u64, _ = get_unet(dict(layers_per_block=1, sample_size=32), seed=3, residual="f16x2")   # 32 x 32: the C = 320 level is fusable (HW % 128 == 0)
     for net, S in ((u, 16), (u64, 32)):
         lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(1)).half().to(DEV)
         ctx = torch.cat([synthetic_prompt_embeds(2, seed=5), synthetic_prompt_embeds(2, seed=6)]).half().to(DEV)

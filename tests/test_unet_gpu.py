@@ -12,6 +12,7 @@ import torch
 from consolver_amd.unet import HipUNet2DConditionModel, SD15_CONFIG
 from consolver_amd.synth import synthetic_unet_state_dict, synthetic_prompt_embeds
 from oracle.unet_oracle import UNetOracle
+from tests._models import get_unet, get_oracle
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -23,10 +24,9 @@ def rel_l2(a, b):
 
 
 def build(cfg_over):
-    u = HipUNet2DConditionModel(cfg_over, device=DEV)
-    sd = synthetic_unet_state_dict(u.manifest(), seed=7)
-    u.load_state_dict(sd)
-    return u, UNetOracle(sd, u.config)
+    # one build per (config, seed) and pytest process (tests/_models.py); default residual stream (f16x2)
+    u, _ = get_unet(cfg_over, seed=7)
+    return u, get_oracle(cfg_over, seed=7)
 
 
 def test_reduced_unet_matches_oracle():
@@ -141,7 +141,6 @@ def test_cfg_shared_prefix_matches_full_dual_batch():
             tt = torch.full((2 * n_lat,), 499.0, device=DEV)
             assert torch.equal(u(lat, tt, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0], full)
             assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat) and u.flops_executed(2 * n_lat, 1) == u.flops(2 * n_lat)
-            del u
     finally:
         ops.set_tuning("cfg_share", 1)
 
@@ -192,7 +191,6 @@ def test_group_norm_statistics_from_the_producers_match_the_statistics_pass():
         assert torch.isfinite(fused).all()
         assert e_fs < 1.25 * (e_f ** 2 + e_s ** 2) ** 0.5              # two rounding realisations of the same fp32 function (any perturbation decorrelates the fp16 roundings downstream)
         assert e_f < 1.1 * e_s + 1e-4
-        del u
 
 
 @pytest.mark.parametrize("sample_size,n_lat", [(24, 3), (8, 5), (40, 1)])
@@ -216,8 +214,7 @@ def test_forward_does_not_read_uninitialised_workspace(residual):
     filled with random bytes between two runs and the outputs must be bit-identical.  (Round 4: the MFMA conv_in left GroupNorm statistics for the
     first CFG half only, and the last up block normalised the skip connection at full batch with whatever the arena held.)"""
     for cfg, S in ((dict(layers_per_block=1, sample_size=16), 16), (dict(layers_per_block=1, sample_size=32), 32)):
-        u = HipUNet2DConditionModel(cfg, device=DEV, residual=residual)
-        u.load_state_dict(synthetic_unet_state_dict(u.manifest(), seed=3))
+        u, _ = get_unet(cfg, seed=3, residual=residual)
         lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(1)).half().to(DEV)
         ctx = synthetic_prompt_embeds(4, seed=11).half().to(DEV)
         for dup, c in ((2, ctx), (1, ctx[:2].contiguous())):
