@@ -119,10 +119,10 @@ def parity_vs_oracle(unet, replay, guidance, dev, modes):
         sch.factor_net.to(dev)
         sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(dev) for i in replay["idx"]]
         sch.set_timesteps(n, device=dev)
-        x = torch.from_numpy(replay["noise"]).half().to(dev)
+        x = torch.from_numpy(replay["noise"]).to(dev).float()            # the engine's loop: fp32 solver state, the denoiser reads its fp16 copy
         ctx = replay["ctx"].half().to(dev)
         for i, t in enumerate(sch.timesteps[:n_done]):
-            eps = unet(x, t, encoder_hidden_states=ctx, dup=2, reuse_kv=(i > 0))[0]
+            eps = unet(x.half(), t, encoder_hidden_states=ctx, dup=2, reuse_kv=(i > 0))[0]
             x = sch.step(eps[1:], t, x, return_dict=False, eps_uncond=eps[:1], guidance_scale=guidance)[0]
         got = x.double().cpu()
         out[mode] = float((got - want).norm() / want.norm())

@@ -25,6 +25,7 @@ extern int g_tune_ln_fold;
 extern int g_tune_xcd_grid;
 extern int g_tune_epi_fast;
 extern int g_tune_conv_in_mfma;
+extern int g_tune_xattn_tile;
 
 extern "C" {
 
@@ -38,7 +39,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"gn_fuse", &g_tune_gn_fuse, 1, 0, 1, false},    {"xattn_fused", &g_tune_xattn_fused, 1, 0, 1, false}, {"cfg_share", &g_tune_cfg_share, 1, 0, 1, false},
         {"gemm2_prio", &g_tune_gemm2_prio, 0, -1, 1, false}, {"attn_prio", &g_tune_attn_prio, -1, -1, 1, false}, {"attn_qt40", &g_tune_attn_qt40, 4, 2, 4, true},
         {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false}, {"ln_fold", &g_tune_ln_fold, 1, 0, 1, false}, {"xcd_grid", &g_tune_xcd_grid, 1, 0, 1, false}, {"epi_fast", &g_tune_epi_fast, 1, 0, 1, false},
-        {"conv_in_mfma", &g_tune_conv_in_mfma, 1, 0, 1, false},
+        {"conv_in_mfma", &g_tune_conv_in_mfma, 1, 0, 1, false}, {"xattn_tile", &g_tune_xattn_tile, 64, 64, 128, true},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;

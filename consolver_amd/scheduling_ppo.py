@@ -41,6 +41,7 @@ class HistoryMixin:
 
     record_conds = False     # materialise conds['epsilon'] (needed only by the PPO rollout)
     verbose = False          # print coefficients like the reference (forces a host sync)
+    prev_sample_dtype = None  # PPOScheduler.step: None = prev_sample has the sample's dtype; torch.float32 = promote a 16-bit sample (the reference with an fp32 policy net)
 
     def _policy(self, cond_row_f32, B, device, cfg=None, newest=None):
         """-> probs3 [B,A,K], actions [B,A], action_probs [B,A], idx.  ``cfg`` / ``newest``: use_conv under fused CFG -- the newest
@@ -79,7 +80,10 @@ class HistoryMixin:
         a.m, a.order_dim, a.scaler_dim = len(hist), self.config.order_dim, self.config.scaler_dim
         a.actions, a.actions_stride = actions.data_ptr(), actions.shape[1]
         a.B, a.elems = B, sample.numel() // max(B, 1)
-        a.io_dtype, a.out_dtype = L.dtype_code(sample.dtype), L.dtype_code(out_dtype)
+        # io_dtype is the model output's (eps, history, eps_out); an fp32 sample next to a 16-bit model output is passed as such (x_is_f32): the update
+        # reads it unrounded, which is what torch's promotion does with an fp32 `sample` (scheduler_ppo.py:306-332, scheduler_fmppo.py:354)
+        a.io_dtype, a.out_dtype = L.dtype_code(eps_text.dtype), L.dtype_code(out_dtype)
+        a.x_is_f32 = int(sample.dtype == torch.float32 and eps_text.dtype != torch.float32)
         a.x_out = out.data_ptr()
         a.eps_out = eps_out.data_ptr() if eps_out is not None else None
 
@@ -233,8 +237,14 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         L.require_cuda(sample, "sample")
         model_output = model_output.contiguous()
         sample = sample.contiguous()
-        if sample.dtype != model_output.dtype:
+        # dtype of the latents: an fp32 `sample` stays fp32 through the update (torch promotion; the reference's latents ARE fp32 from step 2 on when the policy
+        # net is fp32) -- the native engine keeps its solver state that way: the per-step fp16 rounding of the latents (2.8e-4 relative L2 per step,
+        # accumulating in quadrature) was what made the 8-step drift grow and the 12-step trajectory miss the 1e-3 gate.  A 16-bit sample
+        # keeps its dtype unless `prev_sample_dtype = torch.float32` asks for the promotion.
+        if sample.dtype != model_output.dtype and sample.dtype != torch.float32:
             sample = sample.to(model_output.dtype)
+        if self.prev_sample_dtype is not None and sample.dtype != self.prev_sample_dtype:
+            sample = sample.to(self.prev_sample_dtype)
         dev = model_output.device
         t = self._resolve_timestep(timestep)
         prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
@@ -263,6 +273,8 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         masks = self._masks(B, net.action_dims, m, dev)
 
         prev = out if out is not None else torch.empty_like(sample)
+        if prev.dtype != sample.dtype:
+            raise ValueError(f"step(out=...) must have the sample's dtype {sample.dtype}, got {prev.dtype}")
         a = L.CsStepArgs()
         self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, actions, prev, eps_out, sample.dtype)
         a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = self._ddim_scalars(t, prev_t)

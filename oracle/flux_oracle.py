@@ -31,35 +31,45 @@ def rope_tables(ids, axes_dims, theta=10000.0):
     return cos, sin                                              # [S, head_dim]
 
 
-def apply_rope(x, cos, sin):                                    # x [B, H, S, D]
-    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+def apply_rope(x, cos, sin):                                    # x [B, H, S, D]; fp32 tables, result in x's dtype (as diffusers' apply_rotary_emb)
+    xf = x.float()
+    xr, xi = xf.reshape(*xf.shape[:-1], -1, 2).unbind(-1)
     rot = torch.stack([-xi, xr], dim=-1).flatten(3)
-    return x * cos[None, None] + rot * sin[None, None]
+    return (xf * cos[None, None] + rot * sin[None, None]).to(x.dtype)
 
 
 class _Fp32View:
     """mapping view that converts a tensor to CPU fp32 when it is READ: lets the oracle walk a model whose fp32 weights do not fit in host memory
     (full-depth FLUX: 11.9 B parameters = 48 GB) -- the source mapping may hold them in 16 bits and / or on another device; one weight at a time is live."""
 
-    def __init__(self, sd):
-        self._sd = sd
+    def __init__(self, sd, device="cpu", dtype=torch.float32):
+        self._sd, self._device, self._dtype = sd, device, dtype
 
     def __getitem__(self, k):
-        return self._sd[k].detach().to("cpu", torch.float32)
+        return self._sd[k].detach().to(self._device, self._dtype)
 
 
 class FluxOracle:
-    def __init__(self, sd, config, lazy=False):
-        """lazy=True: `sd` is read through on demand (see _Fp32View) instead of being converted to fp32 up front."""
+    def __init__(self, sd, config, lazy=False, device="cpu", dtype=torch.float32):
+        """lazy=True: `sd` is read through on demand (see _Fp32View) instead of being converted to fp32 up front.
+        device / dtype: the default (CPU, fp32) is the oracle.  Tests also run the SAME restatement as a plain torch bf16 graph on the GPU (device="cuda",
+        dtype=torch.bfloat16: bf16 weights, bf16 activation storage between torch ops, the vendor kernels' fp32 accumulation; sinusoids, RoPE and the RMSNorm
+        statistics in fp32 as diffusers computes them) -- the arithmetic class of the reference's own bf16 pipeline (edit_ppo/generate_ours.py:120-126) -- so that
+        the HIP DiT's distance from the fp32 oracle can be read against what that class delivers (tests/test_flux_gpu.py)."""
         self.cfg = config
-        self.sd = _Fp32View(sd) if lazy else {k: v.float() for k, v in sd.items()}
+        self.device, self.dtype = torch.device(device), dtype
+        self.sd = _Fp32View(sd, self.device, dtype) if lazy else {k: v.to(self.device, dtype) for k, v in sd.items()}
         self.D = config["num_heads"] * config["head_dim"]
+
+    def _in(self, x):
+        return torch.as_tensor(x).to(self.device, self.dtype)
 
     def lin(self, x, p):
         return F.linear(x, self.sd[p + ".weight"], self.sd[p + ".bias"])
 
     def rms(self, x, p):
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * self.sd[p + ".weight"]
+        xf = x.float()                                               # (diffusers' RMSNorm takes the variance in fp32)
+        return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(x.dtype) * self.sd[p + ".weight"]
 
     def heads(self, x):
         B, S, _ = x.shape
@@ -76,15 +86,15 @@ class FluxOracle:
     @torch.no_grad()
     def __call__(self, hidden_states, timestep, guidance, pooled, enc, txt_ids, img_ids):
         cfg, D = self.cfg, self.D
-        x = self.lin(hidden_states.float(), "x_embedder")
-        c = self.lin(enc.float(), "context_embedder")
+        x = self.lin(self._in(hidden_states), "x_embedder")
+        c = self.lin(self._in(enc), "context_embedder")
         tt = "time_text_embed."
-        temb = self.lin(F.silu(self.lin(sinusoid(timestep.float() * 1000), tt + "timestep_embedder.linear_1")), tt + "timestep_embedder.linear_2")
+        temb = self.lin(F.silu(self.lin(self._in(sinusoid(timestep.float().cpu() * 1000)), tt + "timestep_embedder.linear_1")), tt + "timestep_embedder.linear_2")
         if cfg["guidance_embeds"]:
-            temb = temb + self.lin(F.silu(self.lin(sinusoid(guidance.float() * 1000), tt + "guidance_embedder.linear_1")), tt + "guidance_embedder.linear_2")
-        temb = temb + self.lin(F.silu(self.lin(pooled.float(), tt + "text_embedder.linear_1")), tt + "text_embedder.linear_2")
+            temb = temb + self.lin(F.silu(self.lin(self._in(sinusoid(guidance.float().cpu() * 1000)), tt + "guidance_embedder.linear_1")), tt + "guidance_embedder.linear_2")
+        temb = temb + self.lin(F.silu(self.lin(self._in(pooled), tt + "text_embedder.linear_1")), tt + "text_embedder.linear_2")
         ids = np.concatenate([np.asarray(txt_ids, np.float32), np.asarray(img_ids, np.float32)], 0)
-        cos, sin = rope_tables(ids, cfg["axes_dims_rope"])
+        cos, sin = (t.to(self.device) for t in rope_tables(ids, cfg["axes_dims_rope"]))
         T = c.shape[1]
         silu_t = F.silu(temb)
         ln = lambda h: F.layer_norm(h, (D,), eps=1e-6)

@@ -506,10 +506,15 @@ def test_attention_dh40_outlier_key_takes_the_safe_path(Nq, Nk, pos):
     assert float((out.float() - ref).abs().max()) < 1e-2
 
 
-@pytest.mark.parametrize("B,HW,Nk", [(3, 256, 77), (1, 128, 80), (2, 384, 13), (2, 4096, 77)])
-def test_xattn_block_fused_kernel(B, HW, Nk):
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("B,HW,Nk", [(3, 256, 77), (1, 128, 80), (2, 384, 13), (2, 4096, 77), (5, 64, 1), (1, 192, 77)])
+def test_xattn_block_fused_kernel(B, HW, Nk, tile):
     """the fused cross-attention sub-block (LayerNorm2 -> to_q -> <= 80-key attention -> to_out + residual in one kernel, C = 320,
-    8 heads) against plain torch fp32 of the same fp16 inputs, and against the four unfused HIP ops it replaces."""
+    8 heads) against plain torch fp32 of the same fp16 inputs, and against the four unfused HIP ops it replaces.  tile: 64 = xattn64_kernel (round 5
+    default: 64-row tiles, two workgroups per CU), 128 = xattn_block_kernel; the two must agree bit for bit (same per-wave arithmetic)."""
+    if tile == 128 and HW % 128:
+        pytest.skip("the 128-row kernel needs HW % 128 == 0")
+    ops.set_tuning("xattn_tile", tile)
     g = torch.Generator().manual_seed(B * 1000 + HW + Nk)
     C, H = 320, 8
     M = B * HW
@@ -540,6 +545,15 @@ def test_xattn_block_fused_kernel(B, HW, Nk):
     h2 = h.clone()
     ops.xattn_block(h2, gam, bet, wq, kv, wo, bo, heads=H, hw=HW, out=h2)
     assert torch.equal(h2, got)
+    if tile == 64 and HW % 128 == 0:
+        ops.set_tuning("xattn_tile", 128)
+        assert torch.equal(ops.xattn_block(h, gam, bet, wq, kv, wo, bo, heads=H, hw=HW), got)
+        # ... and on the split-fp16 stream, with the row statistics
+        hl = (0.001 * torch.randn(M, C, generator=g)).half().to(DEV)
+        a128 = ops.xattn_block_x2(h, hl, gam, bet, wq, kv, wo, bo, hw=HW, row_stats=True)
+        ops.set_tuning("xattn_tile", 64)
+        a64 = ops.xattn_block_x2(h, hl, gam, bet, wq, kv, wo, bo, hw=HW, row_stats=True)
+        assert all(torch.equal(x, y) for x, y in zip(a128, a64))
 
 
 XCD_GRID_CASES = [   # weight-heavy SD1.5 layers (16 x 16 / 8 x 8 levels, batch 32) where launch_igemm_impl maps the XCDs as a 2-D grid (tile_of, pn > 0)

@@ -93,7 +93,11 @@ def test_sd15_flops_match_survey():
 @pytest.mark.timeout(900)
 def test_full_sd15_unet_matches_oracle_cfg_batch():
     u, orc = build({})
-    assert abs(u.flops(1) / 1e9 - 803.27) / 803.27 < 0.01
+    assert abs(u.flops(1) / 1e9 - 803.27) < 0.02 and abs(u.flops(32) / 32e9 - 803.27) < 0.02       # the reference graph's count, per sample at any batch, whatever the knobs
+    from consolver_amd import ops as _ops
+    _ops.set_tuning("conv_in_mfma", 0)
+    assert abs(u.flops(32) / 32e9 - 803.27) < 0.02
+    _ops.set_tuning("conv_in_mfma", 1)
     g = torch.Generator().manual_seed(5)
     lat = torch.randn(1, 4, 64, 64, generator=g)
     ctx = synthetic_prompt_embeds(2, seed=13)
@@ -140,7 +144,9 @@ def test_cfg_shared_prefix_matches_full_dual_batch():
             # per-sample timesteps (the halves could differ): the shared path is not taken, results equal the full batch
             tt = torch.full((2 * n_lat,), 499.0, device=DEV)
             assert torch.equal(u(lat, tt, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0], full)
-            assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat) and u.flops_executed(2 * n_lat, 1) == u.flops(2 * n_lat)
+            # executed < algorithmic with the shared prefix; without it the two counts differ only by what the execution pads or shares: conv_in on the MFMA conv runs
+            # 64 input channels for 4 (+), one time MLP for the whole batch instead of one per sample (-)
+            assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat) and abs(u.flops_executed(2 * n_lat, 1) / u.flops(2 * n_lat) - 1.0) < 3e-3
     finally:
         ops.set_tuning("cfg_share", 1)
 
