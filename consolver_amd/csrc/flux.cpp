@@ -58,6 +58,7 @@ struct CsFlux {
     u16* mod_w = nullptr; u16* mod_b = nullptr; long mod_total = 0; long mod_final = 0;
     std::vector<DoubleBlk> dbl; std::vector<SingleBlk> sgl;
     Arena2 arena; double dry_flops = 0;
+    int residual = CS_RESIDUAL_F16X2;   // cs_flux_set_residual_precision: the hidden-state stream as hi + lo planes of the model dtype (default) or one plane
 };
 
 namespace {
@@ -145,10 +146,11 @@ struct FRun {
     }
     void gemm(const Lin& L, const void* a, long lda, int M, void* out, long ldc, int col_off = 0, int act = 0, const void* res = nullptr,
               const float* gate = nullptr, long gate_stride = 0, int rows_per_sample = 0,
-              int a_seg = 0, int a_stride = 0, long a_off = 0, int c_seg = 0, int c_stride = 0, long c_off = 0) {
+              int a_seg = 0, int a_stride = 0, long a_off = 0, int c_seg = 0, int c_stride = 0, long c_off = 0, void* lo = nullptr) {
         if (dry) { f->dry_flops += 2.0 * M * (double)L.n * L.k; return; }
         if (rc != CS_OK) return;
         Gemm2Args g = gargs(L, a, lda, M, out, ldc, col_off, act, res, gate, gate_stride, rows_per_sample, a_seg, a_stride, a_off, c_seg, c_stride, c_off);
+        g.res_lo = lo; g.out_lo = lo;          // split residual stream: the lo plane is updated in place like the hi plane (out == res)
         g.dtype = dt; g.tail_ws = tail_ws; g.tail_ws_bytes = tail_ws_bytes;
         rc = launch_gemm2(g, s);
     }
@@ -163,10 +165,11 @@ struct FRun {
         if (dry) { f->dry_flops += 2.0 * Rr * (double)N * K; return; }
         if (rc == CS_OK) rc = launch_small_linear(x, Rr, K, w, b, (int)N, out, silu_in, silu_out, dt, s);
     }
-    void lnmod(const void* x, void* y, int M, int C, int rps, const float* shift, const float* scale, long stride) {
+    void lnmod(const void* x, void* y, int M, int C, int rps, const float* shift, const float* scale, long stride, const void* x_lo = nullptr) {
         if (dry || rc != CS_OK) return;
-        rc = launch_ln_modulate(x, y, M, C, rps, shift, scale, stride, 1e-6f, dt, s);
+        rc = launch_ln_modulate(x, y, M, C, rps, shift, scale, stride, 1e-6f, dt, s, x_lo);
     }
+    static Gemm2Args with_lo(Gemm2Args g, void* lo) { g.res_lo = lo; g.out_lo = lo; return g; }
     void attn(const u16* qkv, int B, int S, u16* out, long out_stride) {
         const CsFluxConfig& c = f->cfg; const int D = f->D;
         if (dry) { f->dry_flops += 4.0 * B * (double)S * S * D; return; }
@@ -197,11 +200,17 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     float* temb = (float*)Rn.alloc((size_t)B * D * 4);
     float* mod = (float*)Rn.alloc((size_t)B * f->mod_total * 4);
     u16* img = (u16*)Rn.alloc((size_t)B * I * D * e); u16* ctx = (u16*)Rn.alloc((size_t)B * T * D * e);
+    // Round 5, split residual stream: the hidden states of both streams (img / ctx, then the joint hs) carry a lo plane; every gated-residual epilogue adds hi + lo
+    // in fp32 and writes both, the adaLN LayerNorms read hi + lo.  tools/sim_precision_flux.py: at full depth the bf16 STREAM is 1.16e-2 of the forward's 1.18e-2
+    // relative error, everything else 2.5e-3.  The embedders' outputs start with lo = 0 (two of ~120 stream stores).
+    const bool split = f->residual == CS_RESIDUAL_F16X2;
+    u16* img_lo = split ? (u16*)Rn.alloc((size_t)B * I * D * e) : nullptr; u16* ctx_lo = split ? (u16*)Rn.alloc((size_t)B * T * D * e) : nullptr;
     u16* nimg = (u16*)Rn.alloc((size_t)B * I * D * e); u16* nctx = (u16*)Rn.alloc((size_t)B * T * D * e);
     u16* qkv = (u16*)Rn.alloc((size_t)B * S * 3 * D * e); u16* att = (u16*)Rn.alloc((size_t)B * S * D * e);
     u16* mlp = (u16*)Rn.alloc((size_t)B * I * 4 * D * e);            // double blocks: FF hidden of the image stream
     u16* cmlp = (u16*)Rn.alloc((size_t)B * T * 4 * D * e);           // ... and of the text stream (both FFs run in one grouped launch)
     u16* hs = (u16*)Rn.alloc((size_t)B * S * D * e); u16* nhs = (u16*)Rn.alloc((size_t)B * S * D * e);
+    u16* hs_lo = split ? (u16*)Rn.alloc((size_t)B * S * D * e) : nullptr;
     u16* cat = (u16*)Rn.alloc((size_t)B * S * 5 * D * e);
     {   // long-K launches whose last round is partly empty: image + text FF2 (K = 4 D), single-stream proj_out (K = 5 D)
         const int tD = (D + 255) / 256;
@@ -240,35 +249,42 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     else
         Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D);
     Rn.gemm(f->c_emb, enc, c.joint_attention_dim, B * T, ctx, D);
+    if (split && !dry && Rn.rc == CS_OK) {
+        hipMemsetAsync(img_lo, 0, (size_t)B * I * D * e, s); hipMemsetAsync(ctx_lo, 0, (size_t)B * T * D * e, s);
+    }
 
     // ---- double-stream blocks -----------------------------------------------------------------------------------
     for (auto& k : f->dbl) {
         const float* mi = mod + k.mod_img; const float* mc = mod + k.mod_ctx;      // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp]
-        Rn.lnmod(img, nimg, B * I, D, I, mi, mi + D, MS); Rn.lnmod(ctx, nctx, B * T, D, T, mc, mc + D, MS);
+        Rn.lnmod(img, nimg, B * I, D, I, mi, mi + D, MS, img_lo); Rn.lnmod(ctx, nctx, B * T, D, T, mc, mc + D, MS, ctx_lo);
         Rn.gemm_pair(FRun::gargs(k.qkv, nimg, D, B * I, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I, S, T),
                      FRun::gargs(k.add_qkv, nctx, D, B * T, qkv, 3 * D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, T, S, 0));
         if (!dry && Rn.rc == CS_OK)
             Rn.rc = launch_qk_norm_rope(qkv, 3 * D, B * S, S, H, dh, 0, D, k.nq, k.nk, k.naq, k.nak, T, rcos, rsin, 1e-6f, c.dtype, s);
         Rn.attn(qkv, B, S, att, D);
-        Rn.gemm_pair(FRun::gargs(k.out, att, D, B * I, img, D, 0, 0, img, mi + 2 * D, MS, I, I, S, T, 0, 0, 0),
-                     FRun::gargs(k.add_out, att, D, B * T, ctx, D, 0, 0, ctx, mc + 2 * D, MS, T, T, S, 0, 0, 0, 0));
-        Rn.lnmod(img, nimg, B * I, D, I, mi + 3 * D, mi + 4 * D, MS); Rn.lnmod(ctx, nctx, B * T, D, T, mc + 3 * D, mc + 4 * D, MS);
+        Rn.gemm_pair(FRun::with_lo(FRun::gargs(k.out, att, D, B * I, img, D, 0, 0, img, mi + 2 * D, MS, I, I, S, T, 0, 0, 0), img_lo),
+                     FRun::with_lo(FRun::gargs(k.add_out, att, D, B * T, ctx, D, 0, 0, ctx, mc + 2 * D, MS, T, T, S, 0, 0, 0, 0), ctx_lo));
+        Rn.lnmod(img, nimg, B * I, D, I, mi + 3 * D, mi + 4 * D, MS, img_lo); Rn.lnmod(ctx, nctx, B * T, D, T, mc + 3 * D, mc + 4 * D, MS, ctx_lo);
         Rn.gemm_pair(FRun::gargs(k.ff1, nimg, D, B * I, mlp, 4 * D, 0, 1, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0),
                      FRun::gargs(k.cff1, nctx, D, B * T, cmlp, 4 * D, 0, 1, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0));
-        Rn.gemm_pair(FRun::gargs(k.ff2, mlp, 4 * D, B * I, img, D, 0, 0, img, mi + 5 * D, MS, I, 0, 0, 0, 0, 0, 0),
-                     FRun::gargs(k.cff2, cmlp, 4 * D, B * T, ctx, D, 0, 0, ctx, mc + 5 * D, MS, T, 0, 0, 0, 0, 0, 0));
+        Rn.gemm_pair(FRun::with_lo(FRun::gargs(k.ff2, mlp, 4 * D, B * I, img, D, 0, 0, img, mi + 5 * D, MS, I, 0, 0, 0, 0, 0, 0), img_lo),
+                     FRun::with_lo(FRun::gargs(k.cff2, cmlp, 4 * D, B * T, ctx, D, 0, 0, ctx, mc + 5 * D, MS, T, 0, 0, 0, 0, 0, 0), ctx_lo));
     }
     // ---- joint sequence [context | image] ---------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK) {
         for (int b = 0; b < B; ++b) {
             hipMemcpyAsync(hs + ((size_t)b * S) * D, ctx + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s);
             hipMemcpyAsync(hs + ((size_t)b * S + T) * D, img + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s);
+            if (split) {
+                hipMemcpyAsync(hs_lo + ((size_t)b * S) * D, ctx_lo + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s);
+                hipMemcpyAsync(hs_lo + ((size_t)b * S + T) * D, img_lo + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s);
+            }
         }
     }
     // ---- single-stream blocks ---------------------------------------------------------------------------------------------
     for (auto& k : f->sgl) {
         const float* m = mod + k.mod;                                             // [shift, scale, gate]
-        Rn.lnmod(hs, nhs, B * S, D, S, m, m + D, MS);
+        Rn.lnmod(hs, nhs, B * S, D, S, m, m + D, MS, hs_lo);
         // fused [q | k | v | mlp] projection: qkv part -> qkv buffer, GELU(mlp) part -> columns D.. of `cat`
         Lin lq = k.qkv_mlp; lq.n = 3 * D;
         Rn.gemm(lq, nhs, D, B * S, qkv, 3 * D);
@@ -277,14 +293,16 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
         if (!dry && Rn.rc == CS_OK)
             Rn.rc = launch_qk_norm_rope(qkv, 3 * D, B * S, S, H, dh, 0, D, k.nq, k.nk, nullptr, nullptr, 0, rcos, rsin, 1e-6f, c.dtype, s);
         Rn.attn(qkv, B, S, cat, 5 * D);
-        Rn.gemm(k.out, cat, 5 * D, B * S, hs, D, 0, 0, hs, m + 2 * D, MS, S);
+        Rn.gemm(k.out, cat, 5 * D, B * S, hs, D, 0, 0, hs, m + 2 * D, MS, S, 0, 0, 0, 0, 0, 0, hs_lo);
     }
     // ---- output head on the image tokens ----------------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK)
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < B; ++b) {
             hipMemcpyAsync(img + (size_t)b * I1 * D, hs + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s);
+            if (split) hipMemcpyAsync(img_lo + (size_t)b * I1 * D, hs_lo + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s);
+        }
     const float* mf = mod + f->mod_final;                                         // AdaLayerNormContinuous: [scale, shift]
-    Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS);
+    Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS, img_lo);
     Rn.gemm(f->proj_out, nimg, D, B * I1, out, c.in_channels);
     return Rn.rc;
 }
@@ -424,6 +442,14 @@ int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len
     return flux_forward(f, false, hidden_states, batch, img_len, encoder_hidden_states, txt_len, pooled_f32, timestep, guidance, rope_cos, rope_sin, out,
                         (char*)workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+int cs_flux_set_residual_precision(CsFlux* f, int mode) {
+    if (!f) CS_FAIL(CS_E_ARG, "flux is NULL");
+    if (mode != CS_RESIDUAL_F16 && mode != CS_RESIDUAL_F16X2) CS_FAIL(CS_E_ARG, "residual precision %d: CS_RESIDUAL_F16 (0, one plane) or CS_RESIDUAL_F16X2 (1, hi + lo planes)", mode);
+    f->residual = mode;
+    return CS_OK;
+}
+int cs_flux_get_residual_precision(const CsFlux* f) { return f ? f->residual : -1; }
 
 int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const void* image_latents, int image_len, int batch,
                           const void* encoder_hidden_states, int txt_len, const float* pooled_f32, const float* timestep, const float* guidance,

@@ -7,9 +7,11 @@
 namespace {
 
 // y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; one wave per token row, row kept in registers
-template <typename T, int MAXV>
+// SPLIT: x is a split residual stream (value = x + x_lo, two planes of T)
+template <typename T, int MAXV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict__ x, u16* __restrict__ y, int M, int C, int rows_per_sample,
-                                                          const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride, float eps) {
+                                                          const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride, float eps,
+                                                          const u16* __restrict__ x_lo = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + w;
     if (row >= M) return;
@@ -23,6 +25,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict_
             const u32x4 t = *reinterpret_cast<const u32x4*>(x + (size_t)row * C + cv * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[j][2 * k] = El<T>::tof((u16)(t[k] & 0xffff)); v[j][2 * k + 1] = El<T>::tof((u16)(t[k] >> 16)); }
+            if constexpr (SPLIT) {
+                const u32x4 t2 = *reinterpret_cast<const u32x4*>(x_lo + (size_t)row * C + cv * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[j][2 * k] += El<T>::tof((u16)(t2[k] & 0xffff)); v[j][2 * k + 1] += El<T>::tof((u16)(t2[k] >> 16)); }
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) sum += v[j][k];
         } else {
@@ -204,13 +211,14 @@ template <typename T> __global__ void cast_kernel(const float* x, u16* out, long
 }  // namespace
 
 int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
-                       float eps, int dtype, hipStream_t s) {
+                       float eps, int dtype, hipStream_t s, const void* x_lo) {
     if (!x || !y || !shift || !scale) CS_FAIL(CS_E_ARG, "ln_modulate: null pointer");
     if (C % 8 || C > 8 * 64 * 8) CS_FAIL(CS_E_SHAPE, "ln_modulate: C=%d unsupported", C);
     if (M <= 0) return CS_OK;
     const dim3 grid((M + 3) / 4), block(256);
     const int nv = (C / 8 + 63) / 64;
-#define LNM(T, V) hipLaunchKernelGGL((ln_modulate_kernel<T, V>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps)
+#define LNM(T, V) do { if (x_lo) hipLaunchKernelGGL((ln_modulate_kernel<T, V, true>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps, (const u16*)x_lo); \
+                       else hipLaunchKernelGGL((ln_modulate_kernel<T, V, false>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps, (const u16*)nullptr); } while (0)
     if (dtype == CS_BF16) { if (nv <= 1) LNM(bf16_el, 1); else if (nv <= 2) LNM(bf16_el, 2); else if (nv <= 4) LNM(bf16_el, 4); else if (nv <= 6) LNM(bf16_el, 6); else LNM(bf16_el, 8); }
     else if (dtype == CS_F16) { if (nv <= 1) LNM(f16, 1); else if (nv <= 2) LNM(f16, 2); else if (nv <= 4) LNM(f16, 4); else if (nv <= 6) LNM(f16, 6); else LNM(f16, 8); }
     else CS_FAIL(CS_E_DTYPE, "ln_modulate: dtype");

@@ -30,6 +30,7 @@ struct G2Params {
     const u16* w; const u16* bias;
     int M, N, K, KT;
     u16* out; const u16* res; long ldc; int c_col; int c_seg, c_stride; long c_off;
+    const u16* res_lo; u16* out_lo;          // split residual stream (Gemm2Args::res_lo / out_lo) or null
     const float* gate; long gate_stride; int rows_per_sample;   // fp32 adaLN gate [B][gate_stride]
     int act;
     int tiles_m, tiles_n, nblk;
@@ -107,7 +108,9 @@ constexpr int g2_wait_count(int q, int NQ, int LA, int MT, int QB) {
 // q = (k half, weight tile) of 4 MFMAs, 16 per step; weight fragments through a 4-slot ring 3 items ahead; the step's barrier in front of item 13 with all of the
 // stage's fragments in registers; pieces 0..2 of stage kt + 2 go out with items 13..15 (their buffer is free behind the barrier), pieces 3..7 with items 0..4 of
 // the next step, vmcnt(0) in front of the next barrier.  Needs 32-bit byte offsets into A and W and no k split (the split-K tail keeps the other loop).
-template <typename T, int ACT, bool W8 = false>
+// X2 (round 5): the gated-residual epilogue on a split residual stream (res_lo / out_lo): a separate instantiation, not a runtime branch (a load under a branch is
+// waited for with vmcnt(0) at the join, and code that never runs still taxes the register allocation of the k loop: DESIGN section 8, round 4).
+template <typename T, int ACT, bool W8 = false, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
     constexpr int BMX = 256, BNX = 256, NT = 8, MT = 4;
     constexpr int A_BYTES = BMX * BK * 2, B_BYTES = BNX * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -372,10 +375,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
             off[k] = (size_t)rowmap(ok[k] ? m : 0, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + (n_ok ? n : 0);
         }
         if (p.res || p.gate) {
-            u32x4 rv[CH];
+            u32x4 rv[CH], rvl[X2 ? CH : 1];
             if (p.res) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) rv[k] = *reinterpret_cast<const u32x4*>(p.res + off[k]);
+            }
+            if constexpr (X2) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) rvl[k] = *reinterpret_cast<const u32x4*>(p.res_lo + off[k]);
             }
             f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
             if (p.gate && one_sample && n_ok) {
@@ -400,10 +407,21 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rv[k][r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rv[k][r] >> 16)); }
                 }
+                if constexpr (X2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rvl[k][r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rvl[k][r] >> 16)); }
+                }
                 u32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (unsigned)El<T>::fromf(f[2 * r]) | ((unsigned)El<T>::fromf(f[2 * r + 1]) << 16);
                 if (ok[k]) *reinterpret_cast<u32x4*>(p.out + off[k]) = o;
+                if constexpr (X2) {          // lo = T(value - float(hi)): hi + lo carries twice the significand
+                    u32x4 l;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        l[r] = (unsigned)El<T>::fromf(f[2 * r] - El<T>::tof((u16)(o[r] & 0xffff))) | ((unsigned)El<T>::fromf(f[2 * r + 1] - El<T>::tof((u16)(o[r] >> 16))) << 16);
+                    if (ok[k]) *reinterpret_cast<u32x4*>(p.out_lo + off[k]) = l;
+                }
             }
         } else {
 #pragma unroll
@@ -458,10 +476,22 @@ __global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(rv[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(rv[k] >> 16)); }
     }
+    if (p.res_lo) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res_lo + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(rv[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(rv[k] >> 16)); }
+    }
     u32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (unsigned)El<T>::fromf(f[2 * k]) | ((unsigned)El<T>::fromf(f[2 * k + 1]) << 16);
     *reinterpret_cast<u32x4*>(p.out + off) = o;
+    if (p.out_lo) {
+        u32x4 l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            l[k] = (unsigned)El<T>::fromf(f[2 * k] - El<T>::tof((u16)(o[k] & 0xffff))) | ((unsigned)El<T>::fromf(f[2 * k + 1] - El<T>::tof((u16)(o[k] >> 16))) << 16);
+        *reinterpret_cast<u32x4*>(p.out_lo + off) = l;
+    }
 }
 
 // tiny-M linear: out[r][n] = act(sum_k x[r][k] w[n][k] + b[n]); x/out fp32, weights T.  One wave per n.
@@ -503,7 +533,10 @@ static int g2_fill(const Gemm2Args& a, G2Params& p) {
     if (a.gate && a.rows_per_sample <= 0) CS_FAIL(CS_E_ARG, "gemm2: rows_per_sample required with gate");
     p.a = (const u16*)a.a; p.lda = a.lda ? a.lda : a.K; p.a_seg = a.a_seg_rows; p.a_stride = a.a_seg_stride; p.a_off = a.a_row_off;
     p.w = (const u16*)a.w; p.bias = (const u16*)a.bias; p.M = a.M; p.N = a.N; p.K = a.K; p.KT = a.K / BK;
+    if ((a.res_lo == nullptr) != (a.out_lo == nullptr) || (a.res_lo && !a.res)) CS_FAIL(CS_E_ARG, "gemm2: res_lo and out_lo go together and need res");
+    if (a.res_lo && a.act != 0) CS_FAIL(CS_E_ARG, "gemm2: the split residual stream excludes an activation");
     p.out = (u16*)a.out; p.res = (const u16*)a.res; p.ldc = a.ldc ? a.ldc : a.N; p.c_col = a.c_col_off;
+    p.res_lo = (const u16*)a.res_lo; p.out_lo = (u16*)a.out_lo;
     p.c_seg = a.c_seg_rows; p.c_stride = a.c_seg_stride; p.c_off = a.c_row_off;
     p.gate = (const float*)a.gate; p.gate_stride = a.gate_stride; p.rows_per_sample = a.rows_per_sample; p.act = a.act;
     p.tiles_n = (a.N + 255) / 256;            // the packed weight has tiles_n * 256 rows (zero padded)
@@ -530,6 +563,20 @@ static int g2_launch_t(const G2Pair& pp, hipStream_t s, dim3 grid) {
         configured = true;
     }
     const bool w8 = g_tune_gemm2_w8 && pp.splits == 1 && g2_fits32(pp.p[0]) && g2_fits32(pp.p[1]);
+    if constexpr (ACT == 0) {
+        if (pp.p[0].out_lo) {                 // split residual stream (both problems of a pair: g2_run checks)
+            static bool configured2 = false;
+            if (!configured2) {
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, 0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                configured2 = true;
+            }
+            if (w8) hipLaunchKernelGGL((gemm2_kernel<T, 0, true, true>), grid, dim3(512), lds, s, pp);
+            else hipLaunchKernelGGL((gemm2_kernel<T, 0, false, true>), grid, dim3(512), lds, s, pp);
+            CS_CHECK_LAUNCH();
+            return CS_OK;
+        }
+    }
     if (w8) hipLaunchKernelGGL((gemm2_kernel<T, ACT, true>), grid, dim3(512), lds, s, pp);
     else hipLaunchKernelGGL((gemm2_kernel<T, ACT, false>), grid, dim3(512), lds, s, pp);
     CS_CHECK_LAUNCH();
@@ -600,7 +647,7 @@ int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) {
     if (a.dtype != b.dtype) CS_FAIL(CS_E_DTYPE, "gemm2 pair: both problems must have the same dtype");
     if (a.M <= 0 || a.N <= 0) return launch_gemm2(b, s);
     if (b.M <= 0 || b.N <= 0) return launch_gemm2(a, s);
-    if (a.act != b.act) { const int r = launch_gemm2(a, s); return r != CS_OK ? r : launch_gemm2(b, s); }
+    if (a.act != b.act || (a.out_lo == nullptr) != (b.out_lo == nullptr)) { const int r = launch_gemm2(a, s); return r != CS_OK ? r : launch_gemm2(b, s); }
     G2Pair pp{};
     int rc = g2_fill(a, pp.p[0]);
     if (rc == CS_OK) rc = g2_fill(b, pp.p[1]);

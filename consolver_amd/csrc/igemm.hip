@@ -1559,49 +1559,101 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const f16* __restrict__ 
     if (lane == 0) { stats[2 * (size_t)row] = s1; stats[2 * (size_t)row + 1] = s2; }
 }
 
-// out = sum_s partial[s] + bias + temb + res  (8 channels per thread)
+// out = sum_s partial[s] + bias + temb + res  (8 channels per thread): one (row m, 8-channel chunk n) item; returns the fp16 values stored to the hi plane
+__device__ __forceinline__ f16x8 splitk_reduce_item(const IgemmParams& p, const float* __restrict__ partial, int splits, int m, int n) {
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < splits; ++s) {
+        const float* src = partial + ((size_t)s * p.M + m) * p.N + n;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+    }
+    if (p.ln_stats) {                                      // LayerNorm folded into this GEMM (see igemm_epilogue_impl)
+        float s1 = 0.f, s2 = 0.f;
+        const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
+        ln_row_moments(st, p.ln_groups, s1, s2);
+        const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps), mr = mean * rstd;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], rstd, __builtin_fmaf(-mr, p.ln_s[n + k], p.ln_b[n + k]));
+    } else if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+    if (p.temb) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+    if (p.res) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.N + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+    if (p.res && p.res_lo) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res_lo + (size_t)m * p.N + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
+    *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
+    if (p.out_lo) {
+        f16x8 l;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l[k] = (f16)(v[k] - (float)o[k]);
+        *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * p.N + n) = l;
+    }
+    return o;
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, const float* __restrict__ partial, int splits) {
     const int NV = p.N >> 3;
     const long total = (long)p.M * NV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / NV), n = (int)(i - (long)m * NV) * 8;
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < splits; ++s) {
-            const float* src = partial + ((size_t)s * p.M + m) * p.N + n;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
-        }
-        if (p.ln_stats) {                                      // LayerNorm folded into this GEMM (see igemm_epilogue_impl)
-            float s1 = 0.f, s2 = 0.f;
-            const float* st = p.ln_stats + (size_t)m * p.ln_groups * 2;
-            ln_row_moments(st, p.ln_groups, s1, s2);
-            const float mean = s1 * p.ln_inv_c, rstd = __builtin_amdgcn_rsqf(fmaxf(__builtin_fmaf(-mean, mean, s2 * p.ln_inv_c), 0.f) + p.ln_eps), mr = mean * rstd;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], rstd, __builtin_fmaf(-mr, p.ln_s[n + k], p.ln_b[n + k]));
-        } else if (p.bias) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.bias + n);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
-        if (p.temb) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.temb + (size_t)(m / p.HoWo) * p.temb_stride + n);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
-        if (p.res) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.N + n);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
-        if (p.res && p.res_lo) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res_lo + (size_t)m * p.N + n);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
-        f16x8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
-        *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
-        if (p.out_lo) {
-            f16x8 l;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) l[k] = (f16)(v[k] - (float)o[k]);
-            *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * p.N + n) = l;
-        }
+        splitk_reduce_item(p, partial, splits, m, n);
     }
+}
+
+// Round 5, the 8 x 8 level (64 pixels per sample = ONE statistics slot): the reduce also leaves the GroupNorm statistics of its output, in the layout the conv
+// epilogues write (gn_stats[B][1][N / 2][2] = (sum, sum of squares) of channel pairs over the sample's 64 rows, from the fp16 values of the hi plane).  The split-K
+// layers had a gn_stats_kernel launch behind every reduce (16 per UNet forward, 10 us each).  A workgroup owns 64 rows (one sample) x 32 channels: thread = (row, chunk of
+// 8 channels); rows are reduced by wave shuffles (a wave holds 16 rows x 4 chunks) and across the four waves through LDS.  Deterministic (fixed order).
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(IgemmParams p, const float* __restrict__ partial, int splits, float* __restrict__ gn_stats) {
+    __shared__ float red[4][4][16];                       // [wave][chunk][8 sums | 8 sums of squares]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int row = t >> 2, chunk = t & 3;
+    const int b = blockIdx.y, n = blockIdx.x * 32 + chunk * 8, m = b * 64 + row;
+    const f16x8 o = splitk_reduce_item(p, partial, splits, m, n);
+    float sm[8], sq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float f = (float)o[k]; sm[k] = f; sq[k] = f * f; }
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sm[k] += __shfl_xor(sm[k], off, 64); sq[k] += __shfl_xor(sq[k], off, 64); }
+    if (lane < 4) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { red[w][lane][k] = sm[k]; red[w][lane][8 + k] = sq[k]; }
+    }
+    __syncthreads();
+    if (t < 16) {                                         // 16 channel pairs of the workgroup's 32 channels: pair t = chunk t >> 2, channels 2 (t & 3), 2 (t & 3) + 1
+        const int c = t >> 2, k = 2 * (t & 3);
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { a += red[ww][c][k] + red[ww][c][k + 1]; q += red[ww][c][8 + k] + red[ww][c][8 + k + 1]; }
+        *reinterpret_cast<f32x2*>(gn_stats + ((size_t)b * (p.N >> 1) + (blockIdx.x * 16 + t)) * 2) = f32x2{a, q};
+    }
+}
+
+// the reduce behind a split-K launch.  With p.gn_stats set (statistics wanted and allowed: launch_igemm_impl) and one 64-row statistics slot per sample it also
+// leaves the GroupNorm statistics: reduce_leaves_stats(p) tells the caller that no statistics pass is needed.
+static bool reduce_leaves_stats(const IgemmParams& p) { return p.gn_stats && p.HoWo == 64 && p.M % 64 == 0 && p.N % 32 == 0 && !(p.debug & 64); }      // (debug bit 64: A/B against the statistics pass)
+static int launch_splitk_reduce(const IgemmParams& p, const float* partial, int splits, hipStream_t s) {
+    if (reduce_leaves_stats(p)) {
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(p.N / 32, p.M / 64), dim3(256), 0, s, p, partial, splits, p.gn_stats);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
+    const long total = (long)p.M * (p.N / 8);
+    int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid2), dim3(256), 0, s, p, partial, splits);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1934,12 +1986,7 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
     }
     hipLaunchKernelGGL(kfn, dim3(p.nblk, splits), dim3(256), lds, s, p);
     CS_CHECK_LAUNCH();
-    if (splits > 1) {
-        const long total = (long)p.M * (p.N / 8);
-        int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid2), dim3(256), 0, s, p, (const float*)p.partial, splits);
-        CS_CHECK_LAUNCH();
-    }
+    if (splits > 1) return launch_splitk_reduce(p, (const float*)p.partial, splits, s);
     return CS_OK;
 }
 
@@ -2123,13 +2170,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
             else rc = a.upsample ? launch_halo<true, 128, 1>(h, grid, l, s) : launch_halo<false, 128, 1>(h, grid, l, s);
             if (rc != CS_OK) return rc;
             CS_CHECK_LAUNCH();
-            li->gn_done = stats_ok && splits == 1;
-            if (splits > 1) {
-                const long total = (long)p.M * (p.N / 8);
-                int grid2 = (int)((total + 255) / 256); if (grid2 > 2048) grid2 = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid2), dim3(256), 0, s, h.e, (const float*)a.splitk_ws, splits);
-                CS_CHECK_LAUNCH();
-            }
+            li->gn_done = stats_ok && (splits == 1 || reduce_leaves_stats(h.e));
+            if (splits > 1) return launch_splitk_reduce(h.e, (const float*)a.splitk_ws, splits, s);
             return CS_OK;
         }
     }
@@ -2210,7 +2252,7 @@ generic_tiles:
                (size_t)(splits * 2) * p.M * a.N * sizeof(float) <= a.splitk_ws_bytes) splits *= 2;
         if (splits > 1) p.partial = a.splitk_ws;
     }
-    li->gn_done = stats_ok && splits == 1;
+    li->gn_done = stats_ok && (splits == 1 || reduce_leaves_stats(p));
     li->row_groups = (splits == 1 && !conv3) ? a.N / (bn / 2) : 0;          // igemm_kernel: 64 x bn / 2 wave tiles; the split-K reduce leaves no row statistics
     if (conv3) return bn == 128 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<160, true, false>(p, s, splits);
     const int lk = splits > 1 ? 0 : lnm;            // (split-K: raw partial sums leave the main kernel; the reduce kernel applies a folded LayerNorm itself)

@@ -120,6 +120,9 @@ struct Gemm2Args {
     int act;                               // 0 none, 1 GELU(tanh)
     int dtype;
     void* tail_ws; size_t tail_ws_bytes;   // optional scratch for the split-K tail (gemm2_tail_workspace_bytes)
+    // optional split residual stream (round 5; FLUX hidden states as hi + lo planes of the model dtype, value = hi + lo): res_lo is added with res in fp32,
+    // out_lo receives what the 16-bit store of out dropped.  Same addressing as res / out (ldc, column offset, segment map).  Both or neither; needs res.
+    const void* res_lo; void* out_lo;
 };
 int launch_gemm2(const Gemm2Args& a, hipStream_t s);
 size_t gemm2_tail_workspace_bytes(int tiles, int K);   // tiles = 256 x 256 output tiles of the launch (both problems of a pair); 0: never splits
@@ -128,8 +131,9 @@ int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s);
 int launch_small_linear(const float* x, int R, int K, const void* w, const void* bias, int N, float* out, int silu_in, int silu_out,
                         int dtype, hipStream_t s);
 // y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b] ; x,y [M][C] (dtype), scale/shift fp32 rows of stride mod_stride
+// x_lo: optional lo plane of a split stream (value = x + x_lo)
 int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
-                       float eps, int dtype, hipStream_t s);
+                       float eps, int dtype, hipStream_t s, const void* x_lo = nullptr);
 // in place on a fused qkv buffer [S_total rows][ld]: per head RMSNorm(q) * wq, RMSNorm(k) * wk, then RoPE (pairs) with cos/sin [S][dh/2]
 int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col, const void* wq, const void* wk,
                         const void* wq_ctx, const void* wk_ctx, int ctx_rows, const float* cosv, const float* sinv, float eps, int dtype,

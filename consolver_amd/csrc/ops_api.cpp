@@ -224,6 +224,18 @@ int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, in
     return launch_gemm2(g, (hipStream_t)stream);
 }
 
+int cs_op_gemm2_x2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo, const float* gate, long gate_stride,
+                   int rows_per_sample, void* out, void* out_lo, int dtype, void* tail_ws, size_t tail_ws_bytes, void* stream) {
+    Gemm2Args g{};
+    g.a = x; g.lda = K; g.w = w; g.bias = bias; g.M = M; g.N = N; g.K = K; g.out = out; g.res = res; g.ldc = N; g.res_lo = res_lo; g.out_lo = out_lo;
+    g.gate = gate; g.gate_stride = gate_stride; g.rows_per_sample = rows_per_sample; g.act = 0; g.dtype = dtype; g.tail_ws = tail_ws; g.tail_ws_bytes = tail_ws_bytes;
+    return launch_gemm2(g, (hipStream_t)stream);
+}
+int cs_op_ln_modulate_x2(const void* x, const void* x_lo, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride, float eps,
+                         int dtype, void* stream) {
+    return launch_ln_modulate(x, y, M, C, rows_per_sample, shift, scale, mod_stride, eps, dtype, (hipStream_t)stream, x_lo);
+}
+
 size_t cs_op_attention_workspace(int B, int H, int Nq, int Nk, int dh) { return attention_split_workspace_bytes(B, H, Nq, Nk, dh); }
 int cs_op_attention_ws(const void* q, int q_stride, const void* k, int k_stride, const void* v, int v_stride, void* out, int out_stride,
                        int B, int H, int Nq, int Nk, int dh, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream) {

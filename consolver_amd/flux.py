@@ -71,7 +71,11 @@ def rope_tables(ids, axes_dims, theta=10000.0):
 class HipFluxTransformer2DModel:
     is_consolver_hip = True
 
-    def __init__(self, config=None, device="cuda:0"):
+    RESIDUAL_MODES = {"plain": 0, "bf16": 0, "f16": 0, "split": 1, "bf16x2": 1, "f16x2": 1}
+
+    def __init__(self, config=None, device="cuda:0", residual="split"):
+        """``residual``: storage of the hidden-state stream between kernels (include/consolver_hip.h, cs_flux_set_residual_precision): ``"split"`` (default: hi + lo
+        planes of the model dtype, fp32-class adds along the 57-block stream) or ``"plain"`` (one plane: the reference bf16 pipeline's own arithmetic class)."""
         cfg = _Config(FLUX_KONTEXT_CONFIG)
         cfg.update(config or {})
         self.config = cfg
@@ -92,6 +96,17 @@ class HipFluxTransformer2DModel:
         self._ws = None
         self._ws_key = None
         self._rope = {}
+        self.residual = "split"
+        if residual != "split":
+            self.set_residual_precision(residual)
+
+    def set_residual_precision(self, mode):
+        if mode not in self.RESIDUAL_MODES:
+            raise ValueError(f"residual must be one of {sorted(self.RESIDUAL_MODES)}, got {mode!r}")
+        L.check(L.lib().cs_flux_set_residual_precision(self._h, self.RESIDUAL_MODES[mode]))
+        self.residual = "split" if self.RESIDUAL_MODES[mode] else "plain"
+        self._ws, self._ws_key = None, None          # the workspace size depends on the mode
+        return self
 
     def __del__(self):
         try:

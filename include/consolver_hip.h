@@ -260,6 +260,14 @@ int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const voi
                           const float* guidance, const float* rope_cos, const float* rope_sin, void* out, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Storage of the DiT's hidden-state (residual) stream between kernels, as for the UNet (CS_RESIDUAL_* above): CS_RESIDUAL_F16X2 (default) keeps the image / text /
+ * joint hidden states as two planes of the model dtype (value = hi + lo): the 57 + 38 gated-residual epilogues add in fp32 and write both planes, the adaLN
+ * LayerNorms read both; every GEMM operand stays a plain 16-bit tensor.  CS_RESIDUAL_F16: one plane -- the reference bf16 pipeline's own arithmetic class.  At
+ * full depth (19 + 38 blocks, bf16) the one-plane stream is 1.16e-2 of the forward's 1.2e-2 relative error against an fp32 evaluation (tools/sim_precision_flux.py).
+ * Changes the workspace size: query cs_flux_workspace_bytes after switching. */
+int cs_flux_set_residual_precision(CsFlux* f, int mode);
+int cs_flux_get_residual_precision(const CsFlux* f);
+
 /* ------------------------------------------------------------------------
  * AutoencoderKL decoder (SD1.5 VAE): latents -> images.  Replaces
  * `vae.decode(latents / vae.config.scaling_factor).sample` and the

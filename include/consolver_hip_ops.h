@@ -114,6 +114,15 @@ int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, 
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
 int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
                 int rows_per_sample, int act, void* out, long ldc, int col_off, int dtype, void* stream);
+/* cs_op_gemm2's gated-residual form on a SPLIT residual stream (round 5; FLUX hidden states as hi + lo planes of the model dtype, value = hi + lo):
+ * out + out_lo = (res + res_lo) + gate * T(x . w + bias), the sum taken in fp32; out_lo = T(value - float(out)).  res / res_lo / out / out_lo are [M][N]; out may
+ * alias res and out_lo res_lo.  tail_ws: optional split-K tail scratch (cs_op_gemm2_workspace).  Replaces `hidden_states = hidden_states + gate * attn_output` and
+ * its three siblings in diffusers' FluxTransformerBlock / FluxSingleTransformerBlock (call site edit_ppo/pipeline.py:1087-1097). */
+int cs_op_gemm2_x2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo, const float* gate, long gate_stride,
+                   int rows_per_sample, void* out, void* out_lo, int dtype, void* tail_ws, size_t tail_ws_bytes, void* stream);
+/* y = LayerNorm_noaffine(x + x_lo) * (1 + scale[b]) + shift[b]: the adaLN LayerNorm reading a split stream (x_lo = NULL: one plane) */
+int cs_op_ln_modulate_x2(const void* x, const void* x_lo, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride, float eps,
+                         int dtype, void* stream);
 /* Grouped form: two independent cs_op_gemm2 problems of the same dtype in ONE launch (problem b's tiles are appended to problem a's tile
  * list).  FLUX's double-stream blocks (reference: diffusers FluxTransformerBlock, called from FLUX/train_ppo_flux.py:150-163 through
  * pipe.transformer) run the image-token and the text-token linear of each stage this way. */

@@ -60,6 +60,9 @@ class FluxOracle:
         self.device, self.dtype = torch.device(device), dtype
         self.sd = _Fp32View(sd, self.device, dtype) if lazy else {k: v.to(self.device, dtype) for k, v in sd.items()}
         self.D = config["num_heads"] * config["head_dim"]
+        # precision emulation (tools/sim_precision_flux.py): rs rounds the residual STREAM after every update, rb the BRANCH tensors (modulated LayerNorm outputs,
+        # q / k / v, attention output, MLP activations, the linear outputs that are added onto the stream) -- identity in the oracle
+        self.rs = self.rb = (lambda t: t)
 
     def _in(self, x):
         return torch.as_tensor(x).to(self.device, self.dtype)
@@ -86,8 +89,8 @@ class FluxOracle:
     @torch.no_grad()
     def __call__(self, hidden_states, timestep, guidance, pooled, enc, txt_ids, img_ids):
         cfg, D = self.cfg, self.D
-        x = self.lin(self._in(hidden_states), "x_embedder")
-        c = self.lin(self._in(enc), "context_embedder")
+        x = self.rs(self.lin(self._in(hidden_states), "x_embedder"))
+        c = self.rs(self.lin(self._in(enc), "context_embedder"))
         tt = "time_text_embed."
         temb = self.lin(F.silu(self.lin(self._in(sinusoid(timestep.float().cpu() * 1000)), tt + "timestep_embedder.linear_1")), tt + "timestep_embedder.linear_2")
         if cfg["guidance_embeds"]:
@@ -102,34 +105,36 @@ class FluxOracle:
             b = f"transformer_blocks.{i}"
             m = self.lin(silu_t, b + ".norm1.linear")[:, None].chunk(6, dim=-1)
             mc = self.lin(silu_t, b + ".norm1_context.linear")[:, None].chunk(6, dim=-1)
-            nx = ln(x) * (1 + m[1]) + m[0]
-            nc = ln(c) * (1 + mc[1]) + mc[0]
-            q = self.rms(self.heads(self.lin(nx, b + ".attn.to_q")), b + ".attn.norm_q")
-            k = self.rms(self.heads(self.lin(nx, b + ".attn.to_k")), b + ".attn.norm_k")
-            v = self.heads(self.lin(nx, b + ".attn.to_v"))
-            cq = self.rms(self.heads(self.lin(nc, b + ".attn.add_q_proj")), b + ".attn.norm_added_q")
-            ck = self.rms(self.heads(self.lin(nc, b + ".attn.add_k_proj")), b + ".attn.norm_added_k")
-            cv = self.heads(self.lin(nc, b + ".attn.add_v_proj"))
+            rs, rb = self.rs, self.rb
+            nx = rb(ln(x) * (1 + m[1]) + m[0])
+            nc = rb(ln(c) * (1 + mc[1]) + mc[0])
+            q = self.rms(self.heads(rb(self.lin(nx, b + ".attn.to_q"))), b + ".attn.norm_q")
+            k = self.rms(self.heads(rb(self.lin(nx, b + ".attn.to_k"))), b + ".attn.norm_k")
+            v = self.heads(rb(self.lin(nx, b + ".attn.to_v")))
+            cq = self.rms(self.heads(rb(self.lin(nc, b + ".attn.add_q_proj"))), b + ".attn.norm_added_q")
+            ck = self.rms(self.heads(rb(self.lin(nc, b + ".attn.add_k_proj"))), b + ".attn.norm_added_k")
+            cv = self.heads(rb(self.lin(nc, b + ".attn.add_v_proj")))
             q, k, v = torch.cat([cq, q], 2), torch.cat([ck, k], 2), torch.cat([cv, v], 2)
-            a = self.attn(apply_rope(q, cos, sin), apply_rope(k, cos, sin), v)
+            a = rb(self.attn(rb(apply_rope(q, cos, sin)), rb(apply_rope(k, cos, sin)), v))
             ca, xa = a[:, :T], a[:, T:]
-            x = x + m[2] * self.lin(xa, b + ".attn.to_out.0")
-            c = c + mc[2] * self.lin(ca, b + ".attn.to_add_out")
-            nx = ln(x) * (1 + m[4]) + m[3]
-            x = x + m[5] * self.lin(F.gelu(self.lin(nx, b + ".ff.net.0.proj"), approximate="tanh"), b + ".ff.net.2")
-            nc = ln(c) * (1 + mc[4]) + mc[3]
-            c = c + mc[5] * self.lin(F.gelu(self.lin(nc, b + ".ff_context.net.0.proj"), approximate="tanh"), b + ".ff_context.net.2")
+            x = rs(x + m[2] * self.lin(xa, b + ".attn.to_out.0"))
+            c = rs(c + mc[2] * self.lin(ca, b + ".attn.to_add_out"))
+            nx = rb(ln(x) * (1 + m[4]) + m[3])
+            x = rs(x + m[5] * self.lin(rb(F.gelu(self.lin(nx, b + ".ff.net.0.proj"), approximate="tanh")), b + ".ff.net.2"))
+            nc = rb(ln(c) * (1 + mc[4]) + mc[3])
+            c = rs(c + mc[5] * self.lin(rb(F.gelu(self.lin(nc, b + ".ff_context.net.0.proj"), approximate="tanh")), b + ".ff_context.net.2"))
         h = torch.cat([c, x], dim=1)
         for i in range(cfg["num_single_layers"]):
             b = f"single_transformer_blocks.{i}"
             m = self.lin(silu_t, b + ".norm.linear")[:, None].chunk(3, dim=-1)
-            n = ln(h) * (1 + m[1]) + m[0]
-            mlp = F.gelu(self.lin(n, b + ".proj_mlp"), approximate="tanh")
-            q = self.rms(self.heads(self.lin(n, b + ".attn.to_q")), b + ".attn.norm_q")
-            k = self.rms(self.heads(self.lin(n, b + ".attn.to_k")), b + ".attn.norm_k")
-            v = self.heads(self.lin(n, b + ".attn.to_v"))
-            a = self.attn(apply_rope(q, cos, sin), apply_rope(k, cos, sin), v)
-            h = h + m[2] * self.lin(torch.cat([a, mlp], dim=2), b + ".proj_out")
+            rs, rb = self.rs, self.rb
+            n = rb(ln(h) * (1 + m[1]) + m[0])
+            mlp = rb(F.gelu(self.lin(n, b + ".proj_mlp"), approximate="tanh"))
+            q = self.rms(self.heads(rb(self.lin(n, b + ".attn.to_q"))), b + ".attn.norm_q")
+            k = self.rms(self.heads(rb(self.lin(n, b + ".attn.to_k"))), b + ".attn.norm_k")
+            v = self.heads(rb(self.lin(n, b + ".attn.to_v")))
+            a = rb(self.attn(rb(apply_rope(q, cos, sin)), rb(apply_rope(k, cos, sin)), v))
+            h = rs(h + m[2] * self.lin(torch.cat([a, mlp], dim=2), b + ".proj_out"))
         x = h[:, T:]
         sc, sh = self.lin(silu_t, "norm_out.linear")[:, None].chunk(2, dim=-1)
         x = ln(x) * (1 + sc) + sh

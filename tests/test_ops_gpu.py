@@ -386,7 +386,10 @@ GN_FUSE_CASES = [
     (4, 8, 320, 0, 320, 9, 1, False, False, True),     # 8 x 8 images: four per tile, one per wave
     (2, 16, 64, 0, 320, 9, 1, True, False, False),     # fused x2 upsample (32 x 32 out)
     (2, 32, 128, 0, 128, 9, 2, False, False, False),   # stride-2 downsample: generic kernel
-    (8, 8, 1280, 0, 320, 9, 1, False, False, True),    # split-K form: statistics pass fallback
+    (8, 8, 1280, 0, 320, 9, 1, False, False, True),    # split-K form at 8 x 8: the statistics come from splitk_reduce_stats_kernel (round 5)
+    (32, 8, 1280, 0, 1280, 9, 1, False, True, False),  # ... resnet conv1 at the UNet's 8 x 8 level (+ temb)
+    (8, 16, 640, 0, 1280, 9, 2, False, False, False),  # ... stride-2 downsample into 8 x 8 (generic kernel + split-K)
+    (6, 8, 1280, 0, 1280, 1, 1, False, False, True),   # ... 1x1 + residual at 8 x 8
     (32, 64, 320, 0, 320, 1, 1, False, False, True),   # 1x1 (proj_out + residual): 256 x 320 GEMM
     (2, 16, 640, 0, 1280, 1, 1, False, False, True),   # 1x1, few tiles: generic / 256 x 160 GEMM
     (2, 8, 64, 64, 128, 9, 1, False, True, True),      # two-source input (generic kernel)

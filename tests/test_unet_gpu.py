@@ -146,7 +146,9 @@ def test_cfg_shared_prefix_matches_full_dual_batch():
             assert torch.equal(u(lat, tt, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0], full)
             # executed < algorithmic with the shared prefix; without it the two counts differ only by what the execution pads or shares: conv_in on the MFMA conv runs
             # 64 input channels for 4 (+), one time MLP for the whole batch instead of one per sample (-)
-            assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat) and abs(u.flops_executed(2 * n_lat, 1) / u.flops(2 * n_lat) - 1.0) < 3e-3
+            assert abs(u.flops_executed(2 * n_lat, 1) / u.flops(2 * n_lat) - 1.0) < (3e-3 if exact else 3e-2)
+            if exact:       # (full model: the shared prefix outweighs the padded conv_in and the shortcut's second k pass; not so at 16 x 16 latents)
+                assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat)
     finally:
         ops.set_tuning("cfg_share", 1)
 
