@@ -2,10 +2,10 @@
 full SD1.5 UNet (HIP fp16) + PPOScheduler vs UNet oracle (fp32, fp16-rounded weights) + solver oracle
 on identical seeded weights, prompts, noise and replayed action indices.
 
-The north_star 1e-3 gate applies to the SOLVER given identical eps (tests/test_solver_gpu.py).  This
-test additionally bounds the drift of the whole fp16 pipeline over the trajectory (the denoiser runs in
-fp16 with fp16 activation storage, 1.6e-3 per forward, see tests/test_parity_e2e_gpu.py for the 8-step full-size
-case and what that error is made of): measured 1.5e-3 ... 2.1e-3 on the final latents, gated at measured + ~35 %."""
+The engine in its default configuration -- split-fp16 residual stream in the denoiser, fp32 solver state -- against the fp32 oracle end to end (no fp16 rounding
+in the comparator: only the conds are fp16-typed, as scheduler_ppo.py:207 makes them).  Measured 0.72e-3 ... 1.06e-3 on these short / reduced cases (the first step
+from t = 999 maps the per-forward eps error 1:1 into the latents), every bound = measured + 10 %; north_star's 1e-3 gate is asserted on the full UNet at
+n = 4 / 8 / 12 in tests/test_parity_e2e_gpu.py."""
 import os
 
 import numpy as np
@@ -79,7 +79,7 @@ def test_engine_trajectory_reduced_unet(use_graph):
     want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g, cfg_over=dict(layers_per_block=1, sample_size=16))
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 4-step reduced-unet rel l2", err, "graph" if use_graph else "eager")
-    assert np.isfinite(got).all() and err < 2.6e-3, err          # measured 1.93e-3 (eager) / 1.45e-3 (graph: one index set), + ~35 %
+    assert np.isfinite(got).all() and err < (0.80e-3 if use_graph else 1.14e-3), err          # measured 1.028e-3 (eager) / 0.723e-3 (graph: one index set), + 10 %; gate 1e-3 is on the full UNet (test_parity_e2e_gpu.py)
 
 
 def test_engine_use_conv_under_cfg():
@@ -109,8 +109,8 @@ def test_engine_use_conv_under_cfg():
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     perr = max(float(np.abs(a - b).max()) for a, b in zip(got_probs, want_probs))
     print("engine use_conv + CFG 5-step rel l2", err, "max |dprob|", perr)
-    assert np.isfinite(got).all() and err < 2.6e-3, err
-    assert perr < 5e-3, perr
+    assert np.isfinite(got).all() and err < 0.91e-3, err          # measured 0.820e-3, + 10 %
+    assert perr < 1e-3, perr                                       # measured 2.9e-5 (max |dprob| over the five steps' policy outputs)
     assert float(sch.factor_net.mlp[0].weight[:, 2:].abs().max()) > 0.1      # (the cosine inputs carry weight in this policy)
 
 
@@ -127,7 +127,7 @@ def test_engine_trajectory_full_sd15_two_steps():
     want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g, cfg_over={})
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     print("engine 2-step SD1.5 rel l2", err)
-    assert err < 2.8e-3, err                                     # measured 2.13e-3, + 30 % (8 steps on the full UNet: tests/test_parity_e2e_gpu.py)
+    assert err < 1.17e-3, err                                     # measured 1.055e-3 (two steps from t = 999: the first step maps the eps error 1:1), + 10 %; 8 steps: tests/test_parity_e2e_gpu.py
 
 
 def test_engine_pixel_output_matches_decode_of_its_latents():

@@ -5,7 +5,7 @@ reference pipeline is itself fp16 (gen_ppo.py:193-195): fp16 weights, fp16 activ
 fp32 accumulation inside the vendor kernels; its own distance from the fp32 oracle is 1.9e-3.  The HIP engine has two
 residual-stream storage modes (include/consolver_hip.h):
   * residual="f16x2" (split-fp16 stream, hi + lo planes): asserted AGAINST THE GATE, final latents <= 1.0e-3;
-  * residual="f16"   (one plane, the reference's own arithmetic class): 1.40e-3 measured; it cannot meet the gate (every add onto the
+  * residual="f16"   (one plane, the reference's own arithmetic class): 1.26e-3 measured; it cannot meet the gate (every add onto the
     stream rounds it: tools/sim_precision.py reproduces the executor's 1.56e-3 per forward from the rounding points alone), so its
     assertions are "measured + 10 %" regression bounds and the gate is printed next to them.
 These tests measure
@@ -38,7 +38,7 @@ from tests._models import get_unet, get_oracle, drop
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GATE = 1.0e-3          # north_star: latents within 1e-3 relative fp32 of the reference
-FWD_X2_BOUND = 0.98e-3  # per-forward eps error of the f16x2 stream on random latents: measured + 10 % (re-stated each round; the 8-step latents are what the gate is on)
+FWD_X2_BOUND = 1.0e-3   # per-forward eps error of the f16x2 stream on random latents: measured 0.857e-3 / 0.910e-3 / 0.873e-3 at t = 999 / 499 / 124, + 10 % (the 8-step latents are what the gate is on)
 
 
 def rel_l2(a, b):
@@ -168,7 +168,7 @@ def test_forward_error_budget_and_class_attribution():
     print(f"  gate (north_star, on the 8-step latents): {GATE:.1e}; per-forward eps error is printed for attribution, the latents are what is gated")
     for r in rows:
         assert r["hip_executor"] <= 1.25 * r["torch_fp16"], r
-        assert r["hip_executor"] < 1.72e-3, r                     # f16 stream: regression bound = measured 1.49e-3 .. 1.56e-3 + 10 % (gate 1.0e-3 not met in this mode)
+        assert r["hip_executor"] < 1.75e-3, r                     # f16 stream: regression bound = measured 1.47e-3 .. 1.59e-3 + 10 % (gate 1.0e-3 not met in this mode)
         assert r["hip_executor_f16x2"] < FWD_X2_BOUND, r          # f16x2 stream: measured + 10 % (see FWD_X2_BOUND)
         assert r["hip_executor_f16x2"] < 0.72 * r["hip_executor"], r
 
@@ -268,7 +268,7 @@ def test_eight_step_trajectory_full_unet_vs_oracle(B):
               "latents: f16x2 {drift_x2:.3e} f16 {drift_hip:.3e} torch-fp16 {drift_t16:.3e}".format(**r))
     final_hip, final_x2, final_t16 = rows[-1]["drift_hip"], rows[-1]["drift_x2"], rows[-1]["drift_t16"]
     print(f"  final latents: f16x2 {final_x2:.3e} (gate {GATE:.1e}: {'MET' if final_x2 <= GATE else 'NOT MET'}, margin {100 * (1 - final_x2 / GATE):.1f} %), "
-          f"f16 {final_hip:.3e} (gate not met in this mode; regression bound 1.54e-3), torch-fp16 class {final_t16:.3e}")
+          f"f16 {final_hip:.3e} (gate not met in this mode; regression bound 1.39e-3), torch-fp16 class {final_t16:.3e}")
     assert np.isfinite(res["f16"][0][-1]).all() and np.isfinite(res["f16x2"][0][-1]).all()
     # ---- the gate: split-fp16 residual stream
     assert final_x2 <= GATE, final_x2
@@ -278,7 +278,7 @@ def test_eight_step_trajectory_full_unet_vs_oracle(B):
     for r in rows:
         assert r["fwd_hip"] <= 1.25 * r["fwd_t16"], r
     assert final_hip <= 1.25 * final_t16 + 2e-4, (final_hip, final_t16)
-    assert final_hip < 1.54e-3, final_hip                         # measured 1.40e-3 at B = 2, 1.35e-3 at B = 16 (torch-fp16 class: 1.94e-3), + 10 %
+    assert final_hip < 1.39e-3, final_hip                         # measured 1.263e-3 at B = 2 with the fp32 solver state (fp16 state, round 4: 1.40e-3; torch-fp16 class: 1.97e-3), + 10 %
 
 
 # the step counts the reference publishes besides 8 (readme.md:158-163: 5 / 8 / 10 / 12; train_ppo.py:345 draws 2..15) and a second weight seed: the gated mode only,

@@ -2,9 +2,9 @@
 
 The oracle is "parity unpinned" w.r.t. diffusers (see oracle/unet_oracle.py); what is pinned here is
 that the HIP kernels compute the same function as the fp32 restatement on identical seeded weights.
-Tolerance: activations are stored in fp16 between ~400 kernels -> relative L2 of the eps output 1.5e-3 ... 1.6e-3,
-gated at measured + 30 %; stated here because it is looser than the solver's 1e-3 gate (what that error is made of and
-how it compares with a torch-fp16 evaluation of the same graph: tests/test_parity_e2e_gpu.py).
+Tolerance: per-forward relative L2 of the eps output in the default residual-stream mode (f16x2): 0.87e-3 ... 0.89e-3 (1.06e-3 on 8 x 8 latents), every
+bound = measured + 10 % (round 5; the f16 stream measures 1.5e-3 ... 1.6e-3).  What that error is made of and how it compares with a torch-fp16 evaluation of the
+same graph: tests/test_parity_e2e_gpu.py; the 1e-3 gate itself is on the 8-step latents there.
 """
 import pytest
 import torch
@@ -42,10 +42,10 @@ def test_reduced_unet_matches_oracle():
     assert got.shape == (4, 4, 16, 16) and got.dtype == torch.float16
     err = rel_l2(got, want)
     print('reduced unet rel l2', err)
-    assert err < 2.0e-3, err            # measured 1.48e-3
+    assert err < 0.99e-3, err            # default stream (f16x2): measured 0.892e-3, + 10 %  (f16 stream: 1.48e-3)
     # cached cross-attention K/V (second step, same ctx) and per-sample timesteps give the same function
     got2 = u(lat.half().to(DEV), torch.full((4,), float(t), device=DEV), encoder_hidden_states=ctx.half().to(DEV), dup=2, reuse_kv=True)[0]
-    assert rel_l2(got2, want) < 2.0e-3
+    assert rel_l2(got2, want) < 0.99e-3
     # un-duplicated batch path == dual batch path on the conditional half
     got3 = u(lat.half().to(DEV), t, encoder_hidden_states=ctx[2:].half().to(DEV), dup=1, reuse_kv=False)[0]
     assert torch.equal(got3, got[2:])
@@ -106,7 +106,7 @@ def test_full_sd15_unet_matches_oracle_cfg_batch():
     want = orc(torch.cat([lat.half().float()] * 2), 499, ctx.half().float())
     err = rel_l2(got, want)
     print('sd15 unet rel l2', err)
-    assert err < 2.1e-3, err            # measured 1.61e-3 (a plain torch-fp16 evaluation of the same graph: 2.9e-3, tests/test_parity_e2e_gpu.py)
+    assert err < 0.96e-3, err            # default stream (f16x2): measured 0.872e-3, + 10 % (f16 stream 1.59e-3; a plain torch-fp16 evaluation of the same graph: 2.9e-3, tests/test_parity_e2e_gpu.py)
     assert torch.isfinite(got).all()
     # determinism
     again = u(lat.half().to(DEV), 499, encoder_hidden_states=ctx.half().to(DEV), dup=2)[0]
@@ -173,7 +173,7 @@ def test_fused_cross_attention_block_matches_the_four_kernel_path():
     print(f"fused vs four kernels {e_ff:.3e}; vs fp32 oracle: fused {e_fused:.3e}, four kernels {e_four:.3e}")
     assert e_ff < 1.25 * (e_fused ** 2 + e_four ** 2) ** 0.5          # two independent roundings of the same fp32 function
     assert e_fused < 1.15 * e_four + 1e-4          # the fusion costs no accuracy
-    assert e_fused < 3.0e-3 and e_four < 3.0e-3
+    assert e_fused < 1.05e-3 and e_four < 1.05e-3          # measured 0.955e-3 / 0.951e-3, + 10 %
 
 
 def test_group_norm_statistics_from_the_producers_match_the_statistics_pass():
@@ -213,7 +213,8 @@ def test_unet_at_sizes_where_only_some_levels_take_the_fused_paths(sample_size, 
     want = orc(torch.cat([lat.half().float()] * 2), 301, ctx.half().float())
     err = rel_l2(got, want)
     print(f"sample_size {sample_size}: rel l2 vs fp32 oracle {err:.3e}")
-    assert torch.isfinite(got).all() and err < 2.5e-3, err
+    bound = {24: 0.87e-3, 8: 1.17e-3, 40: 0.88e-3}[sample_size]          # measured 0.783e-3 / 1.060e-3 / 0.797e-3 (default stream), + 10 %
+    assert torch.isfinite(got).all() and err < bound, err
 
 
 @pytest.mark.parametrize("residual", ["f16x2", "f16"])
