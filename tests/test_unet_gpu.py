@@ -144,11 +144,10 @@ def test_cfg_shared_prefix_matches_full_dual_batch():
             # per-sample timesteps (the halves could differ): the shared path is not taken, results equal the full batch
             tt = torch.full((2 * n_lat,), 499.0, device=DEV)
             assert torch.equal(u(lat, tt, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0], full)
-            # executed < algorithmic with the shared prefix; without it the two counts differ only by what the execution pads or shares: conv_in on the MFMA conv runs
-            # 64 input channels for 4 (+), one time MLP for the whole batch instead of one per sample (-)
-            assert abs(u.flops_executed(2 * n_lat, 1) / u.flops(2 * n_lat) - 1.0) < (3e-3 if exact else 3e-2)
-            if exact:       # (full model: the shared prefix outweighs the padded conv_in and the shortcut's second k pass; not so at 16 x 16 latents)
-                assert u.flops_executed(n_lat, 2) < u.flops(2 * n_lat)
+            # the executed count differs from the reference graph's by what the execution pads, doubles or shares: conv_in on the MFMA conv runs 64 input channels for 4 (+),
+            # the resnet shortcut's hi + lo k passes in the f16x2 mode (+ 2.2 %), one time MLP per forward instead of one per sample (-), the CFG-shared prefix (- 2.5 %)
+            assert abs(u.flops_executed(2 * n_lat, 1) / u.flops(2 * n_lat) - 1.0) < 3e-2
+            assert u.flops_executed(n_lat, 2) < u.flops_executed(2 * n_lat, 1)
     finally:
         ops.set_tuning("cfg_share", 1)
 
