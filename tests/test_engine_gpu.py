@@ -249,7 +249,7 @@ def test_bench_prints_one_contract_line():
     assert rec["unit"] == "images/s" and rec["value"] > 1.0 and "workload" in rec["config"] and "model" not in rec["config"]
     rf = rec["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0
-    assert rf["frac_executed"] < rf["frac"] and abs(rf["frac_executed"] - rf["achieved_executed"] / rf["peak"]) < 1e-9     # executed < algorithmic (CFG shared prefix)
+    assert rf["frac_executed"] < 1.03 * rf["frac"] and abs(rf["frac_executed"] - rf["achieved_executed"] / rf["peak"]) < 1e-9     # executed vs algorithmic: - 2.5 % CFG shared prefix, + 2.2 % the shortcut's hi + lo passes (f16x2)
     assert abs(rf["achieved_executed"] / rf["achieved"] - rf["flops_executed_per_launch"] / rf["flops_per_launch"]) < 1e-9
     assert rec["ceilings"]["vendor_gemm_f16_8192_tflops"] > 100 and rec["ceilings"]["dtod_copy_1gib_tbps"] > 1.0
     assert rec["cpu_baseline"] is None          # --no-cpu-baseline
