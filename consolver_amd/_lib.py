@@ -190,6 +190,8 @@ SYMBOLS = {
     "cs_op_layer_norm_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "cs_op_xattn_block_x2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cs_unet_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "cs_unet_clear_tuning": (C.c_int, [C.c_void_p]),
     "cs_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "cs_get_tuning": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "cs_reset_tuning": (C.c_int, []),

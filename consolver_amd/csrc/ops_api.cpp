@@ -27,6 +27,11 @@ extern int g_tune_epi_fast;
 extern int g_tune_conv_in_mfma;
 extern int g_tune_xattn_tile;
 
+#include <mutex>
+// cs_set_tuning / cs_reset_tuning and a forward that runs with per-handle overrides (cs_unet_set_tuning) exclude each other: the knobs are read on the HOST while a
+// forward's launches are issued, so holding this for the duration of the host call is what "this handle runs with its own knob set" takes
+std::recursive_mutex g_tune_mutex;
+
 extern "C" {
 
 // every kernel-selection knob: name, variable, default, accepted range (or the two-value set {lo, hi} when `pair`)
@@ -47,6 +52,7 @@ static const TuneKnob* tune_knobs(int* n) {
 
 int cs_set_tuning(const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
+    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
     int n; const TuneKnob* k = tune_knobs(&n);
     for (int i = 0; i < n; ++i)
         if (!strcmp(key, k[i].key)) {
@@ -67,6 +73,7 @@ int cs_get_tuning(const char* key, int* value) {
 }
 
 int cs_reset_tuning(void) {
+    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
     int n; const TuneKnob* k = tune_knobs(&n);
     for (int i = 0; i < n; ++i) *k[i].var = k[i].def;
     return CS_OK;

@@ -23,7 +23,11 @@
 #include <memory>
 #include <cstring>
 #include <cmath>
+#include <mutex>
 
+extern std::recursive_mutex g_tune_mutex;      // ops_api.cpp
+extern "C" int cs_set_tuning(const char* key, int value);
+extern "C" int cs_get_tuning(const char* key, int* value);
 int g_tune_xattn_fused = 1;    // 1 (default): the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
 extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
 int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
@@ -144,6 +148,7 @@ struct CsUNet {
     double prof_ms[P_COUNT] = {}, prof_flops[P_COUNT] = {}, prof_bytes[P_COUNT] = {}; int prof_launches[P_COUNT] = {};
     double dry_flops = 0;
     int residual = CS_RESIDUAL_F16X2;   // cs_unet_set_residual_precision (default: the mode that meets the 1e-3 latent gate)
+    std::map<std::string, int> tune;    // cs_unet_set_tuning: knob values THIS handle's forwards run with (on top of the process-wide cs_set_tuning state)
 };
 
 namespace {
@@ -889,8 +894,20 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     if (!latents || !timesteps || !ctx || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
     if (n_timesteps != 1 && n_timesteps != n_lat * dup) CS_FAIL(CS_E_SHAPE, "n_timesteps must be 1 or the batch size");
     u->ev_used = 0;
+    // per-handle knob overrides: applied for the duration of this host call (every knob is read on the host while the launches are issued), restored afterwards
+    std::unique_lock<std::recursive_mutex> tune_lock(g_tune_mutex, std::defer_lock);
+    std::vector<std::pair<std::string, int>> saved;
+    if (!u->tune.empty()) {
+        tune_lock.lock();
+        for (auto& kv : u->tune) {
+            int cur = 0;
+            if (cs_get_tuning(kv.first.c_str(), &cur) == CS_OK) { saved.push_back({kv.first, cur}); cs_set_tuning(kv.first.c_str(), kv.second); }
+        }
+    }
     int rc = run_forward(u, false, (const f16*)latents, n_lat, dup, timesteps, n_timesteps, (const f16*)ctx, (f16*)out, (char*)workspace,
                          workspace_bytes, kv_cache_valid, (hipStream_t)stream);
+    for (auto it = saved.rbegin(); it != saved.rend(); ++it) cs_set_tuning(it->first.c_str(), it->second);
+    if (tune_lock.owns_lock()) tune_lock.unlock();
     if (rc == CS_OK && u->profiling) {
         CS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
         for (int k = 0; k < P_COUNT; ++k) { u->prof_ms[k] = u->prof_flops[k] = u->prof_bytes[k] = 0; u->prof_launches[k] = 0; }
@@ -902,6 +919,20 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     }
     return rc;
 }
+
+int cs_unet_set_tuning(CsUNet* u, const char* key, int value) {
+    if (!u || !key) CS_FAIL(CS_E_ARG, "unet / key is NULL");
+    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
+    int cur = 0;
+    int rc = cs_get_tuning(key, &cur);                   // known knob?
+    if (rc != CS_OK) return rc;
+    rc = cs_set_tuning(key, value);                      // value in range?  (validated by the same table, then put back)
+    cs_set_tuning(key, cur);
+    if (rc != CS_OK) return rc;
+    u->tune[key] = value;
+    return CS_OK;
+}
+int cs_unet_clear_tuning(CsUNet* u) { if (!u) CS_FAIL(CS_E_ARG, "unet is NULL"); u->tune.clear(); return CS_OK; }
 
 int cs_unet_set_residual_precision(CsUNet* u, int mode) {
     if (!u) CS_FAIL(CS_E_ARG, "unet is NULL");

@@ -69,6 +69,15 @@ class HipUNet2DConditionModel:
         self.invalidate_kv()
         return self
 
+    def set_tuning(self, key, value):
+        """kernel-selection knob for THIS model only (cs_unet_set_tuning): applied around each of its forwards, the process-wide ``ops.set_tuning`` state is untouched"""
+        L.check(L.lib().cs_unet_set_tuning(self._h, key.encode(), int(value)))
+        return self
+
+    def clear_tuning(self):
+        L.check(L.lib().cs_unet_clear_tuning(self._h))
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

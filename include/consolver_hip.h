@@ -206,6 +206,12 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
 #define CS_RESIDUAL_F16   0
 #define CS_RESIDUAL_F16X2 1
 int cs_unet_set_residual_precision(CsUNet* u, int mode);
+/* Kernel-selection knobs for THIS handle (keys and ranges: cs_set_tuning in consolver_hip_ops.h): cs_unet_forward applies them for the duration of its host call and
+ * restores the process-wide values afterwards, under the lock cs_set_tuning takes -- two handles in one process can run different knob sets (their forwards'
+ * host calls serialize; the GPU work does not).  The workspace size does not depend on them (cs_unet_workspace_bytes covers every variant).  Unknown keys and
+ * out-of-range values are rejected.  cs_unet_clear_tuning drops the handle's overrides. */
+int cs_unet_set_tuning(CsUNet* u, const char* key, int value);
+int cs_unet_clear_tuning(CsUNet* u);
 int cs_unet_get_residual_precision(const CsUNet* u);
 
 /* per-kernel-class profile of the last forward recorded with events

@@ -231,3 +231,37 @@ def test_forward_does_not_read_uninitialised_workspace(residual):
                 u._ws.fill_(fill)
                 b = u(lat, 749, encoder_hidden_states=c, dup=dup, reuse_kv=False)[0].clone()
                 assert torch.isfinite(b.float()).all() and torch.equal(a, b), (S, dup, fill)
+
+
+def test_two_handles_run_different_knob_sets_in_one_process():
+    """cs_unet_set_tuning (round 5): kernel-selection knobs per HANDLE.  Two models of the same weights, one with the fused cross-attention block and the folded LayerNorm
+    switched off for itself: each reproduces, bit for bit, what the process-wide knobs give when set to its values -- in either call order, with the process-wide state
+    untouched afterwards; unknown keys / out-of-range values are rejected."""
+    from consolver_amd import ops, _lib as L
+    cfg = dict(layers_per_block=1, sample_size=32)
+    a, sd = get_unet(cfg, seed=3)
+    b = HipUNet2DConditionModel(cfg, device=DEV)
+    b.load_state_dict(sd)
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(2)).half().to(DEV)
+    ctx = synthetic_prompt_embeds(4, seed=31).half().to(DEV)
+    run = lambda m: m(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+    base = run(a)
+    ops.set_tuning("xattn_fused", 0); ops.set_tuning("ln_fold", 0)
+    want_alt = run(a)
+    ops.set_tuning("xattn_fused", 1); ops.set_tuning("ln_fold", 1)
+    assert not torch.equal(base, want_alt)
+    b.set_tuning("xattn_fused", 0).set_tuning("ln_fold", 0)
+    for order in ((a, b), (b, a), (b, b, a)):
+        outs = [run(m) for m in order]
+        for m, o in zip(order, outs):
+            assert torch.equal(o, want_alt if m is b else base)
+    v = __import__("ctypes").c_int()
+    for k in ("xattn_fused", "ln_fold"):
+        L.check(L.lib().cs_get_tuning(k.encode(), __import__("ctypes").byref(v)))
+        assert v.value == 1                                            # the process-wide state is as it was
+    with pytest.raises(RuntimeError):
+        b.set_tuning("no_such_knob", 1)
+    with pytest.raises(RuntimeError):
+        b.set_tuning("ln_fold", 7)
+    b.clear_tuning()
+    assert torch.equal(run(b), base)
