@@ -10,7 +10,7 @@ dev = "cuda:0"
 for kv in os.environ.get("CS_TUNE", "").split(","):
     if "=" in kv:
         k, v = kv.split("="); ops.set_tuning(k, int(v))
-u = HipUNet2DConditionModel(device=dev, residual=os.environ.get("CS_RESIDUAL", "f16x2")); u.load_state_dict(synthetic_unet_state_dict(u.manifest(), device=dev))
+u = HipUNet2DConditionModel(device=dev, residual=os.environ.get("CS_RESIDUAL", "f16x2")); u.load_state_dict(synthetic_unet_state_dict(u.manifest()))      # (host-side synthesis on purpose: the PMC traffic passes sum the counters over EVERY dispatch of this process)
 NL = int(os.environ.get("CS_NLAT", "16"))
 lat = torch.randn(NL, 4, 64, 64, device=dev).half()
 ctx = synthetic_prompt_embeds(2 * NL).half().to(dev)
