@@ -47,3 +47,28 @@ def test_hand_scheduled_kernels_do_not_spill(igemm_build):
         assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
         assert occ >= 2, f"{name}: occupancy {occ}"
     assert seen >= 10
+
+
+@pytest.mark.parametrize("src,kernels", [("xattn.hip", ("xattn64_kernel",)), ("gemm2.hip", ("gemm2_kernel",))])
+def test_round5_kernels_do_not_spill(tmp_path, src, kernels):
+    """xattn64_kernel (251 VGPRs at two workgroups per CU: its first form spilled 68 registers with the V half tile in flight next to the LayerNorm's 16 rows) and the
+    split-stream instantiations of gemm2_kernel (251-253 VGPRs against 214-218) sit at the register limit of two waves per SIMD: no scratch, occupancy 2."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (src + ".s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S",
+                        "-Rpass-analysis=kernel-resource-usage", "-x", "hip", os.path.join(ROOT, "consolver_amd", "csrc", src), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split("\n")[0].split()[0]
+        if not any(k in name for k in kernels):
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        occ = int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1))
+        assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane"
+        assert occ >= 2, f"{name}: occupancy {occ}"
+    assert seen >= (2 if src == "xattn.hip" else 12)
