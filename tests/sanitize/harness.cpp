@@ -48,7 +48,10 @@ static void unet_part() {
     }
     EXPECT(cs_unet_finalize(u) == CS_OK && cs_unet_finalize(u) == CS_OK);
     EXPECT(cs_unet_set_weight(u, "conv_in.bias", buf.data(), shape, 1) != CS_OK);   // packed already
-    EXPECT(cs_unet_flops(u, 2) > 0 && cs_unet_flops_executed(u, 2, 2) > 0 && cs_unet_flops_executed(u, 2, 2) < cs_unet_flops(u, 4));
+    EXPECT(cs_unet_flops(u, 2) > 0 && cs_unet_flops_executed(u, 2, 2) > 0 && cs_unet_flops_executed(u, 2, 2) < cs_unet_flops_executed(u, 4, 1));
+    // per-handle knobs: validated against the knob table, applied around the forwards below, dropped again
+    EXPECT(cs_unet_set_tuning(u, "no_such_knob", 1) != CS_OK && cs_unet_set_tuning(u, "ln_fold", 9) != CS_OK && cs_unet_set_tuning(nullptr, "ln_fold", 0) != CS_OK);
+    EXPECT(cs_unet_set_tuning(u, "ln_fold", 0) == CS_OK && cs_unet_set_tuning(u, "xattn_fused", 0) == CS_OK);
     EXPECT(cs_unet_set_residual_precision(u, 7) != CS_OK);
 
     const int S = c.sample_size;
@@ -87,6 +90,7 @@ static void unet_part() {
             free(ws);
         }
     }
+    EXPECT(cs_unet_clear_tuning(u) == CS_OK);
     // a workspace sized in one residual mode is refused (not overrun) in the other
     EXPECT(cs_unet_set_residual_precision(u, CS_RESIDUAL_F16) == CS_OK);
     const size_t small = cs_unet_workspace_bytes(u, 2);
@@ -159,7 +163,10 @@ static void flux_part() {
         EXPECT(cs_flux_set_weight(f, name, buf.data(), 0, shape, nd) == CS_OK);
     }
     EXPECT(cs_flux_finalize(f) == CS_OK);
+    EXPECT(cs_flux_set_residual_precision(f, 5) != CS_OK && cs_flux_get_residual_precision(f) == CS_RESIDUAL_F16X2);       // default: split hidden-state stream
+    for (int mode : {CS_RESIDUAL_F16X2, CS_RESIDUAL_F16})
     for (int B : {1, 2}) {
+        EXPECT(cs_flux_set_residual_precision(f, mode) == CS_OK && cs_flux_get_residual_precision(f) == mode);
         const int T = 64, Lq = 256, Li = 256, D2 = c.head_dim / 2;
         const size_t wsb = cs_flux_workspace_bytes(f, B, T, Lq + Li);
         EXPECT(wsb > 0 && cs_flux_flops(f, B, T, Lq + Li) > 0);

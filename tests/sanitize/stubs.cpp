@@ -12,7 +12,8 @@
 #include <cstring>
 
 int g_tune_attn_lw = 1, g_tune_attn_prio = -1, g_tune_attn_qt40 = 4, g_tune_biggemm = 1, g_tune_conv_lw = 1, g_tune_debug = 0, g_tune_gemm2_prio = 0,
-    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1, g_tune_epi_fast = 1;
+    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1, g_tune_epi_fast = 1,
+    g_tune_xattn_tile = 64;
 
 // ---- HIP runtime -------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -97,6 +98,10 @@ int launch_quick_gelu(f16* x, long n, hipStream_t) { wr(x, (size_t)n * 2); retur
 int launch_gemm2(const Gemm2Args& a, hipStream_t) {
     rd(a.a, 2); rd(a.w, (size_t)((a.N + 255) / 256 * 256) * a.K * 2); wr(a.out, 2);
     if (!a.c_seg_rows) wr(a.out, (((size_t)a.M - 1 + a.c_row_off) * a.ldc + a.c_col_off + a.N) * 2);
+    if (a.out_lo) {          // split residual stream: the lo planes are addressed like res / out
+        rd(a.res_lo, 2); wr(a.out_lo, 2); rd(a.res, 2);
+        if (!a.c_seg_rows) { const size_t n = (((size_t)a.M - 1 + a.c_row_off) * a.ldc + a.c_col_off + a.N) * 2; rd(a.res_lo, n); wr(a.out_lo, n); rd(a.res, n); }
+    }
     if (!a.a_seg_rows) rd(a.a, (((size_t)a.M - 1 + a.a_row_off) * a.lda + a.K) * 2);
     if (a.tail_ws) wr(a.tail_ws, a.tail_ws_bytes);
     return CS_OK;
@@ -104,7 +109,7 @@ int launch_gemm2(const Gemm2Args& a, hipStream_t) {
 int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) { launch_gemm2(a, s); return launch_gemm2(b, s); }
 size_t gemm2_tail_workspace_bytes(int tiles, int K) { return K >= 6144 && tiles % 256 ? (size_t)3 * 256 * 256 * 256 * 4 : 0; }
 int launch_small_linear(const float* x, int R, int K, const void* w, const void*, int N, float* out, int, int, int, hipStream_t) { rd(x, (size_t)R * K * 4); rd(w, (size_t)N * K * 2); wr(out, (size_t)R * N * 4); return CS_OK; }
-int launch_ln_modulate(const void* x, void* y, int M, int C, int, const float* sh, const float* sc, long, float, int, hipStream_t) { rd(x, (size_t)M * C * 2); wr(y, (size_t)M * C * 2); rd(sh, C * 4); rd(sc, C * 4); return CS_OK; }
+int launch_ln_modulate(const void* x, void* y, int M, int C, int, const float* sh, const float* sc, long, float, int, hipStream_t, const void* x_lo) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(y, (size_t)M * C * 2); rd(sh, C * 4); rd(sc, C * 4); return CS_OK; }
 int launch_qk_norm_rope(void* qkv, long ld, int rows, int, int heads, int dh, int, int k_col, const void*, const void*, const void*, const void*, int, const float*, const float*, float, int, hipStream_t) {
     wr(qkv, (((size_t)rows - 1) * ld + k_col + (size_t)heads * dh) * 2); return CS_OK;
 }
