@@ -62,7 +62,6 @@ struct IgemmParams {
     int gm;             // gemm_big_kernel tile order: bands of gm tile rows walked column-major (1 = plain row-major)
     int pn;             // tile_of: 0 = contiguous run of tiles per XCD, > 0 = the XCDs as an (8 / pn) x pn grid over (row tiles, column tiles)
     int epi_fast;       // knob epi_fast: the FAST forms of the fp32-patch epilogue (igemm_epilogue_f32)
-    int a_tiled, out_tiled;   // IgemmArgs::a_tiled / out_tiled: the GEGLU intermediate as [M / 256][K / 64][256][64] blocks
 };
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
@@ -479,11 +478,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             } else {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(wave_lds + row * ROWB + ch * 16);
                 if (m >= 0) {
-                    size_t off = (size_t)m * Nout + n0 + ch * 8;
-                    if constexpr (GEGLU) {                     // tiled GEGLU intermediate: block (m / 256, n / 64), row m % 256 of 64 halfs
-                        const int n = n0 + ch * 8;
-                        if (p.out_tiled) off = ((size_t)(m >> 8) * (Nout >> 6) + (n >> 6)) * (256 * 64) + (size_t)(m & 255) * 64 + (n & 63);
-                    }
+                    const size_t off = (size_t)m * Nout + n0 + ch * 8;
                     *reinterpret_cast<f16x8*>(p.out + off) = v;
                 } else if (stats) {
                     *reinterpret_cast<f16x8*>(wave_lds + row * ROWB + ch * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -1435,9 +1430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
         const unsigned m = (unsigned)min(m_blk + r, p.M - 1);
         const unsigned ch = (unsigned)((pch ^ ((r >> 1) & 7)) * 16);
         aoff0[j] = m * (unsigned)(p.c0 * 2) + ch; aoff1[j] = m * (unsigned)(p.c1 * 2) + ch;
-        if (p.a_tiled) aoff0[j] = (unsigned)tm * (unsigned)(p.c0 >> 6) * 32768u + (unsigned)r * 128u + ch;      // tiled A: row r of the tile's k block 0; a k step advances one 32 KB block
     }
-    const int a_kshift = p.a_tiled ? 15 : 7;                     // byte offset of k step kt: kt * 32768 (tiled) or kt * 128 (row-major)
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int r = 8 * (w + 8 * j) + lr;
@@ -1458,7 +1451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
         if constexpr (n < 4) {
             lptr_t dst = (lptr_t)(smem + buf * STAGE + (w * 4 + n) * 1024);
             if (!lo) {
-                if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, dst, 16, aoff0[n], (cc >> 6) << a_kshift, 0, 0);
+                if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0, dst, 16, aoff0[n], cc * 2, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra1, dst, 16, aoff1[n], (cc - p.c0) * 2, 0, 0);
             } else {
                 if (cc < p.c0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra0l, dst, 16, aoff0[n], cc * 2, 0, 0);
@@ -2000,7 +1993,6 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 }  // namespace
 
 int g_tune_debug = 0;
-int g_tune_ff_tiled = 1;       // 1 (default, round 5): the GEGLU intermediate between FF1 and FF2 travels in the tiled layout where both run on the 256 x 320 GEMM kernel (bit-identical), 0: row-major
 int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
 int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
 int g_tune_halo = 1;
@@ -2086,10 +2078,6 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
         p.KT = 2 * p.KTh;                                  // Ktot (row length of w) stays cin: the lo k steps re-read the same weight columns
     }
     if (a.geglu && a.out_lo) CS_FAIL(CS_E_ARG, "igemm: the GEGLU epilogue writes no lo plane");
-    p.a_tiled = a.a_tiled; p.out_tiled = a.out_tiled;
-    if (a.out_tiled && (!a.geglu || p.M % 256 || (a.N / 2) % 64)) CS_FAIL(CS_E_ARG, "igemm: out_tiled is the GEGLU output layout (M %% 256 == 0, N / 2 %% 64 == 0)");
-    if (a.a_tiled && (a.taps != 1 || a.c1 || a.a0_lo || !igemm_tiled_ok(p.M, a.c0, a.N)))
-        CS_FAIL(CS_E_UNSUPPORTED, "igemm: a_tiled is read by the 256 x 320 GEMM kernel only (one source, M %% 256 == 0; ask igemm_tiled_ok first)");
     p.debug = g_tune_debug; p.partial = nullptr;
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
@@ -2270,15 +2258,6 @@ generic_tiles:
     const int lk = splits > 1 ? 0 : lnm;            // (split-K: raw partial sums leave the main kernel; the reduce kernel applies a folded LayerNorm itself)
     if (bn == 128) return lk == 1 ? launch_variant<128, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<128, false, false, 2>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
     return lk == 1 ? launch_variant<160, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<160, false, false, 2>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
-}
-
-bool igemm_tiled_ok(int M, int K, int N) {
-    // the conditions under which launch_igemm_impl sends a linear layer to gemm_w8_kernel (the one kernel whose A staging knows the tiled layout)
-    if (M <= 0 || M % 256 || K % 64 || N % 320) return false;
-    if (!g_tune_biggemm || !g_tune_gemm_w8 || g_tune_debug || !g_tune_ff_tiled) return false;
-    const int tiles_m = M / 256, tn = N / 320;
-    if (!(tiles_m * tn >= 192 || g_tune_biggemm == 2)) return false;
-    return (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
 }
 
 int launch_igemm(const IgemmArgs& a, hipStream_t s) {

@@ -39,16 +39,8 @@ struct IgemmArgs {
     //   consumer: ln_stats (that buffer), ln_groups = G, ln_eps, ln_s, ln_b (fp32 [N]); w = W'; bias is ignored (b' holds it).  The row length is c0.
     float* row_stats; int* row_stats_groups;
     const float* ln_stats; int ln_groups; float ln_eps; const float* ln_s; const float* ln_b;
-    // ---- round 5: TILED layout of the GEGLU intermediate (the [M][4C] tensor FF1 writes and FF2 reads; nobody else sees it).  Row-major, FF2's A stage is 256 pieces of
-    // 128 B at a stride of 8 C bytes and FF1's output tile 256 pieces of 320 B at the same stride: the worst DRAM pattern of the forward (FF2 streams its operand at
-    // 3.3 TB/s where the contiguous-row layers reach 5.1).  Tiled = [M / 256][K / 64][256 rows][64 halfs]: a k step's A stage is ONE contiguous 32 KB block.
-    //   out_tiled (GEGLU only): the output is written in that layout (K = N / 2); a_tiled (1x1 / linear, one source, M % 256 == 0): a0 is read in it.
-    // Only the 256 x 320 GEMM kernel reads it: ask igemm_tiled_ok() first (launch_igemm rejects a_tiled on any other path).
-    int a_tiled, out_tiled;
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
-// true when launch_igemm would run a linear layer [M][K] x [N][K]^T on the 256 x 320 GEMM kernel with its hand-scheduled loop (the only reader of the tiled layout)
-bool igemm_tiled_ok(int M, int K, int N);
 double igemm_flops(const IgemmArgs& a);
 void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out);
 // (sum, sum of squares) per row of x [M][C] (+ x_lo): stats[M][1][2]; the statistics pass behind IgemmArgs::row_stats and after the fused cross-attention block

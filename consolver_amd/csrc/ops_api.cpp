@@ -26,7 +26,6 @@ extern int g_tune_xcd_grid;
 extern int g_tune_epi_fast;
 extern int g_tune_conv_in_mfma;
 extern int g_tune_xattn_tile;
-extern int g_tune_ff_tiled;
 
 #include <mutex>
 // cs_set_tuning / cs_reset_tuning and a forward that runs with per-handle overrides (cs_unet_set_tuning) exclude each other: the knobs are read on the HOST while a
@@ -45,7 +44,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"gn_fuse", &g_tune_gn_fuse, 1, 0, 1, false},    {"xattn_fused", &g_tune_xattn_fused, 1, 0, 1, false}, {"cfg_share", &g_tune_cfg_share, 1, 0, 1, false},
         {"gemm2_prio", &g_tune_gemm2_prio, 0, -1, 1, false}, {"attn_prio", &g_tune_attn_prio, -1, -1, 1, false}, {"attn_qt40", &g_tune_attn_qt40, 4, 2, 4, true},
         {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false}, {"ln_fold", &g_tune_ln_fold, 1, 0, 1, false}, {"xcd_grid", &g_tune_xcd_grid, 1, 0, 1, false}, {"epi_fast", &g_tune_epi_fast, 1, 0, 1, false},
-        {"conv_in_mfma", &g_tune_conv_in_mfma, 1, 0, 1, false}, {"xattn_tile", &g_tune_xattn_tile, 64, 64, 128, true}, {"ff_tiled", &g_tune_ff_tiled, 1, 0, 1, false},
+        {"conv_in_mfma", &g_tune_conv_in_mfma, 1, 0, 1, false}, {"xattn_tile", &g_tune_xattn_tile, 64, 64, 128, true},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;
@@ -106,15 +105,6 @@ int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int H
     a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
     a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes; a.gn_stats = gn_stats;
     if (gn_stats && (a.Ho * a.Wo) % 64) CS_FAIL(CS_E_SHAPE, "conv2d_gn: Ho * Wo = %d must be a multiple of 64", a.Ho * a.Wo);
-    return launch_igemm(a, (hipStream_t)stream);
-}
-
-int cs_op_linear_tiled_ok(int M, int K, int N) { return igemm_tiled_ok(M, K, N) ? 1 : 0; }
-int cs_op_linear_tiled(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, void* out, int geglu, int a_tiled, int out_tiled, void* stream) {
-    IgemmArgs a{};
-    a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
-    a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out; a.geglu = geglu; a.a_tiled = a_tiled; a.out_tiled = out_tiled;
-    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
     return launch_igemm(a, (hipStream_t)stream);
 }
 

@@ -414,10 +414,8 @@ struct Run {
         // cs_unet_flops is the algorithmic count of SURVEY 8(d), independent of how a layer is executed
         launch(c.taps == 9 ? P_CONV3 : P_GEMM, (algo_flops >= 0 && !count_executed) ? algo_flops : igemm_flops(a) * ((count_executed && a.a0_lo) ? 2.0 : 1.0), bytes, [&] { return launch_igemm(a, s); });
     }
-    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu, float* row_stats = nullptr, int* row_groups = nullptr,
-                int a_tiled = 0, int out_tiled = 0) {
+    void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu, float* row_stats = nullptr, int* row_groups = nullptr) {
         IgemmArgs a{};
-        a.a_tiled = a_tiled; a.out_tiled = out_tiled;
         a.row_stats = row_stats; a.row_stats_groups = row_groups;
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res.hi; a.out = out.hi; a.geglu = geglu;
         a.res_lo = res.lo; a.out_lo = out.lo;
@@ -426,9 +424,8 @@ struct Run {
         launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
     // out = LayerNorm(h) W^T + b with the LayerNorm folded in: x is the RAW hidden state (hi plane), stats / G what its producer left
-    void linear_ln(const f16* x, int M, int K, const LnLinear& L, const float* stats, int G, float eps, int N, f16* out, int geglu, int out_tiled = 0) {
+    void linear_ln(const f16* x, int M, int K, const LnLinear& L, const float* stats, int G, float eps, int N, f16* out, int geglu) {
         IgemmArgs a{};
-        a.out_tiled = out_tiled;
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = L.w; a.out = out; a.geglu = geglu;
         a.ln_stats = stats; a.ln_groups = G; a.ln_eps = eps; a.ln_s = L.s; a.ln_b = L.b;
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
@@ -523,12 +520,10 @@ struct Run {
         }
         // feed forward (GEGLU fused into the first GEMM's epilogue)
         f16* ff = alloc((size_t)M * 4 * C);
-        // the GEGLU intermediate in the tiled layout wherever FF2 runs on the kernel that reads it (the 64 x 64 and 32 x 32 levels): section 5, IgemmArgs::a_tiled
-        const int tiled = igemm_tiled_ok(M, 4 * C, C) ? 1 : 0;
-        if (fold) linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1, tiled);
-        else { layer_norm(X.ln3, h, M, g); linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1, nullptr, nullptr, 0, tiled); }
+        if (fold) linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
+        else { layer_norm(X.ln3, h, M, g); linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
         const bool po = split && (v_split_a & 2);
-        linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0, nullptr, nullptr, tiled, 0);      // the hidden after the feed-forward has one consumer, proj_out's operand: hi plane only unless proj_out reads hi + lo
+        linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);      // the hidden after the feed-forward has one consumer, proj_out's operand: hi plane only unless proj_out reads hi + lo
         release(ff);
         // proj_out + residual with the block input
         St out(g, split ? alloc((size_t)M * C) : nullptr);
@@ -606,11 +601,10 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0, rs, &G);
     }
     f16* ff = R.alloc((size_t)M * 4 * C);
-    const int tiled = igemm_tiled_ok(M, 4 * C, C) ? 1 : 0;
-    if (fold) R.linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1, tiled);
-    else { R.layer_norm(X.ln3, h, M, g); R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1, nullptr, nullptr, 0, tiled); }
+    if (fold) R.linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
+    else { R.layer_norm(X.ln3, h, M, g); R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
     const bool po = R.split && (R.v_split_a & 2);
-    R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0, nullptr, nullptr, tiled, 0);
+    R.linear(ff, M, 4 * C, X.wff2, X.bff2, C, h, po ? h : St(h.hi), 0);
     R.release(ff);
     // proj_out + residual with the block input, which exists once: one launch per half
     St out(g, R.split ? R.alloc((size_t)M * C) : nullptr);

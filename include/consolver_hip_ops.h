@@ -114,13 +114,6 @@ int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, 
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
 int cs_op_gemm2(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const float* gate, long gate_stride,
                 int rows_per_sample, int act, void* out, long ldc, int col_off, int dtype, void* stream);
-/* cs_op_linear with the TILED layout of the GEGLU intermediate (round 5): [M / 256][K / 64][256 rows][64 halfs] blocks, so that a k step's A stage of the consuming GEMM is
- * one contiguous 32 KB block instead of 256 pieces of 128 B at a stride of K * 2 bytes.  out_tiled (geglu != 0): the output [M][N / 2] is written in that layout;
- * a_tiled: x is read in it (one source, M % 256 == 0).  Only the 256 x 320 GEMM kernel reads the layout: cs_op_linear_tiled_ok(M, K, N) tells whether a linear layer of that
- * shape runs on it under the current knobs; a_tiled on any other path is CS_E_UNSUPPORTED.  Inside cs_unet_forward: the tensor between ff.net.0.proj (GEGLU) and ff.net.2 of
- * diffusers' FeedForward at the 64 x 64 and 32 x 32 levels (knob "ff_tiled", default 1; bit-identical to the row-major path). */
-int cs_op_linear_tiled_ok(int M, int K, int N);
-int cs_op_linear_tiled(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, void* out, int geglu, int a_tiled, int out_tiled, void* stream);
 /* cs_op_gemm2's gated-residual form on a SPLIT residual stream (round 5; FLUX hidden states as hi + lo planes of the model dtype, value = hi + lo):
  * out + out_lo = (res + res_lo) + gate * T(x . w + bias), the sum taken in fp32; out_lo = T(value - float(out)).  res / res_lo / out / out_lo are [M][N]; out may
  * alias res and out_lo res_lo.  tail_ws: optional split-K tail scratch (cs_op_gemm2_workspace).  Replaces `hidden_states = hidden_states + gate * attn_output` and

@@ -13,7 +13,7 @@
 
 int g_tune_attn_lw = 1, g_tune_attn_prio = -1, g_tune_attn_qt40 = 4, g_tune_biggemm = 1, g_tune_conv_lw = 1, g_tune_debug = 0, g_tune_gemm2_prio = 0,
     g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1, g_tune_epi_fast = 1,
-    g_tune_xattn_tile = 64, g_tune_ff_tiled = 1;
+    g_tune_xattn_tile = 64;
 
 // ---- HIP runtime -------------------------------------------------------------------------------------------------------
 extern "C" {
@@ -52,7 +52,6 @@ int launch_igemm(const IgemmArgs& a, hipStream_t) {
     if (a.splitk_ws) wr(a.splitk_ws, a.splitk_ws_bytes);
     return CS_OK;
 }
-bool igemm_tiled_ok(int M, int K, int N) { return M % 256 == 0 && K % 64 == 0 && N % 320 == 0 && (M / 256) * (N / 320) >= 192; }
 int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(stats, (size_t)M * 8); return CS_OK; }
 int launch_attention(const AttnArgs& a, hipStream_t) {
     const size_t C = (size_t)a.H * a.dh;

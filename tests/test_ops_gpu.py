@@ -649,33 +649,3 @@ def test_conv3x3_wider_than_the_loader_wave_zero_region_falls_back():
     assert rel_l2(nchw(out), ref) < 1e-3
     border = torch.ones(H, H, dtype=torch.bool); border[1:-1, 1:-1] = False
     assert rel_l2(nchw(out)[..., border], ref[..., border]) < 1e-3
-
-
-@pytest.mark.parametrize("M,C", [(65536, 320), (16384, 320), (32768, 640), (2048, 1280)])
-def test_geglu_intermediate_in_the_tiled_layout(M, C):
-    """round 5: FF1 (GEGLU) -> FF2 with the intermediate [M][4 C] in [M / 256][4 C / 64][256][64] blocks (IgemmArgs::out_tiled / a_tiled): the intermediate is the row-major
-    tensor re-tiled, bit for bit, and FF2 on it equals FF2 on the row-major tensor bit for bit (the same fragments multiplied in the same order); shapes whose FF2 does not run
-    on the 256 x 320 GEMM kernel are refused (and the executor does not ask for the layout there)."""
-    from consolver_amd import _lib as L
-    lib, st = L.lib(), L.stream_ptr(DEV)
-    x = rnd(M, C, seed=1)
-    w1, b1 = rnd(8 * C, C, seed=2, scale=C ** -0.5), rnd(8 * C, seed=3, scale=0.1)
-    w1p, b1p = ops.geglu_pack(w1, b1)
-    w1p, b1p = w1p.to(DEV), b1p.to(DEV)
-    w2, b2 = rnd(C, 4 * C, seed=4, scale=(4 * C) ** -0.5), rnd(C, seed=5, scale=0.1)
-    res = rnd(M, C, seed=6)
-    ok = bool(lib.cs_op_linear_tiled_ok(M, 4 * C, C))
-    ff_row = ops.linear(x, w1p, b1p, geglu=True)
-    out_row = ops.linear(ff_row, w2, b2, res=res)
-    ff_t = torch.empty_like(ff_row)
-    L.check(lib.cs_op_linear_tiled(x.data_ptr(), M, C, w1p.data_ptr(), b1p.data_ptr(), 8 * C, None, ff_t.data_ptr(), 1, 0, 1, st))
-    want = ff_row.view(M // 256, 256, 4 * C // 64, 64).permute(0, 2, 1, 3).contiguous().view(M, 4 * C)       # block (m / 256, k / 64), row m % 256
-    assert torch.equal(ff_t, want)
-    out_t = torch.empty_like(out_row)
-    rc = lib.cs_op_linear_tiled(ff_t.data_ptr(), M, 4 * C, w2.data_ptr(), b2.data_ptr(), C, res.data_ptr(), out_t.data_ptr(), 0, 1, 0, st)
-    assert (M, C, ok) in ((65536, 320, True), (16384, 320, False), (32768, 640, True), (2048, 1280, False))       # FF2 needs >= 192 tiles of 256 x 320
-    if ok:
-        L.check(rc)
-        assert torch.equal(out_t, out_row)
-    else:
-        assert rc != 0
