@@ -894,20 +894,18 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     if (!latents || !timesteps || !ctx || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
     if (n_timesteps != 1 && n_timesteps != n_lat * dup) CS_FAIL(CS_E_SHAPE, "n_timesteps must be 1 or the batch size");
     u->ev_used = 0;
-    // per-handle knob overrides: applied for the duration of this host call (every knob is read on the host while the launches are issued), restored afterwards
-    std::unique_lock<std::recursive_mutex> tune_lock(g_tune_mutex, std::defer_lock);
+    // per-handle knob overrides: applied for the duration of this host call (every knob is read on the host while the launches are issued), restored afterwards.  Every
+    // forward takes the lock -- also a handle without overrides must not read the process-wide knobs while another thread's forward has its own set installed
+    std::unique_lock<std::recursive_mutex> tune_lock(g_tune_mutex);
     std::vector<std::pair<std::string, int>> saved;
-    if (!u->tune.empty()) {
-        tune_lock.lock();
-        for (auto& kv : u->tune) {
-            int cur = 0;
-            if (cs_get_tuning(kv.first.c_str(), &cur) == CS_OK) { saved.push_back({kv.first, cur}); cs_set_tuning(kv.first.c_str(), kv.second); }
-        }
+    for (auto& kv : u->tune) {
+        int cur = 0;
+        if (cs_get_tuning(kv.first.c_str(), &cur) == CS_OK) { saved.push_back({kv.first, cur}); cs_set_tuning(kv.first.c_str(), kv.second); }
     }
     int rc = run_forward(u, false, (const f16*)latents, n_lat, dup, timesteps, n_timesteps, (const f16*)ctx, (f16*)out, (char*)workspace,
                          workspace_bytes, kv_cache_valid, (hipStream_t)stream);
     for (auto it = saved.rbegin(); it != saved.rend(); ++it) cs_set_tuning(it->first.c_str(), it->second);
-    if (tune_lock.owns_lock()) tune_lock.unlock();
+    tune_lock.unlock();
     if (rc == CS_OK && u->profiling) {
         CS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
         for (int k = 0; k < P_COUNT; ++k) { u->prof_ms[k] = u->prof_flops[k] = u->prof_bytes[k] = 0; u->prof_launches[k] = 0; }
