@@ -130,6 +130,31 @@ def test_engine_trajectory_full_sd15_two_steps():
     assert err < 1.17e-3, err                                     # measured 1.055e-3 (two steps from t = 999: the first step maps the eps error 1:1), + 10 %; 8 steps: tests/test_parity_e2e_gpu.py
 
 
+def test_engine_solver_state_dtype():
+    """SDSamplingEngine(latents_dtype=...): fp32 (default) returns fp32 latents and is closer to the fp32 oracle than the fp16 state (the reference fp16 pipeline's own class,
+    which rounds the latents once per step); both modes are deterministic; an unsupported dtype is refused."""
+    cfg = dict(layers_per_block=1, sample_size=16)
+    unet, sd, sch, w = make(cfg)
+    B, n, g = 2, 6, 3.0
+    idx = np.random.default_rng(9).integers(0, 11, size=(n, B, 3))
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
+    noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(43)).half()
+    want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g, cfg_over=cfg)
+    errs = {}
+    for dt in (torch.float32, torch.float16):
+        eng = SDSamplingEngine(unet, sch, guidance_scale=g, latents_dtype=dt)
+        outs = []
+        for rep in range(2):
+            sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+            outs.append(eng.generate(pe.to(DEV), ne.to(DEV), latents=noise.to(DEV), num_inference_steps=n).clone())
+        assert outs[0].dtype == dt and torch.equal(outs[0], outs[1])
+        errs[dt] = float(np.linalg.norm(outs[0].float().cpu().numpy() - want) / np.linalg.norm(want))
+    print(f"engine 6-step reduced unet: fp32 solver state {errs[torch.float32]:.3e}, fp16 state {errs[torch.float16]:.3e}")
+    assert errs[torch.float32] < errs[torch.float16]
+    with pytest.raises(ValueError):
+        SDSamplingEngine(unet, sch, latents_dtype=torch.bfloat16)
+
+
 def test_engine_pixel_output_matches_decode_of_its_latents():
     """output_type="pt" == decode_latents (utils.py:6-34) of the latents the same engine returns, and matches the
     fp32 VAE oracle applied to those latents (the decoder's own tolerance, tests/test_vae_gpu.py)."""

@@ -181,6 +181,57 @@ def test_full_size_fp32_cfg_trajectory():
     assert worst < 1e-6 and final < 1e-6, (worst, final)
 
 
+def test_fp32_solver_state_with_fp16_model_outputs():
+    """round 5: the engine's solver state.  An fp32 `sample` next to fp16 eps tensors (CsStepArgs::x_is_f32) is read unrounded and stays fp32 -- torch's promotion, and what
+    the reference's latents are from step 2 on with an fp32 policy net.  Against the fp32 oracle fed the same fp16-representable eps values the 8-step CFG trajectory
+    is fp32-class (<= 2e-6: the CFG combine is rounded to fp16 as the history entry on both sides), where the fp16 state sits at ~3e-4 per step; a 16-bit sample keeps its
+    dtype unless prev_sample_dtype asks for the promotion; out= of the wrong dtype is refused."""
+    rng = np.random.default_rng(3)
+    B, n, order, guidance = 4, 8, 4, 3.0
+    s = consolver_amd.PPOScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing", order_dim=order, scaler_dim=0,
+                                   factor_net_kwargs=dict(hidden_dim=64, num_actions=11))
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in s.factor_net.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    w = {k: v.numpy().copy() for k, v in s.factor_net.state_dict().items()}
+    s.factor_net.to(DEV)
+    orc = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing", order_dim=order, scaler_dim=0,
+                                num_actions=11, weights=w)
+    s.set_timesteps(n, device=DEV); orc.set_timesteps(n)
+    x0 = rng.standard_normal((B, 4, 64, 64)).astype(np.float32)                 # NOT fp16-representable: an fp32 state
+    x, xo = cu(x0, torch.float32), x0
+    x16 = cu(so.round_like(x0, "f16"), torch.float16)
+    for i, t in enumerate(s.timesteps):
+        eu = so.round_like(rng.standard_normal(x0.shape).astype(np.float32), "f16")
+        ec = so.round_like((eu + 0.3 * rng.standard_normal(x0.shape)).astype(np.float32), "f16")
+        idx = rng.integers(0, 11, size=(B, order - 1))
+        s.factor_net.forced_action_idx = cu(idx, torch.int64)
+        prev = s.step(cu(ec, torch.float16), t, x, return_dict=False, eps_uncond=cu(eu, torch.float16), guidance_scale=guidance)[0]
+        assert prev.dtype == torch.float32
+        xo = orc.step(so.round_like(so.cfg_combine(eu, ec, guidance), "f16"), int(t), xo, idx, cond_dtype="f16")["prev_sample"]
+        assert rel_l2(prev.cpu().numpy(), xo) < 2e-6, i
+        x = prev
+    # a 16-bit sample keeps its dtype ... unless the promotion is asked for
+    s.set_timesteps(n, device=DEV)
+    s.factor_net.forced_action_idx = cu(np.zeros((B, order - 1), np.int64), torch.int64)
+    e16 = cu(so.round_like(rng.standard_normal(x0.shape).astype(np.float32), "f16"), torch.float16)
+    assert s.step(e16, s.timesteps[0], x16, return_dict=False)[0].dtype == torch.float16
+    s.set_timesteps(n, device=DEV)
+    s.prev_sample_dtype = torch.float32
+    try:
+        p32 = s.step(e16, s.timesteps[0], x16, return_dict=False)[0]
+        assert p32.dtype == torch.float32
+        s.set_timesteps(n, device=DEV)
+        with pytest.raises(ValueError):
+            s.step(e16, s.timesteps[0], x16, return_dict=False, out=torch.empty_like(x16))
+    finally:
+        s.prev_sample_dtype = None
+    s.set_timesteps(n, device=DEV)
+    p16 = s.step(e16, s.timesteps[0], x16, return_dict=False)[0]
+    assert torch.equal(p16, p32.to(torch.float16))                              # the same update, rounded once at the end
+
+
 def test_properties_full_size():
     """size-independent properties at BASELINE shape: order-1 limit == DDIM, linearity in eps,
     coefficient sum == 1 (constant eps history is a fixed point of the combine)."""
