@@ -348,6 +348,60 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
         sample0 = m_base / p.rows_per_sample;
         one_sample = (min(m_base + 63, p.M - 1) / p.rows_per_sample) == sample0;
     }
+    if constexpr (X2) {
+        // ---- split residual stream: the branch value stays FP32 through the patch (four passes of 32 columns, same 144-byte rows), so the sum (res + res_lo) + gate * v
+        // is rounded ONCE, into hi and lo.  The 16-bit patch rounded v to T before the gate multiplied it: 2^-9 of a contribution ~0.3 of the stream, 95 times per forward in
+        // quadrature ~ 3e-3 of the 4.0e-3 the split stream measured at full depth.
+        constexpr int C32 = 32;
+        const int pc4 = lane & 7;                                   // 16-byte chunk = 4 columns
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = grp * 2 + ii;
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    *reinterpret_cast<f32x4*>(patch + (j * 16 + i16) * ROWB + (ii * 16 + g4) * 4) = acc[i][j];
+            }
+            const int n = n_base + grp * C32 + pc4 * 4;
+            const bool n_ok = n < p.N;
+            size_t off[CH]; bool ok[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int m = m_base + prow + 8 * k;
+                ok[k] = n_ok && m < p.M;
+                off[k] = (size_t)rowmap(ok[k] ? m : 0, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + (n_ok ? n : 0);
+            }
+            u32x2 rv[CH], rvl[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) { rv[k] = *reinterpret_cast<const u32x2*>(p.res + off[k]); rvl[k] = *reinterpret_cast<const u32x2*>(p.res_lo + off[k]); }
+            f32x4 g0 = {1.f, 1.f, 1.f, 1.f};
+            if (p.gate && one_sample && n_ok) g0 = *reinterpret_cast<const f32x4*>(p.gate + (size_t)sample0 * p.gate_stride + n);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(patch + (prow + 8 * k) * ROWB + pc4 * 16);
+                if (p.gate && !one_sample && ok[k])
+                    g0 = *reinterpret_cast<const f32x4*>(p.gate + (size_t)((m_base + prow + 8 * k) / p.rows_per_sample) * p.gate_stride + n);
+                float f[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[r] = v[r] * g0[r];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    f[2 * r] += El<T>::tof((u16)(rv[k][r] & 0xffff)) + El<T>::tof((u16)(rvl[k][r] & 0xffff));
+                    f[2 * r + 1] += El<T>::tof((u16)(rv[k][r] >> 16)) + El<T>::tof((u16)(rvl[k][r] >> 16));
+                }
+                u32x2 o, l;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const u16 h0 = El<T>::fromf(f[2 * r]), h1 = El<T>::fromf(f[2 * r + 1]);
+                    o[r] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    l[r] = (unsigned)El<T>::fromf(f[2 * r] - El<T>::tof(h0)) | ((unsigned)El<T>::fromf(f[2 * r + 1] - El<T>::tof(h1)) << 16);
+                }
+                if (ok[k]) { *reinterpret_cast<u32x2*>(p.out + off[k]) = o; *reinterpret_cast<u32x2*>(p.out_lo + off[k]) = l; }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
         // ---- phase 1: registers -> LDS patch [64 rows][64 cols] (bias is already in the accumulators) ----
@@ -375,14 +429,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
             off[k] = (size_t)rowmap(ok[k] ? m : 0, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + (n_ok ? n : 0);
         }
         if (p.res || p.gate) {
-            u32x4 rv[CH], rvl[X2 ? CH : 1];
+            u32x4 rv[CH];
             if (p.res) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) rv[k] = *reinterpret_cast<const u32x4*>(p.res + off[k]);
-            }
-            if constexpr (X2) {
-#pragma unroll
-                for (int k = 0; k < CH; ++k) rvl[k] = *reinterpret_cast<const u32x4*>(p.res_lo + off[k]);
             }
             f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
             if (p.gate && one_sample && n_ok) {
@@ -407,21 +457,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(G2Pair pp) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rv[k][r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rv[k][r] >> 16)); }
                 }
-                if constexpr (X2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { f[2 * r] += El<T>::tof((u16)(rvl[k][r] & 0xffff)); f[2 * r + 1] += El<T>::tof((u16)(rvl[k][r] >> 16)); }
-                }
                 u32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (unsigned)El<T>::fromf(f[2 * r]) | ((unsigned)El<T>::fromf(f[2 * r + 1]) << 16);
                 if (ok[k]) *reinterpret_cast<u32x4*>(p.out + off[k]) = o;
-                if constexpr (X2) {          // lo = T(value - float(hi)): hi + lo carries twice the significand
-                    u32x4 l;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        l[r] = (unsigned)El<T>::fromf(f[2 * r] - El<T>::tof((u16)(o[r] & 0xffff))) | ((unsigned)El<T>::fromf(f[2 * r + 1] - El<T>::tof((u16)(o[r] >> 16))) << 16);
-                    if (ok[k]) *reinterpret_cast<u32x4*>(p.out_lo + off[k]) = l;
-                }
             }
         } else {
 #pragma unroll
@@ -463,8 +502,10 @@ __global__ __launch_bounds__(256) void g2_tail_reduce_kernel(G2Pair pp) {
         for (int k = 0; k < 4; ++k) { f[2 * k] += El<T>::tof((u16)(t[k] & 0xffff)); f[2 * k + 1] += El<T>::tof((u16)(t[k] >> 16)); }
     }
     // same rounding points as the in-kernel epilogue: the biased (and activated) value is rounded to T before gate / residual
+    if (!p.out_lo) {                 // (the split-stream epilogue keeps the branch value in fp32: one rounding, of the sum, into hi and lo)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = El<T>::tof(El<T>::fromf(p.act == 1 ? gelu_tanh(f[k]) : f[k]));
+        for (int k = 0; k < 8; ++k) f[k] = El<T>::tof(El<T>::fromf(p.act == 1 ? gelu_tanh(f[k]) : f[k]));
+    }
     const size_t off = (size_t)rowmap(m, p.c_seg, p.c_stride, p.c_off) * p.ldc + p.c_col + n;
     if (p.gate) {
         const float* gp = p.gate + (size_t)(m / p.rows_per_sample) * p.gate_stride + n;
