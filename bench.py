@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--traffic", default="live", choices=["live", "committed", "none"],
                     help="roofline.traffic: 'live' (N = 1) measures FETCH_SIZE / WRITE_SIZE with two rocprofv3 --pmc child runs of tools/bench_unet.py after the "
                          "timed region (falls back to the newest committed profiles/r*_pmc_traffic.json), 'committed' quotes that file only")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the N > 1 barrier / all_reduce(MAX) / per-rank all-gather "
+                    "branch even at world size 1 (a one-GPU box exercising the exact code an 8-GPU launch runs; tests/test_engine_gpu.py)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch / rendezvous / sharding / reduction path without touching a GPU")
     args = ap.parse_args()
 
@@ -400,9 +402,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                      # (--force-dist outside torch.distributed.run: a free local port)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import consolver_amd

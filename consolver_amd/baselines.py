@@ -33,8 +33,12 @@ class DDIMBaselineScheduler(PPOScheduler):
         L.require_cuda(model_output, "model_output")
         L.require_cuda(sample, "sample")
         model_output, sample = model_output.contiguous(), sample.contiguous()
-        if sample.dtype != model_output.dtype:
+        # same dtype rule as PPOScheduler.step: an fp32 sample next to a 16-bit model output stays fp32 through the update (CsStepArgs::x_is_f32, the
+        # engine's default solver state); any other mismatch is cast to the model output's dtype
+        if sample.dtype != model_output.dtype and sample.dtype != torch.float32:
             sample = sample.to(model_output.dtype)
+        if self.prev_sample_dtype is not None and sample.dtype != self.prev_sample_dtype:
+            sample = sample.to(self.prev_sample_dtype)
         dev, B = model_output.device, model_output.shape[0]
         t = self._resolve_timestep(timestep)
         prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
@@ -44,6 +48,8 @@ class DDIMBaselineScheduler(PPOScheduler):
         if self._zero_actions is None or self._zero_actions.shape[0] < B or self._zero_actions.device != dev:
             self._zero_actions = torch.zeros(max(B, 1), 1, dtype=torch.float32, device=dev)
         prev = out if out is not None else torch.empty_like(sample)
+        if prev.dtype != sample.dtype:
+            raise ValueError(f"step(out=...) must have the sample's dtype {sample.dtype}, got {prev.dtype}")
         eps_out = torch.empty_like(model_output) if eps_uncond is not None else None     # the kernel writes the combined eps
         a = L.CsStepArgs()
         self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, self._zero_actions, prev, eps_out, sample.dtype)
@@ -69,7 +75,9 @@ class FlowMatchEulerBaselineScheduler(FMPPOScheduler):
         L.require_cuda(model_output, "model_output")
         L.require_cuda(sample, "sample")
         model_output = model_output.contiguous()
-        sample = sample.contiguous().to(model_output.dtype)
+        sample = sample.contiguous()
+        if sample.dtype != model_output.dtype and sample.dtype != torch.float32:        # (an fp32 sample is consumed as fp32: scheduler_fm.py upcasts it, FMPPOScheduler.step does the same)
+            sample = sample.to(model_output.dtype)
         dev, B = model_output.device, model_output.shape[0]
         i = self._step_index
         dt = np.float32(self._sigmas[i + 1] - self._sigmas[i])
@@ -77,6 +85,8 @@ class FlowMatchEulerBaselineScheduler(FMPPOScheduler):
         if self._zero_actions is None or self._zero_actions.shape[0] < B or self._zero_actions.device != dev:
             self._zero_actions = torch.zeros(max(B, 1), 1, dtype=torch.float32, device=dev)
         prev = out if out is not None else torch.empty_like(model_output)
+        if prev.dtype != model_output.dtype:                                           # the Euler result is rounded to the model dtype (scheduler_fm.py:410), whatever the sample's
+            raise ValueError(f"step(out=...) must have the model output's dtype {model_output.dtype}, got {prev.dtype}")
         a = L.CsStepArgs()
         self._fill_step_args(a, sample, model_output, None, 1.0, self._zero_actions, prev, None, model_output.dtype)
         a.dt = float(dt)

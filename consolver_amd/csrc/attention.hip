@@ -21,10 +21,6 @@
 #include "el.h"
 #include <type_traits>
 
-int g_tune_attn_qt40 = 4;
-int g_tune_attn_prio = -1;
-extern int g_tune_debug;
-int g_tune_attn_lw = 1;        // 1: head dim 40 self-attention (Nq % 256 == 0, Nk % 64 == 0) runs attn40_lw_kernel (loader waves + hand-placed stream), 2: the same with 16x16x32 MFMAs for both k steps (bit-identical to attn_kernel), 0: attn_kernel     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
 
 namespace {
 
@@ -991,9 +987,9 @@ int launch_attn(AttnParams p, int B, hipStream_t s, void* split_ws = nullptr, si
 constexpr int A40_NS = 6;
 int launch_attn40_lw(AttnParams p, int B, hipStream_t s) {
     constexpr size_t lds = (size_t)A40_NS * 12288;
-    const bool trace = (g_tune_debug & 16384) != 0;
-    auto kfn = trace ? ((g_tune_debug & 1) ? attn40_lw_kernel<A40_NS, true, 1> : (g_tune_debug & 2) ? attn40_lw_kernel<A40_NS, true, 2> : attn40_lw_kernel<A40_NS, true>)
-                     : g_tune_attn_lw == 2 ? attn40_lw_kernel<A40_NS, false, 0, 0, false> : attn40_lw_kernel<A40_NS, false>;
+    const bool trace = (tune().debug & 16384) != 0;
+    auto kfn = trace ? ((tune().debug & 1) ? attn40_lw_kernel<A40_NS, true, 1> : (tune().debug & 2) ? attn40_lw_kernel<A40_NS, true, 2> : attn40_lw_kernel<A40_NS, true>)
+                     : tune().attn_lw == 2 ? attn40_lw_kernel<A40_NS, false, 0, 0, false> : attn40_lw_kernel<A40_NS, false>;
     static bool configured = false;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn40_lw_kernel<A40_NS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1036,7 +1032,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     p.H = a.H; p.Nq = a.Nq; p.Nk = a.Nk;
     p.c = a.scale * 1.4426950408889634f;
     p.bias = a.bias;
-    p.prio = g_tune_attn_prio < 0 ? (a.dh == 128 ? 1 : 0) : g_tune_attn_prio;
+    p.prio = tune().attn_prio < 0 ? (a.dh == 128 ? 1 : 0) : tune().attn_prio;
     if (a.bias) {
         if (a.dh != 64 || a.causal || a.Nk % 4) CS_FAIL(CS_E_UNSUPPORTED, "attention: the biased form is built for head dim 64, no mask, Nk %% 4 == 0");
         if (a.dtype == CS_BF16) return launch_attn<bf16_el, 64, 2, false, true>(p, a.B, s);
@@ -1048,9 +1044,9 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     }
     switch (a.dh) {
         case 40: {
-            const int qt = g_tune_attn_qt40;      // cs_set_tuning("attn_qt40", 2 | 4): query tiles per wave at head dim 40
+            const int qt = tune().attn_qt40;      // cs_set_tuning("attn_qt40", 2 | 4): query tiles per wave at head dim 40
             if (a.dtype == CS_BF16) CS_FAIL(CS_E_UNSUPPORTED, "attention: bf16 is built for head dim 128 only");
-            if (g_tune_attn_lw && qt == 4 && a.Nq % 256 == 0 && a.Nk % 64 == 0) return launch_attn40_lw(p, a.B, s);
+            if (tune().attn_lw && qt == 4 && a.Nq % 256 == 0 && a.Nk % 64 == 0) return launch_attn40_lw(p, a.B, s);
             if (qt == 4) return launch_attn<f16, 40, 4>(p, a.B, s);
             return launch_attn<f16, 40, 2>(p, a.B, s);
         }

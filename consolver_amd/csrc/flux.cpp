@@ -228,6 +228,10 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     if (Rn.attn_ws_bytes) Rn.attn_ws = Rn.alloc(Rn.attn_ws_bytes);
     if (Rn.rc != CS_OK) return Rn.rc;
 
+    // device copies / memsets of the stream planes go through the run's error state: a failed one must not leave uninitialised workspace in the epilogues' adds
+    auto hipok = [&](hipError_t e_, const char* what) {
+        if (e_ != hipSuccess && Rn.rc == CS_OK) { cs_set_error("flux: %s failed: %s", what, hipGetErrorString(e_)); Rn.rc = CS_E_HIP; }
+    };
     // ---- conditioning vector and all adaLN modulations -----------------------------------------------------
     if (!dry) {
         Rn.rc = launch_sinusoid_f32(timestep, 1000.0f, B, 256, sin_t, s);
@@ -250,7 +254,7 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
         Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D);
     Rn.gemm(f->c_emb, enc, c.joint_attention_dim, B * T, ctx, D);
     if (split && !dry && Rn.rc == CS_OK) {
-        hipMemsetAsync(img_lo, 0, (size_t)B * I * D * e, s); hipMemsetAsync(ctx_lo, 0, (size_t)B * T * D * e, s);
+        hipok(hipMemsetAsync(img_lo, 0, (size_t)B * I * D * e, s), "memset img_lo"); hipok(hipMemsetAsync(ctx_lo, 0, (size_t)B * T * D * e, s), "memset ctx_lo");
     }
 
     // ---- double-stream blocks -----------------------------------------------------------------------------------
@@ -273,11 +277,11 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     // ---- joint sequence [context | image] ---------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK) {
         for (int b = 0; b < B; ++b) {
-            hipMemcpyAsync(hs + ((size_t)b * S) * D, ctx + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s);
-            hipMemcpyAsync(hs + ((size_t)b * S + T) * D, img + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s);
+            hipok(hipMemcpyAsync(hs + ((size_t)b * S) * D, ctx + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s), "copy ctx -> joint");
+            hipok(hipMemcpyAsync(hs + ((size_t)b * S + T) * D, img + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s), "copy img -> joint");
             if (split) {
-                hipMemcpyAsync(hs_lo + ((size_t)b * S) * D, ctx_lo + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s);
-                hipMemcpyAsync(hs_lo + ((size_t)b * S + T) * D, img_lo + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s);
+                hipok(hipMemcpyAsync(hs_lo + ((size_t)b * S) * D, ctx_lo + (size_t)b * T * D, (size_t)T * D * e, hipMemcpyDeviceToDevice, s), "copy ctx_lo -> joint");
+                hipok(hipMemcpyAsync(hs_lo + ((size_t)b * S + T) * D, img_lo + (size_t)b * I * D, (size_t)I * D * e, hipMemcpyDeviceToDevice, s), "copy img_lo -> joint");
             }
         }
     }
@@ -298,8 +302,8 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     // ---- output head on the image tokens ----------------------------------------------------------------------------------
     if (!dry && Rn.rc == CS_OK)
         for (int b = 0; b < B; ++b) {
-            hipMemcpyAsync(img + (size_t)b * I1 * D, hs + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s);
-            if (split) hipMemcpyAsync(img_lo + (size_t)b * I1 * D, hs_lo + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s);
+            hipok(hipMemcpyAsync(img + (size_t)b * I1 * D, hs + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s), "copy joint -> img");
+            if (split) hipok(hipMemcpyAsync(img_lo + (size_t)b * I1 * D, hs_lo + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s), "copy joint_lo -> img_lo");
         }
     const float* mf = mod + f->mod_final;                                         // AdaLayerNormContinuous: [scale, shift]
     Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS, img_lo);

@@ -17,8 +17,6 @@
 
 #include <utility>
 
-int g_tune_gemm2_prio = 0;
-int g_tune_gemm2_w8 = 1;       // 1: main launches run the hand-scheduled k loop (W8 instantiation of gemm2_kernel; bit-identical), 0: the compiler-scheduled one
 
 namespace {
 
@@ -603,7 +601,7 @@ static int g2_launch_t(const G2Pair& pp, hipStream_t s, dim3 grid) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<T, ACT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    const bool w8 = g_tune_gemm2_w8 && pp.splits == 1 && g2_fits32(pp.p[0]) && g2_fits32(pp.p[1]);
+    const bool w8 = tune().gemm2_w8 && pp.splits == 1 && g2_fits32(pp.p[0]) && g2_fits32(pp.p[1]);
     if constexpr (ACT == 0) {
         if (pp.p[0].out_lo) {                 // split residual stream (both problems of a pair: g2_run checks)
             static bool configured2 = false;
@@ -656,7 +654,7 @@ size_t gemm2_tail_workspace_bytes(int tiles, int K) {
 }
 
 static int g2_run(G2Pair pp, int dtype, void* tail_ws, size_t tail_ws_bytes, hipStream_t s) {
-    pp.id0 = 0; pp.splits = 1; pp.partial = nullptr; pp.prio = g_tune_gemm2_prio;
+    pp.id0 = 0; pp.splits = 1; pp.partial = nullptr; pp.prio = tune().gemm2_prio;
     const bool two = pp.nblk > pp.nblk0;
     int tail = 0;
     const int sp = tail_ws ? g2_tail_splits(pp.nblk, two ? std::min(pp.p[0].KT, pp.p[1].KT) : pp.p[0].KT, &tail) : 0;

@@ -24,12 +24,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-extern int g_tune_halo;
-extern int g_tune_conv_lw;
-extern int g_tune_gemm_w8;
-extern int g_tune_gemm_lw;
-extern int g_tune_debug;
-extern int g_tune_biggemm;
 
 namespace {
 
@@ -1992,23 +1986,13 @@ int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
 
 }  // namespace
 
-int g_tune_debug = 0;
-int g_tune_gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
-int g_tune_gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
-int g_tune_halo = 1;
-int g_tune_gemm_lw = 1;         // 1: the 256 x 160 linear / 1x1 layers (too few 256 x 320 tiles) through gemm_lw_kernel (loader waves), 0: gemm_big_kernel<false, 160>
-int g_tune_gemm_w8 = 1;         // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
-int g_tune_conv_lw = 1;         // 1: stride-1 3x3 convs with N % 160 == 0 or N % 128 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 3: N % 160 == 0 only, 0: the 8-wave halo kernels
-int g_tune_biggemm = 1;
 // extra dynamic LDS of the folded-LayerNorm consumer instantiations (ln_tile_prologue): 256 rows x 8 B + the (b' | s) tables
 constexpr size_t LN_LDS_W8 = 256 * 8 + 2 * 2 * 160 * 4, LN_LDS_LW = 256 * 8 + 2 * 160 * 4;
-int g_tune_epi_fast = 1;        // 1: the FAST forms of the fp32-patch epilogue (all loads of a pass in front of its phase 1) in conv3_lw / gemm_w8 / gemm_lw, 0: the generic code
-int g_tune_xcd_grid = 1;        // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
 
 // tile_of's pn for a launch of tiles_m x tiles_n tiles that reads a_bytes of activations and w_bytes of weights once each algorithmically: per-XCD L2s mean the
 // contiguous order fetches a + 8 w, an (8 / pn) x pn grid pn a + (8 / pn) w.  Switch only for a clear gain (the contiguous order has the banded walk, IgemmParams::gm).
 static int choose_xcd_grid(int tiles_m, int tiles_n, double a_bytes, double w_bytes) {
-    if (!g_tune_xcd_grid) return 0;
+    if (!tune().xcd_grid) return 0;
     int best = 0; double best_cost = 0.85 * (a_bytes + 8.0 * w_bytes);
     for (int pn = 2; pn <= 8; pn *= 2) {
         const int px = 8 / pn;
@@ -2078,11 +2062,11 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
         p.KT = 2 * p.KTh;                                  // Ktot (row length of w) stays cin: the lo k steps re-read the same weight columns
     }
     if (a.geglu && a.out_lo) CS_FAIL(CS_E_ARG, "igemm: the GEGLU epilogue writes no lo plane");
-    p.debug = g_tune_debug; p.partial = nullptr;
+    p.debug = tune().debug; p.partial = nullptr;
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
-    const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && g_tune_gn_fuse != 0;
+    const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && tune().gn_fuse != 0;
     p.gn_stats = stats_ok ? a.gn_stats : nullptr;
-    p.gm = 1; p.pn = 0; p.epi_fast = g_tune_epi_fast;
+    p.gm = 1; p.pn = 0; p.epi_fast = tune().epi_fast;
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * cin, w_bytes = 2.0 * a.N * a.taps * cin;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
@@ -2091,10 +2075,10 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     else CS_FAIL(CS_E_SHAPE, "igemm: N=%d must be a multiple of 128 or 160", a.N);
     p.tiles_n = a.N / bn; p.nblk = tiles_m * p.tiles_n;
     const bool conv3 = a.taps == 9;
-    const int use_halo = g_tune_halo;   // 0 = never, 1 = when it pays, 2 = whenever the shape allows (tests)
+    const int use_halo = tune().halo;   // 0 = never, 1 = when it pays, 2 = whenever the shape allows (tests)
     const int Wo = a.upsample ? 2 * a.Wi : a.Wi, Ho = a.upsample ? 2 * a.Hi : a.Hi;
     int hbn = a.N % 160 == 0 ? 160 : (a.N % 128 == 0 ? 128 : 0);
-    // 256 x 320 tiles (k32 inner step) when they still fill the chip: SD1.5's 320- and 640-wide layers at 64 x 64 / 32 x 32 (g_tune_halo 3 forces,
+    // 256 x 320 tiles (k32 inner step) when they still fill the chip: SD1.5's 320- and 640-wide layers at 64 x 64 / 32 x 32 (tune().halo 3 forces,
     // 4 forbids: tests / A-B)
     bool wide = false;
     // patch geometry: TW = min(Wo, 16) in {8, 16}; TH = min(Ho, 256 / TW); both powers of two dividing the image
@@ -2106,13 +2090,13 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
         const int TRW = TH * TW, IPT = 256 / TRW;                       // output pixels per image in a tile; images per tile
         const int PX = Wo / TW, PY = Ho / TH, PP = PX * PY;
         const int tiles_m = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP;
-        if (a.N % 320 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 320) >= 192 || g_tune_halo == 3)) { hbn = 320; wide = true; }
-        else if (a.N % 256 == 0 && g_tune_halo != 4 && (tiles_m * (a.N / 256) >= 192 || g_tune_halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
+        if (a.N % 320 == 0 && tune().halo != 4 && (tiles_m * (a.N / 320) >= 192 || tune().halo == 3)) { hbn = 320; wide = true; }
+        else if (a.N % 256 == 0 && tune().halo != 4 && (tiles_m * (a.N / 256) >= 192 || tune().halo == 3)) { hbn = 256; wide = true; }   // VAE: 256 / 512 channels
         // round 3: loader-wave kernel (256 pixels x 160 channels per workgroup) wherever the channel count allows it
         // (conv3_lw_kernel's padded halo rows read g_zero_region + chunk offset: the region covers LW_ZERO_CHUNKS 64-channel chunks, wider inputs take the halo kernels)
         const bool lw_cin_ok = cin / BK <= LW_ZERO_CHUNKS;
-        const bool lw160 = g_tune_conv_lw != 0 && a.N % 160 == 0 && lw_cin_ok;
-        const bool lw128 = g_tune_conv_lw != 0 && g_tune_conv_lw != 3 && !lw160 && a.N % 128 == 0 && lw_cin_ok;        // the VAE's widths 128 / 256 / 512 (conv_lw = 3: BN 160 only)
+        const bool lw160 = tune().conv_lw != 0 && a.N % 160 == 0 && lw_cin_ok;
+        const bool lw128 = tune().conv_lw != 0 && tune().conv_lw != 3 && !lw160 && a.N % 128 == 0 && lw_cin_ok;        // the VAE's widths 128 / 256 / 512 (conv_lw = 3: BN 160 only)
         const bool lw = lw160 || lw128;
         if (lw) { hbn = lw160 ? 160 : 128; wide = false; }
         const int tiles_n = a.N / hbn;
@@ -2141,9 +2125,9 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
                 constexpr size_t llw_max = 2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128);      // = 160 KiB exactly: the whole LDS of a CU
                 const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)hbn * 128);
                 // FAST: plain conv on 16 x 16 patches (every UNet level down to 16 x 16, the VAE): immediate-offset LDS addressing
-                const bool fast = TW == 16 && TH == 16 && g_tune_conv_lw != 2 && (a.upsample ? (h.HALO_W == 10 && h.NQ == 13) : (h.HALO_W == 18 && h.NQ == 41));
-                const bool fast8 = hbn == 160 && TW == 8 && TH == 8 && !a.upsample && IPT == 4 && PP == 1 && h.HALO_W == 10 && h.NQ == 50 && g_tune_conv_lw != 2 &&
-                                   !((g_tune_debug & 16384) != 0);
+                const bool fast = TW == 16 && TH == 16 && tune().conv_lw != 2 && (a.upsample ? (h.HALO_W == 10 && h.NQ == 13) : (h.HALO_W == 18 && h.NQ == 41));
+                const bool fast8 = hbn == 160 && TW == 8 && TH == 8 && !a.upsample && IPT == 4 && PP == 1 && h.HALO_W == 10 && h.NQ == 50 && tune().conv_lw != 2 &&
+                                   !((tune().debug & 16384) != 0);
                 typedef void (*lw_fn)(HaloParams);
                 static const lw_fn variants[11] = {conv3_lw_kernel<false, 160, false, true>, conv3_lw_kernel<false, 160>, conv3_lw_kernel<true, 160>,
                                                    conv3_lw_kernel<false, 160, true, true>, conv3_lw_kernel<false, 160, true, false>, conv3_lw_kernel<true, 160, false, true>,
@@ -2156,7 +2140,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
                     configured_lw = true;
                 }
                 auto launch = [&](lw_fn kfn) -> int { hipLaunchKernelGGL(kfn, grid, dim3(512), llw, s, h); return CS_OK; };
-                const bool trace = (g_tune_debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations (plain conv only)
+                const bool trace = (tune().debug & 16384) && !a.upsample;    // timing experiments: the stamped instantiations (plain conv only)
                 if (fast8) rc = launch(variants[10]);
                 else if (hbn == 128) rc = launch(variants[a.upsample ? (fast ? 9 : 8) : (fast ? 6 : 7)]);
                 else if (trace) rc = launch(variants[fast ? 3 : 4]);
@@ -2176,11 +2160,11 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
         }
     }
     if (a.geglu && conv3) CS_FAIL(CS_E_ARG, "igemm: GEGLU epilogue only for linear layers");
-    if (g_tune_biggemm && !conv3 && a.N % 320 == 0) {
+    if (tune().biggemm && !conv3 && a.N % 320 == 0) {
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 320;
-        if (tiles_m * tn >= 192 || g_tune_biggemm == 2) {
+        if (tiles_m * tn >= 192 || tune().biggemm == 2) {
             p.tiles_n = tn; p.nblk = tiles_m * tn; p.pn = choose_xcd_grid(tiles_m, tn, a_bytes, w_bytes); li->gn_done = stats_ok; li->row_groups = a.N / 160;      // gemm_w8 / gemm_big<., 320>: 64 x 160 wave tiles
-            p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
+            p.gm = tune().gemm_gm >= 0 ? (tune().gemm_gm > 1 ? tune().gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 320 * BK * 2);
             static bool configured = false;
             if (!configured) {
@@ -2190,8 +2174,8 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
             }
             // round 3: the hand-scheduled k loop (gemm_w8_kernel) whenever 32-bit byte offsets reach every operand row
             const bool off32 = (double)p.M * (a.c0 > a.c1 ? a.c0 : a.c1) * 2 < 4.0e9 && (double)a.N * p.Ktot * 2 < 4.0e9;
-            if ((split_a || lnm) && !(g_tune_gemm_w8 && off32 && !g_tune_debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging and no LayerNorm epilogues
-            if (g_tune_gemm_w8 && off32 && !g_tune_debug) {
+            if ((split_a || lnm) && !(tune().gemm_w8 && off32 && !tune().debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging and no LayerNorm epilogues
+            if (tune().gemm_w8 && off32 && !tune().debug) {
                 typedef void (*w8_fn)(IgemmParams);
                 static const w8_fn w8[5] = {gemm_w8_kernel<false, 0>, gemm_w8_kernel<true, 0>, gemm_w8_kernel<false, 1>, gemm_w8_kernel<true, 1>, gemm_w8_kernel<false, 2>};
                 static bool configured_w8 = false;
@@ -2209,20 +2193,20 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
             return CS_OK;
         }
     }
-    if (g_tune_biggemm && !conv3 && !a.geglu && a.N % 160 == 0) {       // too few 256 x 320 tiles: 256 x 160 tiles, same 8-wave structure
+    if (tune().biggemm && !conv3 && !a.geglu && a.N % 160 == 0) {       // too few 256 x 320 tiles: 256 x 160 tiles, same 8-wave structure
         const int tiles_m = (p.M + 255) / 256, tn = a.N / 160;
-        if (tiles_m * tn >= 192 || g_tune_biggemm == 3) {
+        if (tiles_m * tn >= 192 || tune().biggemm == 3) {
             p.tiles_n = tn; p.nblk = tiles_m * tn; p.pn = choose_xcd_grid(tiles_m, tn, a_bytes, w_bytes); li->gn_done = stats_ok;
-            li->row_groups = (g_tune_gemm_lw && !g_tune_debug) ? a.N / 160 : a.N / 80;       // gemm_lw: 64 x 160 wave tiles; gemm_big<., 160>: 64 x 80
-            p.gm = g_tune_gemm_gm >= 0 ? (g_tune_gemm_gm > 1 ? g_tune_gemm_gm : 1) : (tn >= 12 ? 4 : 1);
+            li->row_groups = (tune().gemm_lw && !tune().debug) ? a.N / 160 : a.N / 80;       // gemm_lw: 64 x 160 wave tiles; gemm_big<., 160>: 64 x 80
+            p.gm = tune().gemm_gm >= 0 ? (tune().gemm_gm > 1 ? tune().gemm_gm : 1) : (tn >= 12 ? 4 : 1);
             constexpr size_t lds = 2 * (256 * BK * 2 + 160 * BK * 2);
             static bool configured = false;
             if (!configured) {
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            if ((split_a || lnm) && !(g_tune_gemm_lw && !g_tune_debug)) goto generic_tiles;
-            if (g_tune_gemm_lw && !g_tune_debug) {                    // round 3: the loader-wave form (three 52 KB stages)
+            if ((split_a || lnm) && !(tune().gemm_lw && !tune().debug)) goto generic_tiles;
+            if (tune().gemm_lw && !tune().debug) {                    // round 3: the loader-wave form (three 52 KB stages)
                 constexpr size_t lds_lw = 3 * (256 * BK * 2 + 160 * BK * 2);
                 typedef void (*lw_fn)(IgemmParams);
                 static const lw_fn lwk[3] = {gemm_lw_kernel<0>, gemm_lw_kernel<1>, gemm_lw_kernel<2>};

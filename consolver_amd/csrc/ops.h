@@ -3,6 +3,52 @@
 #pragma once
 #include "common.h"
 
+// ---- kernel-selection knobs (cs_set_tuning / cs_unet_set_tuning) -------------------------------------------------------------------------------------
+// One process-wide set (cs_set_tuning) and, for the duration of a host call that runs with per-handle overrides (cs_unet_forward on a handle with
+// cs_unet_set_tuning entries), a per-THREAD set: the call builds its own TuneSet (process-wide values + the handle's overrides) on its stack and installs a
+// pointer to it in `t_tune`; every launcher reads the knobs through tune().  Nothing writes the process-wide set on behalf of a handle, so another thread's
+// forward / op call never sees a handle's overrides, and forwards of different handles do not serialise on a lock.
+struct TuneSet {
+    int halo = 1;           // conv3_halo_kernel use: 0 never, 1 when it pays, 2 whenever the shape allows (tests), 3 force the 320 / 256-wide form, 4 never the wide form
+    int conv_lw = 1;        // 1: stride-1 3x3 convs with N % 160 == 0 or N % 128 == 0 through conv3_lw_kernel (loader waves), 2: the same without its immediate-offset (FAST) path, 3: N % 160 == 0 only, 0: the 8-wave halo kernels
+    int gemm_w8 = 1;        // 1: the 256 x 320 linear / 1x1 layers through gemm_w8_kernel (hand-scheduled k loop), 0: gemm_big_kernel
+    int gemm_lw = 1;        // 1: the 256 x 160 linear / 1x1 layers (too few 256 x 320 tiles) through gemm_lw_kernel (loader waves), 0: gemm_big_kernel<false, 160>
+    int gemm2_w8 = 1;       // 1: gemm2 main launches run the hand-scheduled k loop (W8 instantiation of gemm2_kernel; bit-identical), 0: the compiler-scheduled one
+    int attn_lw = 1;        // 1: head dim 40 self-attention (Nq % 256 == 0, Nk % 64 == 0) runs attn40_lw_kernel, 2: the same with 16x16x32 MFMAs for both k steps (bit-identical to attn_kernel), 0: attn_kernel
+    int debug = 0;          // experiment / trace bits
+    int gemm_gm = -1;       // gemm_big_kernel tile order: -1 auto (bands of 4 tile rows when there are >= 12 tile columns), 0 / 1 row-major, n bands of n
+    int gn_fuse = 1;        // 1: GroupNorm statistics of a conv / 1x1 output come from its epilogue (IgemmArgs::gn_stats), 0: always a statistics pass
+    int cfg_share = 1;      // 0 runs the CFG dual batch without the shared prefix (A/B, tests)
+    int xattn_fused = 1;    // 1: the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
+    int attn_prio = -1;     // -1 auto (head dim 128 only: -3.4 % on the FLUX shape, +1.5 % at head dim 40), 0 off, 1 on
+    int gemm2_prio = 0;
+    int biggemm = 1;        // 256-row GEMM tiles: 0 never, 1 when the tile count fills the chip, 2 / 3 force the 320 / 160-wide form
+    int attn_qt40 = 4;      // query tiles per wave at head dim 40 (2 | 4)
+    // CS_RESIDUAL_F16X2 only: which GEMMs that consume the residual stream DIRECTLY read hi + lo (two passes of the k loop, IgemmArgs::a0_lo) instead of the hi
+    // plane: bit 0 the resnet shortcut 1x1 (default: its operand rounding is the largest single stream-level error left), bit 1 proj_out
+    int x2_split_a = 1;
+    // 1: the transformer blocks' LayerNorms are folded into the linear layers that consume them (gamma in the packed weights, (mean, rstd) applied in the
+    // GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
+    int ln_fold = 1;
+    int xcd_grid = 1;       // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
+    int epi_fast = 1;       // 1: the FAST forms of the fp32-patch epilogue (all loads of a pass in front of its phase 1) in conv3_lw / gemm_w8 / gemm_lw, 0: the generic code
+    // 1: conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
+    // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
+    int conv_in_mfma = 1;
+    int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
+};
+extern TuneSet g_tune;                              // process-wide (ops_api.cpp)
+extern thread_local const TuneSet* t_tune;          // this thread's override for the duration of a host call, or null
+inline const TuneSet& tune() { return t_tune ? *t_tune : g_tune; }
+struct TuneScope {                                  // RAII: install / remove a per-thread set
+    const TuneSet* prev;
+    explicit TuneScope(const TuneSet* t) : prev(t_tune) { t_tune = t; }
+    ~TuneScope() { t_tune = prev; }
+    TuneScope(const TuneScope&) = delete; TuneScope& operator=(const TuneScope&) = delete;
+};
+// key -> field of `set` (validated against the knob table: known key, value in range); CS_OK or CS_E_ARG with the error text set.  Writes only `set`.
+int tune_apply(TuneSet& set, const char* key, int value);
+
 struct IgemmArgs {
     // activations, NHWC fp16; up to two sources concatenated along channels (skip-concat fusion)
     const f16* a0; const f16* a1; int c0, c1;

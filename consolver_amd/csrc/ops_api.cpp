@@ -3,79 +3,62 @@
 #include "../../include/consolver_hip_ops.h"
 #include <cstring>
 
-extern int g_tune_halo;
-extern int g_tune_conv_lw;
-extern int g_tune_gemm_w8;
-extern int g_tune_gemm_lw;
-extern int g_tune_gemm2_w8;
-extern int g_tune_attn_lw;
-extern int g_tune_debug;
-extern int g_tune_gemm_gm;
-extern int g_tune_gn_fuse;
 int debug_trace_read(void* dst, size_t bytes);
 int debug_attn_trace_read(void* dst, size_t bytes);
-extern int g_tune_cfg_share;
-extern int g_tune_xattn_fused;
-extern int g_tune_attn_prio;
-extern int g_tune_gemm2_prio;
-extern int g_tune_biggemm;
-extern int g_tune_attn_qt40;
-extern int g_tune_x2_split_a;
-extern int g_tune_ln_fold;
-extern int g_tune_xcd_grid;
-extern int g_tune_epi_fast;
-extern int g_tune_conv_in_mfma;
-extern int g_tune_xattn_tile;
 
 #include <mutex>
-// cs_set_tuning / cs_reset_tuning and a forward that runs with per-handle overrides (cs_unet_set_tuning) exclude each other: the knobs are read on the HOST while a
-// forward's launches are issued, so holding this for the duration of the host call is what "this handle runs with its own knob set" takes
-std::recursive_mutex g_tune_mutex;
+TuneSet g_tune;
+thread_local const TuneSet* t_tune = nullptr;
+static std::mutex g_tune_write_mutex;      // writers of the process-wide set (cs_set_tuning / cs_reset_tuning); per-handle overrides never write it (ops.h, TuneSet)
 
-extern "C" {
-
-// every kernel-selection knob: name, variable, default, accepted range (or the two-value set {lo, hi} when `pair`)
-struct TuneKnob { const char* key; int* var; int def, lo, hi; bool pair; };
+// every kernel-selection knob: name, field, accepted range (or the two-value set {lo, hi} when `pair`); the defaults are TuneSet's member initialisers
+struct TuneKnob { const char* key; int TuneSet::* var; int lo, hi; bool pair; };
 static const TuneKnob* tune_knobs(int* n) {
     static const TuneKnob k[] = {
-        {"conv_halo", &g_tune_halo, 1, 0, 4, false},     {"gemm_lw", &g_tune_gemm_lw, 1, 0, 1, false},      {"gemm2_w8", &g_tune_gemm2_w8, 1, 0, 1, false},
-        {"attn_lw", &g_tune_attn_lw, 1, 0, 2, false},    {"gemm_w8", &g_tune_gemm_w8, 1, 0, 1, false},      {"conv_lw", &g_tune_conv_lw, 1, 0, 3, false},
-        {"gemm_big", &g_tune_biggemm, 1, 0, 3, false},   {"debug", &g_tune_debug, 0, 0, 0x7fffffff, false}, {"gemm_gm", &g_tune_gemm_gm, -1, -1, 64, false},
-        {"gn_fuse", &g_tune_gn_fuse, 1, 0, 1, false},    {"xattn_fused", &g_tune_xattn_fused, 1, 0, 1, false}, {"cfg_share", &g_tune_cfg_share, 1, 0, 1, false},
-        {"gemm2_prio", &g_tune_gemm2_prio, 0, -1, 1, false}, {"attn_prio", &g_tune_attn_prio, -1, -1, 1, false}, {"attn_qt40", &g_tune_attn_qt40, 4, 2, 4, true},
-        {"x2_split_a", &g_tune_x2_split_a, 1, 0, 3, false}, {"ln_fold", &g_tune_ln_fold, 1, 0, 1, false}, {"xcd_grid", &g_tune_xcd_grid, 1, 0, 1, false}, {"epi_fast", &g_tune_epi_fast, 1, 0, 1, false},
-        {"conv_in_mfma", &g_tune_conv_in_mfma, 1, 0, 1, false}, {"xattn_tile", &g_tune_xattn_tile, 64, 64, 128, true},
+        {"conv_halo", &TuneSet::halo, 0, 4, false},     {"gemm_lw", &TuneSet::gemm_lw, 0, 1, false},      {"gemm2_w8", &TuneSet::gemm2_w8, 0, 1, false},
+        {"attn_lw", &TuneSet::attn_lw, 0, 2, false},    {"gemm_w8", &TuneSet::gemm_w8, 0, 1, false},      {"conv_lw", &TuneSet::conv_lw, 0, 3, false},
+        {"gemm_big", &TuneSet::biggemm, 0, 3, false},   {"debug", &TuneSet::debug, 0, 0x7fffffff, false}, {"gemm_gm", &TuneSet::gemm_gm, -1, 64, false},
+        {"gn_fuse", &TuneSet::gn_fuse, 0, 1, false},    {"xattn_fused", &TuneSet::xattn_fused, 0, 1, false}, {"cfg_share", &TuneSet::cfg_share, 0, 1, false},
+        {"gemm2_prio", &TuneSet::gemm2_prio, -1, 1, false}, {"attn_prio", &TuneSet::attn_prio, -1, 1, false}, {"attn_qt40", &TuneSet::attn_qt40, 2, 4, true},
+        {"x2_split_a", &TuneSet::x2_split_a, 0, 3, false}, {"ln_fold", &TuneSet::ln_fold, 0, 1, false}, {"xcd_grid", &TuneSet::xcd_grid, 0, 1, false}, {"epi_fast", &TuneSet::epi_fast, 0, 1, false},
+        {"conv_in_mfma", &TuneSet::conv_in_mfma, 0, 1, false}, {"xattn_tile", &TuneSet::xattn_tile, 64, 128, true},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;
 }
 
-int cs_set_tuning(const char* key, int value) {
+int tune_apply(TuneSet& set, const char* key, int value) {
     if (!key) CS_FAIL(CS_E_ARG, "key is NULL");
-    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
     int n; const TuneKnob* k = tune_knobs(&n);
     for (int i = 0; i < n; ++i)
         if (!strcmp(key, k[i].key)) {
             const bool ok = k[i].pair ? (value == k[i].lo || value == k[i].hi) : (value >= k[i].lo && value <= k[i].hi);
             if (!ok) CS_FAIL(CS_E_ARG, "tuning key '%s': value %d outside %s%d%s%d%s", key, value, k[i].pair ? "{" : "[", k[i].lo, k[i].pair ? ", " : " .. ", k[i].hi, k[i].pair ? "}" : "]");
-            *k[i].var = value;
+            set.*(k[i].var) = value;
             return CS_OK;
         }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
 }
 
+extern "C" {
+
+int cs_set_tuning(const char* key, int value) {
+    std::lock_guard<std::mutex> lock(g_tune_write_mutex);
+    return tune_apply(g_tune, key, value);
+}
+
+// the value the CALLING thread's launches would see (the process-wide one outside a per-handle forward)
 int cs_get_tuning(const char* key, int* value) {
     if (!key || !value) CS_FAIL(CS_E_ARG, "key / value is NULL");
     int n; const TuneKnob* k = tune_knobs(&n);
     for (int i = 0; i < n; ++i)
-        if (!strcmp(key, k[i].key)) { *value = *k[i].var; return CS_OK; }
+        if (!strcmp(key, k[i].key)) { *value = tune().*(k[i].var); return CS_OK; }
     CS_FAIL(CS_E_ARG, "unknown tuning key '%s'", key);
 }
 
 int cs_reset_tuning(void) {
-    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
-    int n; const TuneKnob* k = tune_knobs(&n);
-    for (int i = 0; i < n; ++i) *k[i].var = k[i].def;
+    std::lock_guard<std::mutex> lock(g_tune_write_mutex);
+    g_tune = TuneSet();
     return CS_OK;
 }
 

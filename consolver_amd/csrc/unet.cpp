@@ -23,23 +23,6 @@
 #include <memory>
 #include <cstring>
 #include <cmath>
-#include <mutex>
-
-extern std::recursive_mutex g_tune_mutex;      // ops_api.cpp
-extern "C" int cs_set_tuning(const char* key, int value);
-extern "C" int cs_get_tuning(const char* key, int* value);
-int g_tune_xattn_fused = 1;    // 1 (default): the cross-attention sub-block at C = 320 runs as ONE kernel (xattn.hip); 0: four kernels
-extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
-int g_tune_cfg_share = 1;      // cs_set_tuning("cfg_share", 0) runs the CFG dual batch without the shared prefix (A/B, tests)
-// CS_RESIDUAL_F16X2 only: which GEMMs that consume the residual stream DIRECTLY read hi + lo (two passes of the k loop, IgemmArgs::a0_lo) instead of the hi
-// plane: bit 0 the resnet shortcut 1x1 (default: its operand rounding is the largest single stream-level error left), bit 1 proj_out
-int g_tune_x2_split_a = 1;
-// 1 (default): the transformer blocks' LayerNorms are folded into the linear layers that consume them (gamma in the packed weights, (mean, rstd) applied in the
-// GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
-int g_tune_ln_fold = 1;
-// 1 (default): conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
-// GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
-int g_tune_conv_in_mfma = 1;
 
 // LN(h) W^T + b = rstd (h W'^T - mean s) + b':  W' = fp16(W diag(gamma)), s = row sums of W' (of the ROUNDED values: it cancels exactly what the MFMAs summed),
 // b' = W beta + b.  Host memory; w [N][K] fp16 rows, bias may be null.  Shared by the executor's weight packing and cs_op_ln_fold_pack.
@@ -344,9 +327,9 @@ struct Run {
     // flight; the workspace query passes its variants here instead of writing the globals)
     int v_gn_fuse = 1, v_xattn_fused = 1, v_cfg_share = 1;
     bool split = false;            // CS_RESIDUAL_F16X2: residual-stream tensors carry a lo plane
-    int v_split_a = 1;             // snapshot of g_tune_x2_split_a
-    int v_ln_fold = 1;             // snapshot of g_tune_ln_fold
-    int v_conv_in_mfma = 1;        // snapshot of g_tune_conv_in_mfma
+    int v_split_a = 1;             // snapshot of tune().x2_split_a
+    int v_ln_fold = 1;             // snapshot of tune().ln_fold
+    int v_conv_in_mfma = 1;        // snapshot of tune().conv_in_mfma
     bool count_executed = false;   // dry run behind cs_unet_flops_executed: count what is ISSUED (padding included), not the reference graph's FLOPs
     // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
     float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
@@ -620,7 +603,7 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
 }
 
 struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma; };
-static Variant current_variant() { return Variant{g_tune_gn_fuse, g_tune_xattn_fused, g_tune_cfg_share, g_tune_ln_fold, g_tune_conv_in_mfma}; }
+static Variant current_variant() { return Variant{tune().gn_fuse, tune().xattn_fused, tune().cfg_share, tune().ln_fold, tune().conv_in_mfma}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
                 char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant(), bool count_executed = false) {
@@ -632,7 +615,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->arena.reset(ws + kvb + gnb, dry ? 0 : ws_bytes - kvb - gnb, dry);
     u->dry_flops = 0;
     Run R{u, s, dry, B};
-    R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = g_tune_x2_split_a; R.count_executed = count_executed;
+    R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = tune().x2_split_a; R.count_executed = count_executed;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -874,6 +857,9 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
 double cs_unet_flops_executed(const CsUNet* cu, int n_lat, int dup) {
     CsUNet* u = const_cast<CsUNet*>(cu);
     if (!u || !u->finalized || n_lat <= 0 || (dup != 1 && dup != 2)) return 0;
+    TuneSet mine = g_tune;                                   // what THIS handle's forwards execute: its own knob overrides included
+    for (auto& kv : u->tune) tune_apply(mine, kv.first.c_str(), kv.second);
+    TuneScope scope(u->tune.empty() ? nullptr : &mine);
     run_forward(u, true, nullptr, n_lat, dup, nullptr, 1, nullptr, nullptr, nullptr, 0, 0, nullptr, current_variant(), true);
     return u->dry_flops;
 }
@@ -894,18 +880,15 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     if (!latents || !timesteps || !ctx || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
     if (n_timesteps != 1 && n_timesteps != n_lat * dup) CS_FAIL(CS_E_SHAPE, "n_timesteps must be 1 or the batch size");
     u->ev_used = 0;
-    // per-handle knob overrides: applied for the duration of this host call (every knob is read on the host while the launches are issued), restored afterwards.  Every
-    // forward takes the lock -- also a handle without overrides must not read the process-wide knobs while another thread's forward has its own set installed
-    std::unique_lock<std::recursive_mutex> tune_lock(g_tune_mutex);
-    std::vector<std::pair<std::string, int>> saved;
-    for (auto& kv : u->tune) {
-        int cur = 0;
-        if (cs_get_tuning(kv.first.c_str(), &cur) == CS_OK) { saved.push_back({kv.first, cur}); cs_set_tuning(kv.first.c_str(), kv.second); }
-    }
-    int rc = run_forward(u, false, (const f16*)latents, n_lat, dup, timesteps, n_timesteps, (const f16*)ctx, (f16*)out, (char*)workspace,
+    // per-handle knob overrides: this call's own knob set (process-wide values + the handle's entries), visible to THIS thread's launchers only (ops.h, TuneSet)
+    TuneSet mine = g_tune;
+    for (auto& kv : u->tune) tune_apply(mine, kv.first.c_str(), kv.second);
+    int rc;
+    {
+        TuneScope scope(u->tune.empty() ? nullptr : &mine);
+        rc = run_forward(u, false, (const f16*)latents, n_lat, dup, timesteps, n_timesteps, (const f16*)ctx, (f16*)out, (char*)workspace,
                          workspace_bytes, kv_cache_valid, (hipStream_t)stream);
-    for (auto it = saved.rbegin(); it != saved.rend(); ++it) cs_set_tuning(it->first.c_str(), it->second);
-    tune_lock.unlock();
+    }
     if (rc == CS_OK && u->profiling) {
         CS_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
         for (int k = 0; k < P_COUNT; ++k) { u->prof_ms[k] = u->prof_flops[k] = u->prof_bytes[k] = 0; u->prof_launches[k] = 0; }
@@ -920,12 +903,8 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
 
 int cs_unet_set_tuning(CsUNet* u, const char* key, int value) {
     if (!u || !key) CS_FAIL(CS_E_ARG, "unet / key is NULL");
-    std::lock_guard<std::recursive_mutex> lock(g_tune_mutex);
-    int cur = 0;
-    int rc = cs_get_tuning(key, &cur);                   // known knob?
-    if (rc != CS_OK) return rc;
-    rc = cs_set_tuning(key, value);                      // value in range?  (validated by the same table, then put back)
-    cs_set_tuning(key, cur);
+    TuneSet scratch;                                     // known knob, value in range?  (validated on a scratch set: the process-wide one is not touched)
+    const int rc = tune_apply(scratch, key, value);
     if (rc != CS_OK) return rc;
     u->tune[key] = value;
     return CS_OK;

@@ -20,7 +20,6 @@
 #include <algorithm>
 #include <cmath>
 
-extern int g_tune_gn_fuse;     // igemm.hip: GroupNorm statistics from the producer's epilogue (1, default) or a statistics pass (0)
 
 namespace {
 
@@ -183,7 +182,7 @@ struct Run {
     // workspace size does not depend on the knob's value at query time
     bool v_gn_fuse = true;
     void init_stats(size_t floats) {
-        v_gn_fuse = g_tune_gn_fuse != 0;
+        v_gn_fuse = tune().gn_fuse != 0;
         st_floats = floats;
         for (auto& b : st_buf) b = (float*)alloc(floats * 2);           // (alloc counts halfs)
     }

@@ -24,8 +24,6 @@
 // (the unfused kernel's max-free steady state is for thousands of keys).
 #include "ops.h"
 
-extern int g_tune_debug;
-int g_tune_xattn_tile = 64;     // 64 (default, round 5): xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 
 namespace {
 
@@ -718,14 +716,14 @@ int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
     if (!a.h || !a.out || !a.ln_g || !a.ln_b || !a.wq || !a.wo || !a.bo || !a.kv) CS_FAIL(CS_E_ARG, "xattn_block: null pointer");
     if (a.C != 320 || a.heads != 8) CS_FAIL(CS_E_UNSUPPORTED, "xattn_block: built for C = 320, 8 heads (got C = %d, heads = %d)", a.C, a.heads);
     if (a.Nk < 1 || a.Nk > 80) CS_FAIL(CS_E_SHAPE, "xattn_block: 1 <= Nk <= 80 (got %d)", a.Nk);
-    if (a.HW % TM && !(g_tune_xattn_tile == 64 && a.HW % TM2 == 0)) CS_FAIL(CS_E_SHAPE, "xattn_block: rows per sample must be a multiple of %d", TM);
+    if (a.HW % TM && !(tune().xattn_tile == 64 && a.HW % TM2 == 0)) CS_FAIL(CS_E_SHAPE, "xattn_block: rows per sample must be a multiple of %d", TM);
     if (a.M <= 0) return a.M < 0 ? CS_E_SHAPE : CS_OK;
     if (a.M % a.HW) CS_FAIL(CS_E_SHAPE, "xattn_block: M must be a whole number of samples");
     XattnParams p;
     if ((a.h_lo == nullptr) != (a.out_lo == nullptr)) CS_FAIL(CS_E_ARG, "xattn_block: h_lo and out_lo go together");
     p.h = a.h; p.out = a.out; p.h_lo = a.h_lo; p.out_lo = a.out_lo; p.row_stats = a.row_stats; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.ln_eps = a.ln_eps; p.wq = a.wq; p.wo = a.wo; p.bo = a.bo; p.kv = a.kv;
-    p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = g_tune_debug;
-    if (g_tune_xattn_tile == 64 && a.HW % TM2 == 0) {     // round 5 default: 64-row tiles, two workgroups per CU
+    p.M = a.M; p.HW = a.HW; p.Nk = a.Nk; p.c = a.scale * 1.4426950408889634f; p.debug = tune().debug;
+    if (tune().xattn_tile == 64 && a.HW % TM2 == 0) {     // round 5 default: 64-row tiles, two workgroups per CU
         constexpr size_t lds2 = XT2_BYTES + 2 * WST2;      // 81920
         static bool configured2 = false;
         if (!configured2) {

@@ -44,6 +44,7 @@ class SDSamplingEngine:
         if self._bufs is None or self._bufs["key"] != key:
             order = self.scheduler.config.order_dim
             C, H, W = shape
+            self._graph = self._graph_key = None      # a captured graph holds the OLD buffers' addresses (latents_dtype is a public attribute and part of the key)
             self._bufs = dict(
                 key=key,
                 lat=[torch.empty(B, C, H, W, dtype=self.latents_dtype, device=device) for _ in range(2)],

@@ -14,6 +14,16 @@ diverge through their sampled solver coefficients, which first enter the update 
 entry at step 0: eps_eff = eps, scheduler_ppo.py:263-265; scale actions, if any, act from step 0).  The
 denoiser inputs of step 0 (and of step 1 when ``scaler_dim == 0``) are therefore the same for every row:
 they are evaluated for one row and broadcast.  Every returned tensor keeps its full-batch shape.
+
+``solver_state_dtype`` (extension, default ``torch.float32``): the dtype the LATENTS are carried in between the steps of the loop.
+The reference hands ``scheduler.step`` whatever the previous step returned: an fp16 tensor after step 1 and -- because the fp32
+policy's ``[B,1,1,1]`` actions promote the update (scheduler_ppo.py:263-272) -- fp32 tensors afterwards.  Here the
+state is fp32 from step 0 on: the denoiser reads its fp16 rounding (``HipUNet2DConditionModel`` casts its input), the update kernel
+reads and writes the unrounded state (CsStepArgs::x_is_f32).  An fp16 state rounds the latents once per step (2.8e-4 relative L2
+each, adding in quadrature): 12 steps ended at 1.10e-3 of the fp32 oracle, above north_star's 1e-3 gate.  The
+RETURNED latents are cast back to ``noise.dtype`` -- the tensor the trainer decodes (train_ppo.py:359-365) -- and every record
+(``conds`` / ``probs`` / ``actions`` / ``masks``) has the dtype it has in the reference.  ``solver_state_dtype=None`` carries the
+state in ``noise.dtype`` (the arithmetic class of an all-fp16 loop).
 """
 import torch
 
@@ -21,7 +31,8 @@ from . import _lib as L
 
 
 def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg=3, num_inference_steps=50,
-                      gradient_checkpointing=False, prompt_embeds=None, negative_prompt_embeds=None, identical_inputs=False):
+                      gradient_checkpointing=False, prompt_embeds=None, negative_prompt_embeds=None, identical_inputs=False,
+                      solver_state_dtype=torch.float32):
     if gradient_checkpointing:
         raise NotImplementedError("inference-only rollout: the denoiser is frozen (train_ppo.py:148-154)")
     if isinstance(text, str):
@@ -43,11 +54,14 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
             negative_prompt_embeds = text_encoder(ids)[0]
         prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
 
-    latents = noise.clone()
+    native = getattr(unet, "is_consolver_hip", False)
+    if solver_state_dtype not in (None, torch.float32):
+        raise ValueError("solver_state_dtype must be torch.float32 (default) or None (= noise.dtype)")
+    # the solver state: fp32 between the steps (see the module docstring); a foreign denoiser gets the tensor in its own dtype below
+    latents = noise.to(solver_state_dtype) if (solver_state_dtype is not None and native and noise.dtype != solver_state_dtype) else noise.clone()
     scheduler.set_timesteps(num_inference_steps, device=device)
     record_prev = scheduler.record_conds
     scheduler.record_conds = True
-    native = getattr(unet, "is_consolver_hip", False)
     rec = dict(x=[], epsilon=[], probs=[], actions=[], masks=[])
     try:
         shared_steps = 0
@@ -94,5 +108,5 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
     # silently: one device->host read per rollout (the records below are about to be consumed on the host side anyway)
     scheduler.verify_timesteps()
     cat = {k: torch.cat(v, dim=1) for k, v in rec.items()}
-    return latents, {"x": cat["x"], "epsilon": cat["epsilon"]}, cat["probs"], cat["actions"], cat["masks"], prompt_embeds_txt
+    return latents.to(noise.dtype), {"x": cat["x"], "epsilon": cat["epsilon"]}, cat["probs"], cat["actions"], cat["masks"], prompt_embeds_txt
 

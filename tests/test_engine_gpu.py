@@ -155,6 +155,93 @@ def test_engine_solver_state_dtype():
         SDSamplingEngine(unet, sch, latents_dtype=torch.bfloat16)
 
 
+def test_engine_with_ddim_baseline_scheduler_in_both_state_dtypes():
+    """The engine's default fp32 solver state under a BASELINE scheduler (baselines.py): DDIMBaselineScheduler.step takes the fp32 sample as fp32 and writes fp32
+    (CsStepArgs::x_is_f32), like PPOScheduler.step -- it used to store fp16 values into the fp32 ping-pong buffer.  Reference point: the learned solver with every
+    coefficient at its default (action indices (0, 10, 5) -> actions (0, 0, 0) -> eps_eff = eps_t) IS eta = 0 DDIM on the same tables, so the two engines must agree."""
+    from consolver_amd.baselines import DDIMBaselineScheduler
+    cfg = dict(layers_per_block=1, sample_size=16)
+    unet, sd, sch, w = make(cfg)
+    ddim = DDIMBaselineScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing")
+    B, n, g = 2, 5, 3.0
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half().to(DEV), synthetic_prompt_embeds(B, seed=1002).half().to(DEV)
+    noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(45)).half().to(DEV)
+    default_idx = torch.tensor([[0, 10, 5]] * B, device=DEV)
+    for dt in (torch.float32, torch.float16):
+        for guidance in (g, 1.0):                                  # fused CFG path and the plain one (the engine copies eps into the history slot there)
+            sch.factor_net.forced_action_idx = default_idx
+            want = SDSamplingEngine(unet, sch, guidance_scale=guidance, latents_dtype=dt).generate(pe, ne, latents=noise, num_inference_steps=n).clone()
+            got = SDSamplingEngine(unet, ddim, guidance_scale=guidance, latents_dtype=dt).generate(pe, ne, latents=noise, num_inference_steps=n).clone()
+            assert got.dtype == dt and torch.isfinite(got).all()
+            err = float((got.float() - want.float()).norm() / want.float().norm())
+            assert err < 1e-6, (dt, guidance, err)
+    sch.factor_net.forced_action_idx = None
+    # a mismatched out= buffer is refused instead of being filled with the other dtype's bytes
+    ddim.set_timesteps(n, device=DEV)
+    e = torch.randn(B, 4, 16, 16, device=DEV).half()
+    with pytest.raises(ValueError):
+        ddim.step(e, ddim.timesteps[0], noise.float(), return_dict=False, out=torch.empty_like(noise))
+    from consolver_amd.baselines import FlowMatchEulerBaselineScheduler
+    fm = FlowMatchEulerBaselineScheduler(shift=3.0, use_dynamic_shifting=False)
+    fm.set_timesteps(4, device=DEV)
+    v = torch.randn(B, 64, 64, device=DEV).bfloat16()
+    x32 = torch.randn(B, 64, 64, device=DEV)
+    out = fm.step(v, fm.timesteps[0], x32, return_dict=False)[0]
+    step = torch.tensor(np.float32(fm._sigmas[1] - fm._sigmas[0])) * v.cpu()                         # (a bf16 product, as in tests/test_parity_e2e_gpu.py::test_fmppo_fp32_sample_is_consumed_as_fp32)
+    assert out.dtype == torch.bfloat16 and torch.equal(out.cpu(), (x32.cpu() + step).bfloat16())      # the fp32 sample is consumed unrounded (scheduler_fm.py:405-410)
+    with pytest.raises(ValueError):
+        fm.step(v, fm.timesteps[1], x32, return_dict=False, out=torch.empty_like(x32))
+
+
+def test_reference_class_dtype_behaviour_of_the_plain_protocol():
+    """The reference's OWN dtype behaviour with an fp16 denoiser and an fp32 policy net (scheduler_ppo.py:263-272,306-332): the CFG combine is an fp16
+    torch expression (denoise_ppo.py:96-100), step 1 (one history entry, 0-dim scalars only) returns an fp16 prev_sample, every later step returns fp32 because the
+    [B,1,1,1] coefficients promote.  The product reproduces that class through the plain protocol -- fp16 sample in -> fp16 out by default, `prev_sample_dtype =
+    torch.float32` from the second step on -- and is held here against the comparator with exactly those roundings (fp16 eps halves, fp16 combine ops, fp16 latents
+    after step 1 only).  The native engine deviates deliberately: fp32 state from step 0 (no rounding of the first prev_sample); INTEGRATION.md states the difference."""
+    cfg = dict(layers_per_block=1, sample_size=16)
+    unet, sd, sch, w = make(cfg)
+    B, n, g = 2, 5, 3.0
+    idx = np.random.default_rng(12).integers(0, 11, size=(n, B, 3))
+    pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
+    noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(46)).half()
+    # ---- comparator: fp32 oracle graph + the reference's rounding points
+    orc_u = get_oracle(cfg, seed=7)
+    orc_s = so.PPOSchedulerOracle(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", timestep_spacing="trailing", order_dim=4, scaler_dim=0,
+                                  num_actions=11, weights=w)
+    orc_s.set_timesteps(n)
+    r = so.round_f16
+    x = noise.float().numpy()
+    ctx = torch.cat([ne, pe]).float()
+    for i, t in enumerate(orc_s.timesteps):
+        e = r(orc_u(torch.from_numpy(np.concatenate([x, x])), int(t), ctx).numpy())                 # the denoiser's output is an fp16 tensor
+        u, c = e[:B], e[B:]
+        comb = r(u + r(np.float32(g) * r(c - u)))                                                        # u + g * (c - u), one fp16 rounding per torch op
+        x = orc_s.step(comb, int(t), x, idx[i], cond_dtype="f16")["prev_sample"]
+        if i == 0:
+            x = r(x)                                                                                      # step 1 returns fp16; later steps fp32
+    want = x
+    # ---- the product through the plain protocol, dtypes as the reference's loop sees them
+    sch.set_timesteps(n, device=DEV)
+    sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
+    lat = noise.to(DEV)
+    ctx_d = torch.cat([ne, pe]).to(DEV)
+    try:
+        for i, t in enumerate(sch.timesteps):
+            eps = unet(torch.cat([lat] * 2), t, encoder_hidden_states=ctx_d, return_dict=False)[0]
+            u, c = eps.chunk(2)
+            noise_pred = u + g * (c - u)
+            assert noise_pred.dtype == torch.float16
+            sch.prev_sample_dtype = None if i == 0 else torch.float32
+            lat = sch.step(noise_pred, t, lat, return_dict=False)[0]
+            assert lat.dtype == (torch.float16 if i == 0 else torch.float32)
+    finally:
+        sch.prev_sample_dtype = None
+    err = float(np.linalg.norm(lat.cpu().numpy() - want) / np.linalg.norm(want))
+    print(f"plain protocol, reference dtype class (fp16 first step, fp32 afterwards), 5-step reduced UNet: rel l2 vs the same-class comparator {err:.3e}")
+    assert np.isfinite(lat.cpu().numpy()).all() and err < 1.5e-3, err
+
+
 def test_engine_pixel_output_matches_decode_of_its_latents():
     """output_type="pt" == decode_latents (utils.py:6-34) of the latents the same engine returns, and matches the
     fp32 VAE oracle applied to those latents (the decoder's own tolerance, tests/test_vae_gpu.py)."""
@@ -258,16 +345,58 @@ def test_pipeline_call_surface():
 
 
 @pytest.mark.gpu
+def test_rccl_process_group_at_world_size_one():
+    """The RCCL ("nccl" backend on ROCm) side of launch.py on real hardware: a world-size-1 process group on this box's GPU through the SAME helpers the 8-GPU
+    jobs use (gen_ppo.py:349-357,433-465: shard, barrier, max over ranks, gather): barrier, all_reduce(MAX) and all_gather on CUDA tensors, the trainer's
+    gradient mean (train_ppo.py:257,430), and the per-rank record of bench.py.  The gloo twins run in tests/test_launch_cpu.py at world size 2."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, socket, sys
+        sys.path.insert(0, %r)
+        import torch
+        import torch.distributed as dist
+        from consolver_amd import launch
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        dist.barrier()
+        assert launch.reduce_max_seconds(dist, 1.5, dev) == 1.5
+        assert launch.gather_report(dist, 16, 2.25, dev) == [(16, 2.25)]
+        rows = launch.gather_rank_records(dist, [0.0, 0.0, float(torch.cuda.current_device()), 48.0, 0.7, 0.0, 16.0, 123.5, 9.0], dev)
+        assert rows == [[0.0, 0.0, 0.0, 48.0, 0.7, 0.0, 16.0, 123.5, 9.0]], rows
+        g = torch.arange(75000, dtype=torch.float32, device=dev)               # the policy's packed gradient vector (~300 KB)
+        out = launch.average_gradients(dist, g.clone())
+        assert torch.equal(out, g)
+        lo, hi = launch.shard_bounds(16, dist.get_world_size(), dist.get_rank())
+        assert (lo, hi) == (0, 16)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    """ % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_bench_prints_one_contract_line():
     """bench.py (N = 1, short) prints ONE JSON line with the driver's keys plus roofline / ceilings / cpu_baseline objects"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--decode", "0", "--extras", "0",
-                        "--no-cpu-baseline", "--profile-kernels", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+                        "--no-cpu-baseline", "--profile-kernels", "0", "--force-dist"], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
+    # --force-dist: the N > 1 branch of bench.py on this one-GPU box -- init_process_group("nccl", device_id=...), the barriers, all_reduce(MAX) of the elapsed time on a
+    # GPU tensor and launch.gather_rank_records over RCCL -- the code the driver's 8-GPU run executes, at world size 1
+    assert len(rec["per_rank"]) == 1 and rec["per_rank"][0]["rank"] == 0 and rec["per_rank"][0]["images"] == 16 and rec["per_rank_distinct_devices"] == 1
+    assert rec["per_rank"][0]["prompt_shard"] == [0, 16] and abs(rec["per_rank"][0]["elapsed_s"] * 1e3 - rec["ms_per_step"]) < 1e-3 * rec["ms_per_step"] + 1.0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in rec, k
     assert rec["n_gpus"] == 1 and rec["steps"] == 1 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["dtype"] == "f16"
