@@ -56,7 +56,25 @@ struct IgemmParams {
     int gm;             // gemm_big_kernel tile order: bands of gm tile rows walked column-major (1 = plain row-major)
     int pn;             // tile_of: 0 = contiguous run of tiles per XCD, > 0 = the XCDs as an (8 / pn) x pn grid over (row tiles, column tiles)
     int epi_fast;       // knob epi_fast: the FAST forms of the fp32-patch epilogue (igemm_epilogue_f32)
+    int lo8;            // IgemmArgs::lo8: res_lo / out_lo are 8-bit (e5m2) planes, one byte per element
 };
+
+// The lo plane of a split residual-stream tensor as ONE BYTE per element (round 6): e5m2 -- sign, the fp16 exponent, two mantissa bits, i.e. the fp16 lo value
+// rounded to its top byte; v_cvt_pk_bf8_f32 / v_cvt_pk_f32_bf8 convert two elements per instruction.  hi (11 significant bits) + lo8 (3) = 14 bits against 22 with
+// an fp16 lo: tools/sim_precision_r06.py -- the transformer blocks' hidden state stored that way moves the per-forward eps error from 8.8224e-4 to 8.8209e-4 (nothing),
+// EVERY stream tensor stored that way to 8.97e-4 (+1.6 %).  Half the lo plane's bytes through the epilogues' store-bound phase.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lo8_decode_add(float (&f)[8], const u32x2_t w) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[0], false), b = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[0], true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[1], false), d = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[1], true);
+    f[0] += a[0]; f[1] += a[1]; f[2] += b[0]; f[3] += b[1]; f[4] += c[0]; f[5] += c[1]; f[6] += d[0]; f[7] += d[1];
+}
+__device__ __forceinline__ u32x2_t lo8_encode(const float (&r)[8]) {
+    int w0 = __builtin_amdgcn_cvt_pk_bf8_f32(r[0], r[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(r[2], r[3], w0, true);
+    int w1 = __builtin_amdgcn_cvt_pk_bf8_f32(r[4], r[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(r[6], r[7], w1, true);
+    return u32x2_t{(unsigned)w0, (unsigned)w1};
+}
 
 // timing experiments only (debug bit 16384): per-workgroup wall-clock stamps of gemm_big_kernel, read back with cs_debug_trace_read
 #define CS_TRACE_SLOTS 8192
@@ -212,7 +230,10 @@ struct LinearRows {
 // wave's 20 iterations waited a full memory round trip (two with a lo plane) plus the acknowledgement of its predecessor's stores: 28 us of the 71 us a
 // 256 x 320 x 1280 tile took, 43 us in f16x2 mode (from the ISA: tools/README.md, round 4).  Here a pass issues ALL its loads in one go, branch-free, so that
 // the compiler's own counted waits work: one round trip per pass.
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM, int FAST = 0, bool LTAB = false>
+// FAST 4 (round 6) = residual + its lo plane, NO lo plane out: the feed-forward's second linear in the split mode (its output has one consumer, proj_out's fp16 operand) --
+// it ran the generic code since the hidden state after it stopped carrying a lo plane.  LO8: the lo planes are 8-bit (IgemmParams::lo8); FAST 2 / 4 take it as a template
+// parameter, the generic code as a runtime branch.
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT, bool F32, int LNM, int FAST = 0, bool LTAB = false, bool LO8 = false>
 __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
     static_assert(NT % GROUP == 0, "GROUP must divide NT");
     static_assert(MT % RSPLIT == 0, "RSPLIT must divide MT");
@@ -269,7 +290,9 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     constexpr int NI = RT * 16 * CH / 64;                     // phase-2 iterations of a pass
     constexpr int NG = (NT / GROUP) * RSPLIT * NI;            // ... of the wave
     constexpr int PD = NI < 3 ? NI : 3;
-    f16x8 pa[FAST ? PD : 1], pb[FAST == 2 ? PD : 1];
+    constexpr bool RLO = FAST == 2 || FAST == 4;              // the residual comes with a lo plane
+    f16x8 pa[FAST ? PD : 1], pb[(RLO && !LO8) ? PD : 1];
+    u32x2_t pb8[(RLO && LO8) ? PD : 1];
     auto prefetch = [&](int g) {
         if constexpr (FAST != 0) {
             static_assert(!FAST || (F32 && !GEGLU), "FAST is a form of the fp32-patch path");
@@ -282,7 +305,8 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
             else {
                 const size_t off = (size_t)m * Nout + n0p + ch * 8;
                 pa[g % PD] = *reinterpret_cast<const f16x8*>(p.res + off);
-                if constexpr (FAST == 2) pb[g % PD] = *reinterpret_cast<const f16x8*>(p.res_lo + off);
+                if constexpr (RLO && !LO8) pb[g % PD] = *reinterpret_cast<const f16x8*>(p.res_lo + off);
+                if constexpr (RLO && LO8) pb8[g % PD] = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.res_lo) + off);
             }
         }
     };
@@ -427,10 +451,11 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                     if constexpr (FAST != 0) {                // (the same additions in the same order as below, from the registers loaded in front of phase 1)
 #pragma unroll
                         for (int r = 0; r < 8; ++r) f[r] += (float)pa[g % PD][r];
-                        if constexpr (FAST == 2) {
+                        if constexpr (RLO && !LO8) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r) f[r] += (float)pb[g % PD][r];
                         }
+                        if constexpr (RLO && LO8) lo8_decode_add(f, pb8[g % PD]);
                         if (k + PD < NI) prefetch(g + PD);        // (into the registers just consumed)
                     } else {
                     if (p.temb) {
@@ -443,9 +468,12 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
                         if (p.res_lo) {                       // split-fp16 residual stream: value = hi + lo
-                            const f16x8 t2 = *reinterpret_cast<const f16x8*>(p.res_lo + off);
+                            if (p.lo8) lo8_decode_add(f, *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.res_lo) + off));
+                            else {
+                                const f16x8 t2 = *reinterpret_cast<const f16x8*>(p.res_lo + off);
 #pragma unroll
-                            for (int r = 0; r < 8; ++r) f[r] += (float)t2[r];
+                                for (int r = 0; r < 8; ++r) f[r] += (float)t2[r];
+                            }
                         }
                     }
                     }
@@ -456,11 +484,18 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                         for (int r = 0; r < 8; ++r) { rs1 += f[r]; rs2 = __builtin_fmaf(f[r], f[r], rs2); }
                     }
                     *reinterpret_cast<f16x8*>(p.out + off) = o;
-                    if (FAST == 2 || (FAST == 0 && p.out_lo)) {   // what the fp16 store dropped, as a second fp16 plane (exact subtraction, then one rounding)
-                        f16x8 l;
+                    if (FAST == 2 || (FAST == 0 && p.out_lo)) {   // what the fp16 store dropped, as a second plane (exact subtraction, then one rounding: to fp16, or to e5m2 -- lo8)
+                        float d8[8];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) l[r] = (f16)(f[r] - (float)o[r]);
-                        *reinterpret_cast<f16x8*>(p.out_lo + off) = l;
+                        for (int r = 0; r < 8; ++r) d8[r] = f[r] - (float)o[r];
+                        if ((FAST == 2 && LO8) || (FAST == 0 && p.lo8)) {
+                            *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(p.out_lo) + off) = lo8_encode(d8);
+                        } else {
+                            f16x8 l;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) l[r] = (f16)d8[r];
+                            *reinterpret_cast<f16x8*>(p.out_lo + off) = l;
+                        }
                     }
                 }
                 // (the fp16 values of chunk ch go where the fp32 values of chunks ch / 2 were: every lane has read its fp32 slot by now -- LDS operations of a
@@ -517,7 +552,16 @@ __device__ __forceinline__ void igemm_epilogue_f32(const IgemmParams& p, f32x4 (
     if constexpr (EFAST) {
         if (p.epi_fast != 0 && rows.all_valid()) {
             if (p.res && !p.temb) {
-                if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+                if (p.res_lo && p.out_lo) {
+                    if (p.lo8) igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST, true>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+                    else igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+                    return;
+                }
+                if (p.res_lo && !p.out_lo && (p.epi_fast & 2)) {
+                    if (p.lo8) igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 4, EFAST, true>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+                    else igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 4, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+                    return;
+                }
                 if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
             } else if (p.temb && !p.res && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 3, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
         }
@@ -1538,16 +1582,23 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
 
 // row statistics of a [M][C] tensor (value = x + x_lo when x_lo != null): stats[M][1][2] = (sum, sum of squares) per row.  The fallback of IgemmArgs::row_stats
 // for the kernels whose epilogue cannot leave them (split-K forms), and cs_op_row_stats.  One wave per row.
-__global__ __launch_bounds__(256) void row_stats_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, int M, int C, float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void row_stats_kernel(const f16* __restrict__ x, const f16* __restrict__ x_lo, int M, int C, float* __restrict__ stats, int lo8) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 8; c < C; c += 512) {
         const f16x8 t = *reinterpret_cast<const f16x8*>(x + (size_t)row * C + c);
-        f16x8 t2 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (x_lo) t2 = *reinterpret_cast<const f16x8*>(x_lo + (size_t)row * C + c);
+        float fv[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float f = (float)t[k] + (float)t2[k]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
+        for (int k = 0; k < 8; ++k) fv[k] = (float)t[k];
+        if (x_lo && lo8) lo8_decode_add(fv, *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(x_lo) + (size_t)row * C + c));
+        else if (x_lo) {
+            const f16x8 t2 = *reinterpret_cast<const f16x8*>(x_lo + (size_t)row * C + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fv[k] += (float)t2[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float f = fv[k]; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { stats[2 * (size_t)row] = s1; stats[2 * (size_t)row + 1] = s2; }
@@ -1578,18 +1629,27 @@ __device__ __forceinline__ f16x8 splitk_reduce_item(const IgemmParams& p, const 
     if (p.res) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.N + n);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
-    if (p.res && p.res_lo) { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res_lo + (size_t)m * p.N + n);
+    if (p.res && p.res_lo) {
+        if (p.lo8) lo8_decode_add(v, *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.res_lo) + (size_t)m * p.N + n));
+        else { const f16x8 t = *reinterpret_cast<const f16x8*>(p.res_lo + (size_t)m * p.N + n);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+            for (int k = 0; k < 8; ++k) v[k] += (float)t[k]; }
+    }
     f16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
     *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.N + n) = o;
     if (p.out_lo) {
-        f16x8 l;
+        float d8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) l[k] = (f16)(v[k] - (float)o[k]);
-        *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * p.N + n) = l;
+        for (int k = 0; k < 8; ++k) d8[k] = v[k] - (float)o[k];
+        if (p.lo8) *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(p.out_lo) + (size_t)m * p.N + n) = lo8_encode(d8);
+        else {
+            f16x8 l;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) l[k] = (f16)d8[k];
+            *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * p.N + n) = l;
+        }
     }
     return o;
 }
@@ -2042,7 +2102,7 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     if (a.pad_after_only && !(a.taps == 9 && a.stride == 2)) CS_FAIL(CS_E_ARG, "igemm: pad_after_only is the stride-2 3x3 form");
     p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.cpt = cin / BK; p.KT = a.taps * p.cpt; p.Ktot = a.taps * cin;
     p.w = a.w; p.bias = a.bias; p.temb = a.temb; p.temb_stride = a.temb_stride; p.res = a.res; p.out = a.out;
-    p.res_lo = a.res ? a.res_lo : nullptr; p.out_lo = a.out_lo;
+    p.res_lo = a.res ? a.res_lo : nullptr; p.out_lo = a.out_lo; p.lo8 = (a.lo8 && (p.res_lo || p.out_lo)) ? 1 : 0;
     const bool conv3_early = a.taps == 9;
     p.row_stats = a.row_stats;
     p.ln_stats = a.ln_stats; p.ln_groups = a.ln_groups; p.ln_inv_c = 1.0f / (float)cin; p.ln_eps = a.ln_eps; p.ln_s = a.ln_s; p.ln_b = a.ln_b;
@@ -2252,7 +2312,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
         if (li.row_groups > 0) *a.row_stats_groups = li.row_groups;
         else {
             const int M = a.B * a.Ho * a.Wo;
-            hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, (const f16*)a.out, (const f16*)a.out_lo, M, a.N, a.row_stats);
+            hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, (const f16*)a.out, (const f16*)a.out_lo, M, a.N, a.row_stats, a.lo8);
             CS_CHECK_LAUNCH();
             *a.row_stats_groups = 1;
         }
@@ -2263,10 +2323,10 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     return launch_gn_stats64(a.out, a.B, a.Ho * a.Wo, a.N, a.gn_stats, s);
 }
 
-int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s) {
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s, int lo8) {
     if (!x || !stats || C % 8) CS_FAIL(CS_E_ARG, "row_stats: x, stats required; C %% 8 == 0");
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x_lo, M, C, stats);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, x_lo, M, C, stats, lo8);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -191,6 +191,125 @@ __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restri
 }
 
 
+// conv_out on the matrix cores (round 6).  The patch kernel above spends 5760 v_dot2 per thread on a tile whose input it loads with nothing else in flight: the
+// UNet's conv_out (320 -> 4 at 64 x 64, batch 32: an 84 MB read) ran 110 us, 6x its memory floor; the VAE's (128 -> 3 at 512 x 512) 553 us per 16 images.  Here the
+// same 16 x 16 patch / 18 x 18 x 64-channel swizzled LDS halo is the A operand of v_mfma_f32_16x16x32_f16 -- an M tile is one patch row (16 pixels), the tap shift
+// is a row offset into the halo -- against a B fragment holding the COUT (<= 16) filters of one (tap, 32-channel step) in its first COUT columns, zeros elsewhere:
+// 360 MFMAs per wave per patch (the padded columns cost matrix-pipe time nobody is waiting for), and the next 64-channel chunk's global loads are issued in front
+// of the chunk being multiplied (register prefetch, single LDS buffer: 41.5 KB, three workgroups per CU).  What remains is the streaming read.
+template <int COUT>
+__global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __restrict__ x, int Cin, int H, int W, const f16* __restrict__ w,
+                                                            const f16* __restrict__ bias, f16* __restrict__ out, int postprocess) {
+    static_assert(COUT >= 1 && COUT <= 16, "one 16-column MFMA tile");
+    __shared__ __attribute__((aligned(16))) f16 halo[324 * 64];
+    __shared__ __attribute__((aligned(16))) f16 wts[COUT * 9 * 64];      // this chunk's filters [COUT][tap][64]: staged with the halo, so that the fragment reads wait on lgkmcnt --
+                                                                          // a global load issued after the prefetch could only be waited for together with it (vmcnt is in order)
+    constexpr int NV = 324 * 8, NIT = (NV + 255) / 256;          // 16-byte vectors of one halo chunk; staging slots per thread
+    constexpr int NWV = COUT * 72, NWS = (NWV + 255) / 256;      // ... of one chunk's filters
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PX = W >> 4;
+    const int b = blockIdx.y, py = blockIdx.x / PX, px = blockIdx.x - py * PX;
+    const int y0 = py * 16, x0 = px * 16;
+    // this thread's staging slots: source offset within the sample (-1 for the zero padding / the unused tail slot); the swizzled LDS position is recomputed at the write
+    const f16* xb = x + (size_t)b * H * W * Cin;
+    int src[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        const int row = i >> 3, ch = i & 7;
+        const int hy = row / 18, hx = row - hy * 18;
+        const int y = y0 + hy - 1, xx = x0 + hx - 1;
+        const bool ok = i < NV && y >= 0 && y < H && xx >= 0 && xx < W;
+        src[k] = ok ? (y * W + xx) * Cin + ch * 8 : -1;
+    }
+    f16x8 pre[NIT], prew[NWS];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (src[k] >= 0) v = *reinterpret_cast<const f16x8*>(xb + src[k] + c0);
+            pre[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NWS; ++k) {
+            const int j = tid + 256 * k;                        // vector j = (filter, tap, 8-channel group) in wts order
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (j < NWV) v = *reinterpret_cast<const f16x8*>(w + (size_t)(j >> 3) * Cin + c0 + (j & 7) * 8);
+            prew[k] = v;
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = lane & 15, kq = lane >> 4;                  // A: pixel `col` of the M tile, k slice kq; B: filter `col`, k slice kq
+    const f16* wl = wts + (col < COUT ? col : 0) * 9 * 64 + kq * 8;
+    prefetch(0);
+    for (int c0 = 0; c0 < Cin; c0 += 64) {
+        __syncthreads();                                        // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i >> 3, ch = i & 7;
+            if (i < NV) *reinterpret_cast<f16x8*>(halo + row * 64 + ((ch ^ (row & 7)) << 3)) = pre[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NWS; ++k)
+            if (tid + 256 * k < NWV) *reinterpret_cast<f16x8*>(wts + (tid + 256 * k) * 8) = prew[k];
+        __syncthreads();
+        if (c0 + 64 < Cin) prefetch(c0 + 64);                   // in flight under this chunk's MFMAs
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+            f16x8 bw[3][2];                                     // the (dy, dx, k step) filters of this tap row: zero columns beyond COUT
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (col < COUT) v = *reinterpret_cast<const f16x8*>(wl + (dy * 3 + dx) * 64 + ks * 32);
+                    bw[dx][ks] = v;
+                }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int kc = ks * 4 + kq;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int hr = (wave * 4 + mt + dy) * 18 + col + dx;
+                        const f16x8 a = *reinterpret_cast<const f16x8*>(halo + hr * 64 + ((kc ^ (hr & 7)) << 3));
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bw[dx][ks], acc[mt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // D: column = filter (lane & 15), rows = pixels 4 (lane >> 4) + r of the patch row: one 8-byte NCHW store per lane and patch row
+    if (col < COUT) {
+        const float bv = (float)bias[col];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int y = y0 + wave * 4 + mt;
+            typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mt][r] + bv;
+                if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
+                o[r] = (f16)v;
+            }
+            *reinterpret_cast<f16x4*>(out + (((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4) = o;
+        }
+    }
+}
+
+// 16 x 16-patch conv_out: the MFMA form (default) or the v_dot2 one (cs_set_tuning("conv_out_mfma", 0))
+template <int COUT>
+static void launch_conv_out_patch(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s) {
+    const dim3 grid((H / 16) * (W / 16), B);
+    if (tune().conv_out_mfma) hipLaunchKernelGGL(conv_out_mfma_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
+    else hipLaunchKernelGGL(conv_out_patch_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
+}
+
+
 __global__ void embed_tokens_kernel(const int64_t* __restrict__ ids, const f16* __restrict__ tok, const f16* __restrict__ pos, f16* __restrict__ out,
                                     long rows, int L, int C, int vocab) {
     const int CV = C >> 3;
@@ -371,7 +490,7 @@ int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, c
     if (Cin % 8) CS_FAIL(CS_E_SHAPE, "conv_out3: Cin must be a multiple of 8");
     if (B <= 0) return CS_OK;
     if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
-        hipLaunchKernelGGL(conv_out_patch_kernel<3>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
+        launch_conv_out_patch<3>(x, B, Cin, H, W, w, bias, out, postprocess, s);
         CS_CHECK_LAUNCH();
         return CS_OK;
     }
@@ -419,7 +538,7 @@ int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, co
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
     if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
-        hipLaunchKernelGGL(conv_out_patch_kernel<4>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+        launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s);
         CS_CHECK_LAUNCH();
         return CS_OK;
     }
@@ -462,10 +581,9 @@ int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16*
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out_small: null pointer");
     if (H % 16 || W % 16 || Cin % 64) CS_FAIL(CS_E_SHAPE, "conv_out_small: H, W must be multiples of 16 and Cin of 64");
     if (B <= 0) return CS_OK;
-    const dim3 grid((H / 16) * (W / 16), B);
-    if (Cout == 4) hipLaunchKernelGGL(conv_out_patch_kernel<4>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
-    else if (Cout == 8) hipLaunchKernelGGL(conv_out_patch_kernel<8>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
-    else if (Cout == 16) hipLaunchKernelGGL(conv_out_patch_kernel<16>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, 0);
+    if (Cout == 4) launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s);
+    else if (Cout == 8) launch_conv_out_patch<8>(x, B, Cin, H, W, w, bias, out, 0, s);
+    else if (Cout == 16) launch_conv_out_patch<16>(x, B, Cin, H, W, w, bias, out, 0, s);
     else CS_FAIL(CS_E_UNSUPPORTED, "conv_out_small: %d output channels not built", Cout);
     CS_CHECK_LAUNCH();
     return CS_OK;

@@ -31,10 +31,13 @@ struct TuneSet {
     // GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
     int ln_fold = 1;
     int xcd_grid = 1;       // 1: weight-heavy layers map the 8 XCDs as a 2-D grid over (row tiles, column tiles) (tile_of, IgemmParams::pn), 0: contiguous runs always
-    int epi_fast = 1;       // 1: the FAST forms of the fp32-patch epilogue (all loads of a pass in front of its phase 1) in conv3_lw / gemm_w8 / gemm_lw, 0: the generic code
+    int epi_fast = 3;       // bit 0: the FAST forms of the fp32-patch epilogue (all loads of a pass in front of its phase 1) in conv3_lw / gemm_w8 / gemm_lw, 0: the generic code;
+                            // bit 1 (round 6): also the form "residual + its lo plane, no lo plane out" (the feed-forward's second linear in the split mode)
+    int lo8 = 1;            // 1: the transformer blocks' hidden state carries an 8-bit (e5m2) lo plane in the split mode (IgemmArgs::lo8), 0: an fp16 one
     // 1: conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
     // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
     int conv_in_mfma = 1;
+    int conv_out_mfma = 1;  // 1: the 16 x 16-patch conv_out kernels (UNet 320 -> 4, VAE 128 -> 3) on v_mfma_f32_16x16x32_f16 (conv_out_mfma_kernel), 0: the v_dot2 patch kernel
     int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 };
 extern TuneSet g_tune;                              // process-wide (ops_api.cpp)
@@ -73,6 +76,10 @@ struct IgemmArgs {
     // `res` (added in fp32 with it), `out_lo` receives what the fp16 store of `out` dropped: out_lo = f16(v - float(f16(v))).  hi + lo carries 22
     // significant bits, so the adds along the residual stream are fp32-class while every GEMM operand stays a plain fp16 tensor (the hi plane).
     const f16* res_lo; f16* out_lo;
+    // lo8 != 0: res_lo / out_lo are 8-BIT planes, one e5m2 byte per element (the fp16 lo value rounded to its top byte: hi + lo8 = 14 significant bits), same [M][N]
+    // element layout.  For stream tensors whose lo plane is only ever ADDED (the transformer blocks' hidden state: the to_out / feed-forward epilogues and the fused
+    // cross-attention block); a lo plane that is a GEMM operand (a0_lo) stays fp16.
+    int lo8;
     // optional (1x1 / linear only): the A operand itself is a split-fp16 stream tensor -- a0_lo / a1_lo are the lo planes of a0 / a1 (same shapes).  The kernel
     // runs the k loop twice over the same weights, hi planes then lo planes, into one accumulator: W (hi + lo) exactly, 2x the layer's MFMA work.  Used where
     // a GEMM consumes the residual stream directly and its operand rounding is a stream-level error (the resnet shortcut 1x1 over [x | skip]).
@@ -90,7 +97,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);
 void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out);
 // (sum, sum of squares) per row of x [M][C] (+ x_lo): stats[M][1][2]; the statistics pass behind IgemmArgs::row_stats and after the fused cross-attention block
-int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s);
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s, int lo8 = 0);
 
 struct AttnArgs {
     const f16* q; int q_stride;   // [B, Nq, H*dh] rows of q_stride halfs
@@ -133,6 +140,7 @@ int launch_layer_norm(const f16* x, const f16* gamma, const f16* beta, f16* out,
 struct XattnArgs {
     const f16* h; f16* out;                 // [M][C]; out may alias h
     const f16* h_lo; f16* out_lo;           // split-fp16 residual stream: lo planes of h / out (both or neither); out_lo may alias h_lo
+    int lo8;                                // the lo planes are one e5m2 byte per element (IgemmArgs::lo8)
     float* row_stats;                       // optional: (sum, sum of squares) of every OUTPUT row, [M][1][2] (IgemmArgs::row_stats layout with one group): norm3 folded into the GEGLU GEMM
     const f16* ln_g; const f16* ln_b; float ln_eps;
     const f16* wq; const f16* wo; const f16* bo;

@@ -20,8 +20,9 @@ static const TuneKnob* tune_knobs(int* n) {
         {"gemm_big", &TuneSet::biggemm, 0, 3, false},   {"debug", &TuneSet::debug, 0, 0x7fffffff, false}, {"gemm_gm", &TuneSet::gemm_gm, -1, 64, false},
         {"gn_fuse", &TuneSet::gn_fuse, 0, 1, false},    {"xattn_fused", &TuneSet::xattn_fused, 0, 1, false}, {"cfg_share", &TuneSet::cfg_share, 0, 1, false},
         {"gemm2_prio", &TuneSet::gemm2_prio, -1, 1, false}, {"attn_prio", &TuneSet::attn_prio, -1, 1, false}, {"attn_qt40", &TuneSet::attn_qt40, 2, 4, true},
-        {"x2_split_a", &TuneSet::x2_split_a, 0, 3, false}, {"ln_fold", &TuneSet::ln_fold, 0, 1, false}, {"xcd_grid", &TuneSet::xcd_grid, 0, 1, false}, {"epi_fast", &TuneSet::epi_fast, 0, 1, false},
+        {"x2_split_a", &TuneSet::x2_split_a, 0, 3, false}, {"ln_fold", &TuneSet::ln_fold, 0, 1, false}, {"xcd_grid", &TuneSet::xcd_grid, 0, 1, false}, {"epi_fast", &TuneSet::epi_fast, 0, 3, false}, {"lo8", &TuneSet::lo8, 0, 1, false},
         {"conv_in_mfma", &TuneSet::conv_in_mfma, 0, 1, false}, {"xattn_tile", &TuneSet::xattn_tile, 64, 128, true},
+        {"conv_out_mfma", &TuneSet::conv_out_mfma, 0, 1, false},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;
@@ -136,6 +137,42 @@ int cs_op_linear_x2(const void* x, const void* x_lo, int M, int K, const void* w
     a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
     return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_linear_lo8(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo8, void* out, void* out_lo8,
+                     float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream) {
+    IgemmArgs a{};
+    a.row_stats = row_stats; a.row_stats_groups = row_groups;
+    if (res_lo8 && !res) CS_FAIL(CS_E_ARG, "linear_lo8: res_lo8 without res");
+    a.a0 = (const f16*)x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N;
+    a.w = (const f16*)w; a.bias = (const f16*)bias; a.res = (const f16*)res; a.out = (f16*)out;
+    a.res_lo = (const f16*)res_lo8; a.out_lo = (f16*)out_lo8; a.lo8 = 1;
+    a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_xattn_block_lo8(const void* h, const void* h_lo8, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
+                          int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo8, float* row_stats,
+                          void* stream) {
+    XattnArgs a{};
+    a.row_stats = row_stats;
+    a.h = (const f16*)h; a.out = (f16*)out; a.h_lo = (const f16*)h_lo8; a.out_lo = (f16*)out_lo8; a.lo8 = 1;
+    a.ln_g = (const f16*)ln_gamma; a.ln_b = (const f16*)ln_beta; a.ln_eps = ln_eps;
+    a.wq = (const f16*)wq; a.wo = (const f16*)wo; a.bo = (const f16*)bo; a.kv = (const f16*)kv;
+    a.M = M; a.HW = HW; a.Nk = Nk; a.C = C; a.heads = heads; a.scale = scale;
+    return launch_xattn_block(a, (hipStream_t)stream);
+}
+
+int cs_op_row_stats_lo8(const void* x, const void* x_lo8, int M, int C, float* stats, void* stream) {
+    return launch_row_stats((const f16*)x, (const f16*)x_lo8, M, C, stats, (hipStream_t)stream, 1);
+}
+
+int cs_op_conv_out(const void* x, int B, int Cin, int H, int W, const void* w, const void* bias, int Cout, void* out, int postprocess, void* stream) {
+    if (postprocess && Cout != 3) CS_FAIL(CS_E_ARG, "conv_out: postprocess is the image head's (Cout 3)");
+    if (Cout == 3) return launch_conv_out3((const f16*)x, B, Cin, H, W, (const f16*)w, (const f16*)bias, (f16*)out, postprocess, (hipStream_t)stream);
+    if (Cout == 4) return launch_conv_out((const f16*)x, B, Cin, H, W, (const f16*)w, (const f16*)bias, Cout, (f16*)out, (hipStream_t)stream);
+    return launch_conv_out_small((const f16*)x, B, Cin, H, W, (const f16*)w, (const f16*)bias, Cout, (f16*)out, (hipStream_t)stream);
 }
 
 int cs_op_group_norm_x2(const void* x0, const void* x0_lo, int c0, const void* x1, const void* x1_lo, int c1, int B, int HW, int groups,

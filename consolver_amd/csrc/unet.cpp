@@ -95,11 +95,13 @@ struct Arena {
 // (22 significant bits): the epilogues that add onto the stream take hi + lo in fp32 and store both planes (IgemmArgs::res_lo / out_lo), the norms
 // read hi + lo, and a GEMM that consumes the stream directly (shortcut 1x1, down / upsample conv, proj_out) reads the hi plane -- which is exactly
 // the fp16 tensor of the one-plane mode, so no kernel's operand path changes.
+// lo8 (round 6): the lo plane holds ONE BYTE per element (e5m2: the fp16 lo value rounded to its top byte, IgemmArgs::lo8) -- the transformer blocks' hidden state,
+// whose lo plane is only ever added (to_out / cross-attention / feed-forward epilogues), never a GEMM operand.
 struct St {
-    f16* hi = nullptr; f16* lo = nullptr;
+    f16* hi = nullptr; f16* lo = nullptr; bool lo8 = false;
     St() {}
-    St(f16* h, f16* l = nullptr) : hi(h), lo(l) {}
-    St at(size_t off) const { return St(hi + off, lo ? lo + off : nullptr); }
+    St(f16* h, f16* l = nullptr, bool l8 = false) : hi(h), lo(l), lo8(l8 && l) {}
+    St at(size_t off) const { return St(hi + off, lo ? (lo8 ? reinterpret_cast<f16*>(reinterpret_cast<unsigned char*>(lo) + off) : lo + off) : nullptr, lo8); }
 };
 
 enum ProfClass { P_CONV3 = 0, P_GEMM, P_ATTN_SELF, P_ATTN_CROSS, P_GROUPNORM, P_LAYERNORM, P_MISC, P_COUNT };
@@ -330,6 +332,11 @@ struct Run {
     int v_split_a = 1;             // snapshot of tune().x2_split_a
     int v_ln_fold = 1;             // snapshot of tune().ln_fold
     int v_conv_in_mfma = 1;        // snapshot of tune().conv_in_mfma
+    int v_lo8 = 1;                 // snapshot of tune().lo8
+    // the transformer hidden state's lo plane as bytes: only where every consumer of that plane adds it (folded LayerNorms: ln_kernel reads an fp16 lo plane;
+    // proj_out not reading hi + lo as its operand)
+    bool h_lo8() const { return split && v_lo8 != 0 && v_ln_fold != 0 && !(v_split_a & 2); }
+    St salloc_h(size_t elems) { St t; t.hi = alloc(elems); t.lo8 = h_lo8(); t.lo = split ? alloc(t.lo8 ? (elems + 1) / 2 : elems) : nullptr; return t; }
     bool count_executed = false;   // dry run behind cs_unet_flops_executed: count what is ISSUED (padding included), not the reference graph's FLOPs
     // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
     float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
@@ -360,6 +367,11 @@ struct Run {
     // partial-sum buffer for a [Bt][HW][C] tensor about to be produced (Bt samples); registered under `out` by the caller
     float* alloc_stats(int Bt, int HW, int C) { return (float*)alloc((size_t)Bt * (HW / 64) * C * 2); }      // C/2 pairs x 2 floats = C floats = 2C halfs
 
+    // one launch's lo planes are of one kind (IgemmArgs::lo8 covers res_lo and out_lo): mixing them is an executor bug, caught here
+    int lo8_of(const St& res, const St& out) {
+        if (res.lo && out.lo && res.lo8 != out.lo8 && rc == CS_OK) { cs_set_error("unet: a launch with an fp16 and an 8-bit lo plane"); rc = CS_E_STATE; }
+        return ((res.lo && res.lo8) || (out.lo && out.lo8)) ? 1 : 0;
+    }
     template <typename F> void launch(int cls, double flops, double bytes, F&& f) {
         if (dry) { u->dry_flops += flops; return; }
         if (rc != CS_OK) return;
@@ -389,7 +401,7 @@ struct Run {
         }
         a.a0 = a0; a.a1 = a1; a.c0 = c0; a.c1 = c1; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Ho; a.Wo = Wo; a.taps = c.taps; a.stride = stride;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res.hi; a.out = out.hi; a.geglu = 0;
-        a.res_lo = res.lo; a.out_lo = out.lo;
+        a.res_lo = res.lo; a.out_lo = out.lo; a.lo8 = lo8_of(res, out);
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         const double M = (double)B * Ho * Wo;
         const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
@@ -401,9 +413,10 @@ struct Run {
         IgemmArgs a{};
         a.row_stats = row_stats; a.row_stats_groups = row_groups;
         a.a0 = x; a.c0 = K; a.B = 1; a.Hi = M; a.Wi = 1; a.Ho = M; a.Wo = 1; a.taps = 1; a.stride = 1; a.N = N; a.w = w; a.bias = b; a.res = res.hi; a.out = out.hi; a.geglu = geglu;
-        a.res_lo = res.lo; a.out_lo = out.lo;
+        a.res_lo = res.lo; a.out_lo = out.lo; a.lo8 = lo8_of(res, out);
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
-        const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
+        const double lob = a.lo8 ? 0.5 : 1.0;                // (a lo8 plane is half the bytes of an fp16 one)
+        const double bytes = 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) * ((res.hi ? 2 : 1) + (res.lo ? lob : 0) + (out.lo ? lob : 0)));
         launch(P_GEMM, igemm_flops(a), bytes, [&] { return launch_igemm(a, s); });
     }
     // out = LayerNorm(h) W^T + b with the LayerNorm folded in: x is the RAW hidden state (hi plane), stats / G what its producer left
@@ -443,10 +456,10 @@ struct Run {
     void xattn_fused(const Xformer& X, St h_in, St h_out, const f16* kvl, int HW, float* row_stats = nullptr) {
         XattnArgs a{};
         a.row_stats = row_stats;
-        a.h = h_in.hi; a.out = h_out.hi; a.h_lo = h_in.lo; a.out_lo = h_out.lo; a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
+        a.h = h_in.hi; a.out = h_out.hi; a.h_lo = h_in.lo; a.out_lo = h_out.lo; a.lo8 = lo8_of(h_in, h_out); a.ln_g = X.ln2.g; a.ln_b = X.ln2.b; a.ln_eps = X.ln2.eps; a.wq = X.wq2; a.wo = X.wo2; a.bo = X.bo2; a.kv = kvl;
         a.M = B * HW; a.HW = HW; a.Nk = u->cfg.ctx_len; a.C = X.c; a.heads = u->cfg.num_heads; a.scale = 1.0f / sqrtf((float)(X.c / u->cfg.num_heads));
         const double M = (double)B * HW, fl = 4.0 * M * X.c * X.c + 4.0 * M * u->cfg.ctx_len * X.c;
-        launch(P_ATTN_CROSS, fl, 2.0 * ((h_in.lo ? 5.0 : 3.0) * M * X.c), [&] { return launch_xattn_block(a, s); });
+        launch(P_ATTN_CROSS, fl, 2.0 * ((h_in.lo ? (a.lo8 ? 4.0 : 5.0) : 3.0) * M * X.c), [&] { return launch_xattn_block(a, s); });
     }
 
     // x: [B,HW,Cx] (+ optional skip [B,HW,Cs]) -> new tensor [B,HW,Cout]
@@ -477,7 +490,7 @@ struct Run {
         const int C = X.c, HW = H * W, L = u->cfg.ctx_len; const int M = B * HW;
         f16* g = alloc((size_t)M * C);
         group_norm(X.gn, x, C, St(), 0, HW, false, g);
-        St h = salloc((size_t)M * C);
+        St h = salloc_h((size_t)M * C);
         // folded LayerNorms: every layer that writes the hidden state leaves its row statistics in rs (G column groups), the next LayerNorm's consumer reads them
         const bool fold = v_ln_fold != 0;
         float* rs = fold ? alloc_rowstats(M, C) : nullptr; int G = 1;
@@ -541,7 +554,7 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     R.B = n_lat;
     f16* g1 = R.alloc((size_t)M1 * C);
     R.group_norm(X.gn, x_half, C, St(), 0, HW, false, g1);
-    St h1 = R.salloc((size_t)M1 * C);
+    St h1 = R.salloc_h((size_t)M1 * C);
     const bool fold = R.v_ln_fold != 0;
     float* rs = fold ? R.alloc_rowstats(M, C) : nullptr; int G = 1;          // (sized for the full batch: the halves' statistics land side by side later)
     R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h1, false, nullptr, nullptr, nullptr, rs, &G);
@@ -556,7 +569,7 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     if (R.xattn_fusable(X, HW)) {
         // the fused sub-block reads the shared residual stream and writes each half's own copy: no duplication copy, LN2 / to_q run per half
         R.release(g1);
-        h = R.salloc((size_t)M * C);
+        h = R.salloc_h((size_t)M * C);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half)
             R.xattn_fused(X, h1, h.at((size_t)half * M1 * C), kvl + (size_t)half * n_lat * L * 2 * C, HW, rs ? rs + (size_t)half * M1 * 2 : nullptr);
@@ -569,12 +582,12 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         else { R.layer_norm(X.ln2, h1, M1, g1); R.linear(g1, M1, C, X.wq2, nullptr, C, St(), St(q), 0); }
         R.release(g1);
         // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
-        h = R.salloc((size_t)M * C);
+        h = R.salloc_h((size_t)M * C);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half) {
             if (!R.dry && R.rc == CS_OK) {
                 hipMemcpyAsync(h.hi + (size_t)half * M1 * C, h1.hi, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
-                if (h.lo) hipMemcpyAsync(h.lo + (size_t)half * M1 * C, h1.lo, (size_t)M1 * C * sizeof(f16), hipMemcpyDeviceToDevice, R.s);
+                if (h.lo) hipMemcpyAsync(h.at((size_t)half * M1 * C).lo, h1.lo, (size_t)M1 * C * (h.lo8 ? 1 : sizeof(f16)), hipMemcpyDeviceToDevice, R.s);
             }
             const f16* kvh = kvl + (size_t)half * n_lat * L * 2 * C;
             R.attention(true, q, C, kvh, 2 * C, kvh + C, 2 * C, g + (size_t)half * M1 * C, C, HW, L, C);
@@ -602,8 +615,8 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     return out;
 }
 
-struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma; };
-static Variant current_variant() { return Variant{tune().gn_fuse, tune().xattn_fused, tune().cfg_share, tune().ln_fold, tune().conv_in_mfma}; }
+struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma, lo8; };
+static Variant current_variant() { return Variant{tune().gn_fuse, tune().xattn_fused, tune().cfg_share, tune().ln_fold, tune().conv_in_mfma, tune().lo8}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
                 char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant(), bool count_executed = false) {
@@ -616,6 +629,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = tune().x2_split_a; R.count_executed = count_executed;
+    R.v_lo8 = var.lo8;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -839,8 +853,8 @@ size_t cs_unet_workspace_bytes(const CsUNet* cu, int batch) {
     // the arena's peak depends on the execution variant (CFG shared prefix on / off, fused cross-attention block on / off): the workspace
     // covers all of them, whatever the knobs say now, so that toggling a knob later never outgrows a workspace sized earlier
     size_t peak = 0;
-    for (int variant = 0; variant < 16; ++variant) {         // (every knob that changes the allocation sequence: the first-fit arena's peak depends on the holes it leaves)
-        const Variant v{(variant >> 1) & 1, variant & 1, 1, (variant >> 2) & 1, variant >> 3};
+    for (int variant = 0; variant < 32; ++variant) {         // (every knob that changes the allocation sequence: the first-fit arena's peak depends on the holes it leaves)
+        const Variant v{(variant >> 1) & 1, variant & 1, 1, (variant >> 2) & 1, (variant >> 3) & 1, variant >> 4};
         run_forward(u, true, nullptr, batch, 1, nullptr, batch /* worst case: per-sample timesteps */, nullptr, nullptr, nullptr, 0, 0, nullptr, v);
         peak = std::max(peak, u->arena.peak);
         if (batch % 2 == 0) {

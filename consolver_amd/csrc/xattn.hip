@@ -134,7 +134,7 @@ __device__ __forceinline__ void gemm_320(const f16* __restrict__ w, char* smem, 
 
 // SPLIT: the residual stream is split-fp16 (value = h + h_lo).  The LayerNorm reads the hi plane (its output is an fp16 MFMA operand either way: a
 // branch-level rounding); the residual add of the epilogue takes hi + lo and writes both planes, which is where the stream's precision lives.
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XT = smem;
@@ -343,15 +343,20 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
         }
         __syncthreads();
         // 128 rows x 40 chunks = 5120 items, 10 per thread: all residual loads of the thread first, then the patch reads, then the stores
-        f16x8 res[10], resl[SPLIT ? 10 : 1];
+        f16x8 res[10], resl[SPLIT == 1 ? 10 : 1];
+        u32x2 resl8[SPLIT == 2 ? 10 : 1];                 // lo8: the lo planes are one e5m2 byte per element (IgemmArgs::lo8)
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int id = tid + 512 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
             res[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (m < p.M && !(p.debug & 16)) res[k] = *reinterpret_cast<const f16x8*>(p.h + (size_t)m * C + ch * 8);
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
                 resl[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (m < p.M) resl[k] = *reinterpret_cast<const f16x8*>(p.h_lo + (size_t)m * C + ch * 8);
+            }
+            if constexpr (SPLIT == 2) {
+                resl8[k] = u32x2{0, 0};
+                if (m < p.M) resl8[k] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.h_lo) + (size_t)m * C + ch * 8);
             }
         }
 #pragma unroll
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
             const f16x8 v = *reinterpret_cast<const f16x8*>(patch + row * PROW + ch * 16);
             f16x8 o;
             float s1 = 0.f, s2 = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
                 f16x8 l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -369,6 +374,21 @@ __global__ __launch_bounds__(512, 2) void xattn_block_kernel(XattnParams p) {
                     s1 += f; s2 = __builtin_fmaf(f, f, s2);
                 }
                 if (m < p.M) *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * C + ch * 8) = l;
+            } else if constexpr (SPLIT == 2) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 l01 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][0], false), l23 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][0], true);
+                const f2 l45 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][1], false), l67 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][1], true);
+                const float lv[8] = {l01[0], l01[1], l23[0], l23[1], l45[0], l45[1], l67[0], l67[1]};
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e] + (float)res[k][e] + lv[e];
+                    o[e] = (f16)f; d[e] = f - (float)o[e];
+                    s1 += f; s2 = __builtin_fmaf(f, f, s2);
+                }
+                int w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[0], d[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[2], d[3], w0, true);
+                int w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[4], d[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[6], d[7], w1, true);
+                if (m < p.M) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.out_lo) + (size_t)m * C + ch * 8) = u32x2{(unsigned)w0, (unsigned)w1};
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e] + (float)res[k][e]; o[e] = (f16)f; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
@@ -453,7 +473,7 @@ __device__ __forceinline__ void gemm_320_k32(const f16* __restrict__ w, char* sm
     }
 }
 
-template <bool SPLIT>
+template <int SPLIT>
 __global__ __launch_bounds__(256, 2) void xattn64_kernel(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const XT = smem;
@@ -663,15 +683,20 @@ __global__ __launch_bounds__(256, 2) void xattn64_kernel(XattnParams p) {
         }
         __syncthreads();
         // 64 rows x 40 chunks = 2560 items, 10 per thread: all residual loads of the thread first, then the patch reads, then the stores
-        f16x8 res[10], resl[SPLIT ? 10 : 1];
+        f16x8 res[10], resl[SPLIT == 1 ? 10 : 1];
+        u32x2 resl8[SPLIT == 2 ? 10 : 1];                 // lo8: the lo planes are one e5m2 byte per element (IgemmArgs::lo8)
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int id = tid + 256 * k, row = id / 40, ch = id - row * 40, m = m_blk + row;
             res[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (m < p.M) res[k] = *reinterpret_cast<const f16x8*>(p.h + (size_t)m * C + ch * 8);
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
                 resl[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 if (m < p.M) resl[k] = *reinterpret_cast<const f16x8*>(p.h_lo + (size_t)m * C + ch * 8);
+            }
+            if constexpr (SPLIT == 2) {
+                resl8[k] = u32x2{0, 0};
+                if (m < p.M) resl8[k] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.h_lo) + (size_t)m * C + ch * 8);
             }
         }
 #pragma unroll
@@ -680,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void xattn64_kernel(XattnParams p) {
             const f16x8 v = *reinterpret_cast<const f16x8*>(patch + row * PROW + ch * 16);
             f16x8 o;
             float s1 = 0.f, s2 = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 1) {
                 f16x8 l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -689,6 +714,21 @@ __global__ __launch_bounds__(256, 2) void xattn64_kernel(XattnParams p) {
                     s1 += f; s2 = __builtin_fmaf(f, f, s2);
                 }
                 if (m < p.M) *reinterpret_cast<f16x8*>(p.out_lo + (size_t)m * C + ch * 8) = l;
+            } else if constexpr (SPLIT == 2) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 l01 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][0], false), l23 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][0], true);
+                const f2 l45 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][1], false), l67 = __builtin_amdgcn_cvt_pk_f32_bf8((int)resl8[k][1], true);
+                const float lv[8] = {l01[0], l01[1], l23[0], l23[1], l45[0], l45[1], l67[0], l67[1]};
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e] + (float)res[k][e] + lv[e];
+                    o[e] = (f16)f; d[e] = f - (float)o[e];
+                    s1 += f; s2 = __builtin_fmaf(f, f, s2);
+                }
+                int w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[0], d[1], 0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(d[2], d[3], w0, true);
+                int w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[4], d[5], 0, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(d[6], d[7], w1, true);
+                if (m < p.M) *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.out_lo) + (size_t)m * C + ch * 8) = u32x2{(unsigned)w0, (unsigned)w1};
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e] + (float)res[k][e]; o[e] = (f16)f; s1 += f; s2 = __builtin_fmaf(f, f, s2); }
@@ -727,24 +767,28 @@ int launch_xattn_block(const XattnArgs& a, hipStream_t s) {
         constexpr size_t lds2 = XT2_BYTES + 2 * WST2;      // 81920
         static bool configured2 = false;
         if (!configured2) {
-            CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn64_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn64_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             configured2 = true;
         }
-        if (a.h_lo) hipLaunchKernelGGL(xattn64_kernel<true>, dim3(a.M / TM2), dim3(256), lds2, s, p);
-        else hipLaunchKernelGGL(xattn64_kernel<false>, dim3(a.M / TM2), dim3(256), lds2, s, p);
+        if (a.h_lo && a.lo8) hipLaunchKernelGGL(xattn64_kernel<2>, dim3(a.M / TM2), dim3(256), lds2, s, p);
+        else if (a.h_lo) hipLaunchKernelGGL(xattn64_kernel<1>, dim3(a.M / TM2), dim3(256), lds2, s, p);
+        else hipLaunchKernelGGL(xattn64_kernel<0>, dim3(a.M / TM2), dim3(256), lds2, s, p);
         CS_CHECK_LAUNCH();
         return CS_OK;
     }
     constexpr size_t lds = XT_BYTES + 2 * WST;      // 163840: XT + two weight stages (the V tile reuses the stages, the epilogue patch XT)
     static bool configured = false;
     if (!configured) {
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_block_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    if (a.h_lo) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(a.M / TM), dim3(512), lds, s, p);
-    else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(a.M / TM), dim3(512), lds, s, p);
+    if (a.h_lo && a.lo8) hipLaunchKernelGGL(xattn_block_kernel<2>, dim3(a.M / TM), dim3(512), lds, s, p);
+    else if (a.h_lo) hipLaunchKernelGGL(xattn_block_kernel<1>, dim3(a.M / TM), dim3(512), lds, s, p);
+    else hipLaunchKernelGGL(xattn_block_kernel<0>, dim3(a.M / TM), dim3(512), lds, s, p);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -122,6 +122,62 @@ def linear_x2(x, w, bias=None, res=None, res_lo=None, splitk=True, want_lo=True,
     return out, out_lo
 
 
+def lo8_split(v):
+    """fp32 value -> (hi fp16, lo8 uint8): the representation of a stream tensor with an 8-bit lo plane (cs_op_linear_lo8): lo8 = e5m2(v - float(hi))"""
+    hi = v.to(torch.float16)
+    return hi, (v.float() - hi.float()).to(torch.float8_e5m2).view(torch.uint8)
+
+
+def lo8_value(hi, lo8):
+    """hi fp16 + lo8 (uint8 holding e5m2) -> fp32 value"""
+    return hi.float() + lo8.view(torch.float8_e5m2).float()
+
+
+def linear_lo8(x, w, bias=None, res=None, res_lo8=None, splitk=True, want_lo=True, row_stats=False):
+    """cs_op_linear_lo8: linear_x2 with 8-bit (e5m2) lo planes: returns (out_hi fp16, out_lo8 uint8 or None)"""
+    _f16(x, "x")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    out_lo = torch.empty(M, N, dtype=torch.uint8, device=x.device) if want_lo else None
+    ws = None
+    if splitk:
+        ws = _SPLITK_WS.get(x.device)
+        if ws is None:
+            ws = _SPLITK_WS[x.device] = torch.empty(64 << 20, dtype=torch.uint8, device=x.device)
+    rs, G = (torch.zeros(M, N // 64, 2, dtype=torch.float32, device=x.device), C.c_int(0)) if row_stats else (None, None)
+    L.check(L.lib().cs_op_linear_lo8(L.ptr(x), M, K, L.ptr(w), L.ptr(bias), N, L.ptr(res), L.ptr(res_lo8), L.ptr(out), L.ptr(out_lo),
+                                     L.ptr(rs), C.byref(G) if row_stats else None,
+                                     L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(x.device)))
+    if row_stats:
+        return out, out_lo, (rs, G.value)
+    return out, out_lo
+
+
+def xattn_block_lo8(h, h_lo8, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None, row_stats=False):
+    """cs_op_xattn_block_lo8: xattn_block_x2 on a stream with 8-bit lo planes"""
+    _f16(h, "h")
+    M, Cc = h.shape
+    hw = hw or M // kv.shape[0]
+    out = torch.empty_like(h)
+    out_lo = torch.empty(M, Cc, dtype=torch.uint8, device=h.device)
+    rs = torch.zeros(M, 1, 2, dtype=torch.float32, device=h.device) if row_stats else None
+    L.check(L.lib().cs_op_xattn_block_lo8(L.ptr(h), L.ptr(h_lo8), L.ptr(ln_gamma), L.ptr(ln_beta), float(eps), L.ptr(wq), L.ptr(kv), kv.shape[1],
+                                          L.ptr(wo), L.ptr(bo), M, hw, Cc, heads, float((Cc // heads) ** -0.5), L.ptr(out), L.ptr(out_lo), L.ptr(rs),
+                                          L.stream_ptr(h.device)))
+    if row_stats:
+        return out, out_lo, rs
+    return out, out_lo
+
+
+def row_stats_lo8(x, x_lo8):
+    _f16(x, "x")
+    M, Cc = x.shape
+    st = torch.empty(M, 1, 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().cs_op_row_stats_lo8(L.ptr(x), L.ptr(x_lo8), M, Cc, L.ptr(st), L.stream_ptr(x.device)))
+    return st
+
+
 def ln_fold_pack(w, bias, gamma, beta):
     """host-side folding of a LayerNorm (gamma, beta) into the linear layer w [N, K] (+ bias) that consumes it: returns (W' fp16 [N, K], s fp32 [N], b' fp32 [N])
     on the CPU (cs_op_ln_fold_pack; the executor packs its weights with the same function)."""
@@ -221,6 +277,17 @@ def attention(q, k, v, heads, scale=None, q_stride=None, k_stride=None, v_stride
     L.check(L.lib().cs_op_attention(L.ptr(q), q_stride or q.stride(1), L.ptr(k), k_stride or k.stride(1), L.ptr(v),
                                     v_stride or v.stride(1), L.ptr(out), heads * dh, B, heads, Nq, Nk, dh,
                                     float(scale if scale is not None else dh ** -0.5), L.stream_ptr(q.device)))
+    return out
+
+
+def conv_out(x, w_packed, bias, postprocess=False):
+    """3x3 conv (pad 1) NHWC x [B, H, W, Cin] -> NCHW [B, Cout, H, W] for a small Cout (cs_op_conv_out: the UNet's eps head, the VAE's image / moments heads)."""
+    _f16(x, "x")
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    out = torch.empty(B, Cout, H, W, dtype=torch.float16, device=x.device)
+    L.check(L.lib().cs_op_conv_out(L.ptr(x.contiguous()), B, Cin, H, W, L.ptr(w_packed.contiguous()), L.ptr(bias.to(x.device, torch.float16).contiguous()), Cout,
+                                   L.ptr(out), int(postprocess), L.stream_ptr(x.device)))
     return out
 
 

@@ -63,6 +63,12 @@ int cs_op_group_norm(const void* x0, int c0, const void* x1, int c1, int B, int 
 int cs_op_group_norm_pre(const void* x0, int c0, const float* stats0, const void* x1, int c1, const float* stats1, int B, int HW, int groups,
                          float eps, int silu, const void* gamma, const void* beta, void* workspace, void* out, void* stream);
 
+/* conv_out: 3x3 conv (pad 1) from NHWC x[B][H][W][Cin] to NCHW out[B][Cout][H][W], Cout small -- the UNet's 320 -> 4 eps head (diffusers
+ * UNet2DConditionModel.conv_out behind denoise_ppo.py:89-94) and the AutoencoderKL decoder's 128 -> 3 (utils.py:6-34).  w [Cout][9][Cin] (tap-major,
+ * channel-minor), bias [Cout].  Cout in {3, 4} (any H, W; Cin % 8 == 0) -- on 16 x 16 patches with Cin % 64 == 0 the matrix-core kernel -- or
+ * {8, 16} (H, W % 16 == 0, Cin % 64 == 0: the encoder's moments head).  postprocess (Cout 3 only): out = (v / 2 + 0.5).clamp(0, 1). */
+int cs_op_conv_out(const void* x, int B, int Cin, int H, int W, const void* w, const void* bias, int Cout, void* out, int postprocess, void* stream);
+
 /* Fused cross-attention sub-block of the SD1.5 transformer block (diffusers BasicTransformerBlock: norm2 -> attn2 -> residual; reference
  * call site denoise_ppo.py:89-94) at C = 320, 8 heads, <= 80 context keys:
  *   out[M,C] = h + (softmax(scale * (LayerNorm(h) wq^T) K^T) V) wo^T + bo,   kv[M/HW][Nk][2C] = (K | V) projections of the context.
@@ -109,6 +115,19 @@ int cs_op_layer_norm_x2(const void* x, const void* x_lo, const void* gamma, cons
 int cs_op_xattn_block_x2(const void* h, const void* h_lo, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
                          int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo, float* row_stats,
                          void* stream);
+
+/* 8-bit lo planes (round 6).  Inside a transformer block the hidden state's lo plane is only ever ADDED (to_out / cross-attention / feed-forward epilogues), never
+ * multiplied, so it is kept as ONE BYTE per element: e5m2 (sign, the fp16 exponent, two mantissa bits = the fp16 lo value rounded to its top byte; OCP e5m2, what
+ * torch.float8_e5m2 holds), converted two elements per instruction (v_cvt_pk_bf8_f32 / v_cvt_pk_f32_bf8).  hi + lo8 carries 14 significant bits against 22 with an fp16
+ * lo plane; on the SD1.5 UNet that moves the per-forward eps error from 8.8224e-4 to 8.8209e-4 (tools/sim_precision_r06.py) and halves the lo plane's bytes.
+ * The forms below are cs_op_linear_x2 / cs_op_xattn_block_x2 / cs_op_row_stats with res_lo8 / out_lo8 / h_lo8 / x_lo8 as [M][N] BYTE planes (same element layout);
+ * the GEMM's A operand is a plain fp16 tensor (an 8-bit plane is not an MFMA operand here). */
+int cs_op_linear_lo8(const void* x, int M, int K, const void* w, const void* bias, int N, const void* res, const void* res_lo8, void* out, void* out_lo8,
+                     float* row_stats, int* row_groups, void* splitk_ws, size_t splitk_ws_bytes, void* stream);
+int cs_op_xattn_block_lo8(const void* h, const void* h_lo8, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* wq, const void* kv,
+                          int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo8, float* row_stats,
+                          void* stream);
+int cs_op_row_stats_lo8(const void* x, const void* x_lo8, int M, int C, float* stats, void* stream);
 
 /* transformer GEMM (f16 / bf16, dtype = CS_F16 1 | CS_BF16 2): out[m][n] = act(x[m,:] . w[n,:] + bias[n]) (+ res, * gate);
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */
@@ -170,8 +189,12 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                1 (default) the resnet shortcut 1x1, 2 proj_out, 3 both, 0 none;
  *   "xcd_grid":  1 (default) weight-heavy conv / linear launches map the 8 XCDs as a 2-D grid over (row tiles, column tiles) so that each L2 streams a part
  *                of the weights instead of all of them, 0 contiguous tile runs per XCD always;
- *   "epi_fast":  1 (default) conv / linear epilogues that add a residual (+ its lo plane) or a time embedding issue those loads ahead of their use, branch-free
- *                (igemm_epilogue_impl FAST), 0 the generic load-where-added code; bit-identical, see profiles/r04_ab_epi_fast_*.txt;
+ *   "epi_fast":  bit 0: conv / linear epilogues that add a residual (+ its lo plane) or a time embedding issue those loads ahead of their use, branch-free
+ *                (igemm_epilogue_impl FAST), bit 1 (round 6): also the form "residual + its lo plane, no lo plane out" (the feed-forward's second linear in the
+ *                split mode); 3 (default), 0 the generic load-where-added code; bit-identical, see profiles/r04_ab_epi_fast_*.txt;
+ *   "lo8":       1 (default) inside cs_unet_forward (CS_RESIDUAL_F16X2) the transformer blocks' hidden state carries an 8-bit e5m2 lo plane (cs_op_linear_lo8),
+ *                0 an fp16 one;
+ *   "conv_out_mfma": 1 (default) the 16 x 16-patch conv_out kernels (cs_op_conv_out) on the matrix cores, 0 the v_dot2 patch kernel;
  *   "conv_in_mfma": 1 (default) the UNet's conv_in runs on the MFMA conv kernel over latents zero-padded to 64 channels, 0 the scalar conv_in kernel;
  *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),
  *                0 LayerNorm kernel + plain GEMM;

@@ -226,6 +226,35 @@ def test_conv3x3_halo_kernel_split_k(B, H, cin, N):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,post", [(2, 64, 64, 320, 4, False),      # the UNet's eps head (16 patches per sample, image borders on every patch side)
+                                                  (3, 16, 16, 64, 4, False),       # one patch = the whole image: every halo border is padding
+                                                  (1, 32, 48, 128, 3, True),       # the VAE's image head (non-square, postprocess)
+                                                  (2, 16, 32, 128, 8, False), (1, 32, 16, 64, 16, False),       # the encoder's moments head widths
+                                                  (2, 8, 8, 320, 4, False), (1, 24, 24, 40, 3, False)])          # shapes off the patch kernels (one wave per pixel)
+def test_conv_out_small_cout_kernels(B, H, W, cin, cout, post):
+    """cs_op_conv_out: NHWC -> NCHW 3x3 conv with 3 / 4 / 8 / 16 output channels against torch conv2d on the same fp16-rounded inputs; on the 16 x 16-patch
+    shapes the matrix-core kernel (conv_out_mfma_kernel, default) and the v_dot2 patch kernel must agree to accumulation-order precision."""
+    x = rnd(B, H, W, cin, seed=3)
+    w = rnd(cout, cin, 3, 3, seed=4, scale=(1.0 / (9 * cin)) ** 0.5)
+    b = rnd(cout, seed=5, scale=0.1)
+    ref = F.conv2d(nchw(x), w.float(), b.float(), padding=1)
+    if post:
+        ref = (ref / 2 + 0.5).clamp(0, 1)
+    wp = ops.pack_conv_weight(w)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            ops.set_tuning("conv_out_mfma", mode)
+            outs[mode] = ops.conv_out(x, wp, b, postprocess=post)
+            assert outs[mode].shape == (B, cout, H, W)
+            assert rel_l2(outs[mode].float(), ref) < 1e-3, (mode, rel_l2(outs[mode].float(), ref))
+            assert float((outs[mode].float() - ref).abs().max()) < 4e-3
+            assert torch.equal(outs[mode], ops.conv_out(x, wp, b, postprocess=post))          # deterministic
+    finally:
+        ops.set_tuning("conv_out_mfma", 1)
+    assert float((outs[1].float() - outs[0].float()).abs().max()) < 2e-3
+
+
 def test_conv2d_temb_broadcast_and_inplace_residual():
     x = rnd(2, 8, 8, 64, seed=1)
     w = rnd(128, 64, 3, 3, seed=2, scale=0.05)
