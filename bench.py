@@ -171,6 +171,71 @@ def live_traffic(mode, timeout_s=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+class PowerSampler:
+    """mean socket power / shader clock over a timed region from the amdgpu hwmon files (sysfs; the same source rocm-smi reads), sampled by a host thread every 20 ms.
+    Readable as an ordinary user on most boxes; when it is not, `summary()` says so and the bench line carries null."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.paths = {}
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        # card order follows the PCI order HIP enumerates in on a single-GPU box; with several cards take the device_index-th that has a power file
+        withp = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        if withp:
+            h = withp[min(device_index, len(withp) - 1)]
+            for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",))):
+                for nme in names:
+                    if os.path.exists(os.path.join(h, nme)):
+                        self.paths[key] = os.path.join(h, nme)
+                        break
+        self.samples = {k: [] for k in self.paths}
+        self._stop = None
+        self._thr = None
+
+    def _read(self):
+        for k, pth in self.paths.items():
+            try:
+                with open(pth) as f:
+                    self.samples[k].append(float(f.read().strip()))
+            except Exception:
+                pass
+
+    def start(self):
+        if not self.paths:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self._read()
+                self._stop.wait(0.02)
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=1.0)
+            self._thr = None
+        return self.summary()
+
+    def summary(self):
+        if not self.paths:
+            return {"available": False, "why": "no readable amdgpu hwmon power file under /sys/class/drm/card*/device/hwmon"}
+        out = {"available": True, "samples": max((len(v) for v in self.samples.values()), default=0), "source": "sysfs hwmon (amdgpu), 20 ms period"}
+        if self.samples.get("power_uW"):
+            v = self.samples["power_uW"]
+            out["mean_socket_power_w"] = sum(v) / len(v) / 1e6
+            out["max_socket_power_w"] = max(v) / 1e6
+        if self.samples.get("sclk_Hz"):
+            v = self.samples["sclk_Hz"]
+            out["mean_sclk_mhz"] = sum(v) / len(v) / 1e6
+            out["min_sclk_mhz"] = min(v) / 1e6
+        return out
+
+
 def _timed_ms(fn, iters, warm=1):
     for _ in range(warm):
         fn()
@@ -201,8 +266,12 @@ def extra_solver(dev, sch):
     lib = L.lib()
 
     def k1(B, iters):
-        t = lambda: torch.randn(B, 16384, device=dev).half()
-        x, eu, ec, out, eo, h1, h2, h3 = (t() for _ in range(8))
+        # the variant the ENGINE runs (engine.py defaults, round 6): fp32 solver state AND fp32 eps (the UNet's conv_out stores its accumulator unrounded), fp32 history
+        # ring and combined-eps store, plus the fp16 copy of the result for the denoiser written in the same pass (x_out_lp).  Per element: x, eps_u, eps_c, 3 history
+        # entries in (6 x 4 B); x', combined eps (2 x 4 B) and x' fp16 (2 B) out = 34 B (the fp16 kernel of rounds 1-4: 8 passes of 2 B)
+        t = lambda: torch.randn(B, 16384, device=dev)
+        x, eu, ec, eo, h1, h2, h3, out = (t() for _ in range(8))
+        out_lp = torch.empty(B, 16384, device=dev, dtype=torch.float16)
         actions = torch.rand(B, 3, device=dev)
         a = L.CsStepArgs()
         a.x, a.eps_text, a.eps_uncond, a.guidance = x.data_ptr(), ec.data_ptr(), eu.data_ptr(), 3.0
@@ -210,23 +279,42 @@ def extra_solver(dev, sch):
             a.hist[k] = h.data_ptr()
         a.m, a.order_dim, a.scaler_dim = 4, 4, 0
         a.actions, a.actions_stride, a.B, a.elems = actions.data_ptr(), 3, B, 16384
-        a.io_dtype = a.out_dtype = L.dtype_code(torch.float16)
-        a.x_out, a.eps_out = out.data_ptr(), eo.data_ptr()
+        a.io_dtype = a.out_dtype = L.dtype_code(torch.float32)
+        a.x_out, a.eps_out, a.x_out_lp, a.lp_dtype = out.data_ptr(), eo.data_ptr(), out_lp.data_ptr(), L.dtype_code(torch.float16)
         a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = 0.3, 0.95, 0.5, 0.86
         st = L.stream_ptr(dev)
         ms, _ = _timed_ms(lambda: L.check(lib.cs_lms_ddim_step(C.byref(a), st)), iters, warm=3)
-        nbytes = 8 * B * 16384 * 2
+        nbytes = 34 * B * 16384
         return ms * 1e3, nbytes / (ms * 1e-3) / 1e9
     us16, gb16 = k1(16, 200)
     us4k, gb4k = k1(4096, 20)
     row = torch.tensor([[874.0, 749.0]], device=dev)
     net = sch.factor_net
     pol_ms, _ = _timed_ms(lambda: net.probs_from(row, batch=16), 200, warm=5)
+    # the whole per-step solver chain as the engine drives it: scheduler.step on a CFG pair at batch 16 = policy MLP + torch.rand + inverse-CDF sample + the fused
+    # update (masks / conds come from the scheduler's per-shape caches): wall per call, back to back, host launch path included
+    B, n = 16, 8
+    eps = torch.randn(2 * B, 4, 64, 64, device=dev)
+    xs = [torch.randn(B, 4, 64, 64, device=dev), torch.empty(B, 4, 64, 64, device=dev)]
+    x16 = torch.empty(B, 4, 64, 64, device=dev, dtype=torch.float16)
+    ring = [torch.empty(B, 4, 64, 64, device=dev) for _ in range(4)]
+    keep = (sch.num_inference_steps, list(sch.ets))
+
+    def chain():
+        sch.set_timesteps(n, device=dev)
+        for i in range(n):
+            sch.step(eps[B:], sch.timesteps[i], xs[i & 1], return_dict=False, eps_uncond=eps[:B], guidance_scale=3.0, eps_out=ring[i % 4], out=xs[(i & 1) ^ 1], out_lp=x16)
+    chain_ms, _ = _timed_ms(chain, 20, warm=2)
+    if keep[0] is not None:
+        sch.set_timesteps(keep[0], device=dev)
     return {"k1_us_at_batch16": us16, "k1_gbps_at_batch16": gb16, "k1_us_at_1GB": us4k, "k1_gbps_at_1GB": gb4k,
-            "k1_frac_of_hbm_peak_at_1GB": gb4k / PEAK_HBM_GBPS, "k1_note": "fp16, order 4 steady state, CFG: 8 tensor passes per step; "
-            "batch 16 (4.2 MB) is launch-latency bound, the 1 GB working set is what the kernel sustains when HBM-bound",
+            "k1_frac_of_hbm_peak_at_1GB": gb4k / PEAK_HBM_GBPS, "k1_note": "the engine's variant: fp32 state, eps and history, CFG, order 4 steady state, fp16 copy of the result in the same pass: 34 B per element; "
+            "batch 16 (8.9 MB) is launch-latency bound, the 2.3 GB working set is what the kernel sustains when HBM-bound",
             "policy_mlp_us_at_batch16": pol_ms * 1e3, "policy_note": "cs_factor_probs, hidden 256, one conditioning row broadcast to 16 samples; "
-            "wall per call incl. the host launch path (back-to-back launches)"}
+            "wall per call incl. the host launch path (back-to-back launches)",
+            "solver_chain_us_per_step": chain_ms * 1e3 / n,
+            "solver_chain_note": "PPOScheduler.step on a CFG pair at batch 16, fp32 state and eps: policy MLP + torch.rand + inverse-CDF sample + fused update (incl. the fp16 copy of the "
+            "latents); 4 launches per step (round 5: 8 -- masks, two conds launches and the fp32 -> fp16 cast are gone); wall per call incl. the host launch path"}
 
 
 def extra_rollout(unet, vae, dev, B=80, n=8, epochs=4, iters=2):
@@ -460,6 +548,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.forward_events = [] if not args.graph else None
+    power = PowerSampler(local).start() if rank == 0 else None      # (a host thread reading two sysfs files every 20 ms; rank 0 only)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one()
@@ -468,6 +557,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    power = power.stop() if power is not None else None
     elapsed_local = elapsed
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -614,6 +704,25 @@ def main():
         ceilings = {"vendor_gemm_f16_8192_tflops": 2.0 * 8192 ** 3 / (gms * 1e-3) / 1e12,
                     "dtod_copy_1gib_tbps": 2.0 * (1 << 30) / (cms * 1e-3) / 1e12,
                     "note": "torch.matmul (hipBLASLt/rocBLAS) 8192^3 fp16 and a 1 GiB device copy (read + write bytes) on this box, random data"}
+        # SUSTAINED ceilings: the boxes of the pool differ by up to 8 % on one build and a 20 ms GEMM burst does not see it (it is not power-limited; the 28 ms forward,
+        # run back to back for seconds, is).  Two >= 250 ms back-to-back loops travel with every line as this box's index: the vendor GEMM again, and ONE fixed product
+        # kernel -- the 64 x 64 320 -> 320 3x3 conv at batch 32 (conv3_lw_kernel, the forward's dominant kernel) -- so that `roofline.frac` of two driver runs can be
+        # compared through `frac / sustained`.
+        try:
+            from consolver_amd import ops as _ops
+            gms_s = _ev(lambda: torch.matmul(ga, gb, out=gc), 300)
+            cx = (torch.randn(32, 64, 64, 320, device=dev)).half()
+            cw = _ops.pack_conv_weight(torch.randn(320, 320, 3, 3) * (1.0 / 2880) ** 0.5).to(dev)
+            cb = torch.zeros(320, device=dev, dtype=torch.float16)
+            cms_s = _ev(lambda: _ops.conv2d(cx, cw, cb, taps=9), 1500)
+            cfl = 2.0 * 32 * 4096 * 2880 * 320
+            ceilings.update({"sustained_vendor_gemm_f16_8192_tflops": 2.0 * 8192 ** 3 / (gms_s * 1e-3) / 1e12,
+                             "sustained_conv3_lw_64x64_320_tflops": cfl / (cms_s * 1e-3) / 1e12, "sustained_conv3_lw_us_per_launch": cms_s * 1e3,
+                             "sustained_note": "300 back-to-back 8192^3 GEMMs (~0.3 s) and 1500 back-to-back launches of the product's own 3x3 conv kernel at 64 x 64, 320 -> 320, "
+                                               "batch 32 (~0.3 s, random fp16 data): what this box sustains under the power limit"})
+            del cx, cw, cb
+        except Exception as e:
+            ceilings["sustained_error"] = f"{type(e).__name__}: {e}"
         del ga, gb, gc, src, dst
 
     # ---- the other configurations of BASELINE.json, measured in the same driver-run process (sub-records; N = 1 only) -------------
@@ -664,8 +773,13 @@ def main():
             roofline["traffic_ratio"] = roofline["traffic"] / roofline["traffic_algorithmic_one_plane"]
         if extras:
             rec.update({k: v for k, v in extras.items() if v is not None})
+        rec["power_over_timed_region"] = power
         if ceilings:
             rec["ceilings"] = ceilings
+            if ceilings.get("sustained_conv3_lw_64x64_320_tflops"):
+                # the forward's algorithmic rate over what this box sustains on the product's own dominant kernel: comparable across boxes of the pool
+                rec["roofline"]["achieved_over_sustained_conv3_lw"] = achieved / ceilings["sustained_conv3_lw_64x64_320_tflops"]
+                rec["roofline"]["achieved_over_sustained_vendor_gemm"] = achieved / ceilings["sustained_vendor_gemm_f16_8192_tflops"]
             rec["roofline"]["frac_of_vendor_gemm"] = achieved / ceilings["vendor_gemm_f16_8192_tflops"]
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(sd, unet.config, n, args.guidance, vae_sd=vae_sd)

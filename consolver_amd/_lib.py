@@ -29,7 +29,7 @@ class CsStepArgs(C.Structure):
                 ("actions", C.c_void_p), ("actions_stride", C.c_int), ("B", C.c_int), ("elems", C.c_int64),
                 ("io_dtype", C.c_int), ("out_dtype", C.c_int), ("x_out", C.c_void_p), ("eps_out", C.c_void_p),
                 ("sqrt_at", C.c_float), ("sqrt_1mat", C.c_float), ("sqrt_ap", C.c_float), ("sqrt_1map", C.c_float),
-                ("v_prediction", C.c_int), ("dt", C.c_float), ("x_is_f32", C.c_int)]
+                ("v_prediction", C.c_int), ("dt", C.c_float), ("x_is_f32", C.c_int), ("x_out_lp", C.c_void_p), ("lp_dtype", C.c_int)]
 
 
 class CsFluxConfig(C.Structure):
@@ -126,6 +126,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cs_unet_set_residual_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_unet_get_residual_precision": (C.c_int, [C.c_void_p]),
+    "cs_unet_set_output_dtype": (C.c_int, [C.c_void_p, C.c_int]),
+    "cs_unet_get_output_dtype": (C.c_int, [C.c_void_p]),
     "cs_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_unet_profile_entries": (C.c_int, [C.c_void_p]),
     "cs_unet_profile_entry": (C.c_char_p, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),

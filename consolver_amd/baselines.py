@@ -27,7 +27,7 @@ class DDIMBaselineScheduler(PPOScheduler):
         self.factor_net = None                      # no policy
         self._zero_actions = None
 
-    def step(self, model_output, timestep, sample, return_dict=True, *, eps_uncond=None, guidance_scale=1.0, out=None, **_ignored):
+    def step(self, model_output, timestep, sample, return_dict=True, *, eps_uncond=None, guidance_scale=1.0, out=None, out_lp=None, **_ignored):
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None'. Call 'set_timesteps' first.")
         L.require_cuda(model_output, "model_output")
@@ -52,7 +52,7 @@ class DDIMBaselineScheduler(PPOScheduler):
             raise ValueError(f"step(out=...) must have the sample's dtype {sample.dtype}, got {prev.dtype}")
         eps_out = torch.empty_like(model_output) if eps_uncond is not None else None     # the kernel writes the combined eps
         a = L.CsStepArgs()
-        self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, self._zero_actions, prev, eps_out, sample.dtype)
+        self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, self._zero_actions, prev, eps_out, sample.dtype, out_lp)
         a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = self._ddim_scalars(t, prev_t)
         a.v_prediction = int(self.config.prediction_type == "v_prediction")
         L.check(L.lib().cs_lms_ddim_step(C.byref(a), L.stream_ptr(dev)))

@@ -468,8 +468,9 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
 #pragma unroll
                         for (int r = 0; r < 8; ++r) f[r] += (float)t[r];
                         if (p.res_lo) {                       // split-fp16 residual stream: value = hi + lo
-                            if (p.lo8) lo8_decode_add(f, *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.res_lo) + off));
-                            else {
+                            if constexpr (LO8) {                // (the byte-plane family's kernels only ever see byte planes: launch_igemm_impl)
+                                lo8_decode_add(f, *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned char*>(p.res_lo) + off));
+                            } else {
                                 const f16x8 t2 = *reinterpret_cast<const f16x8*>(p.res_lo + off);
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) f[r] += (float)t2[r];
@@ -488,7 +489,7 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
                         float d8[8];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) d8[r] = f[r] - (float)o[r];
-                        if ((FAST == 2 && LO8) || (FAST == 0 && p.lo8)) {
+                        if constexpr (LO8) {
                             *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(p.out_lo) + off) = lo8_encode(d8);
                         } else {
                             f16x8 l;
@@ -546,36 +547,48 @@ __device__ __forceinline__ void igemm_epilogue_impl(const IgemmParams& p, f32x4 
     }
 }
 
-// the fp32-patch path: the FAST forms where the layer adds exactly what one of them covers (EFAST: the kernel wants them compiled), else the generic code
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RS2, int LNM, bool EFAST>
+// the fp32-patch path: the FAST forms where the layer adds exactly what one of them covers (EFAST: the kernel wants them compiled), else the generic code.
+// EPI (round 6) selects the FAMILY of forms a kernel instantiation carries -- a kernel template parameter like LNM, for the same reason: every form compiled into a
+// kernel taxes its register allocation, used or not (with the byte-plane forms added to the round-5 kernels gemm_w8_kernel<false, 0> went from 248 to 256 VGPRs,
+// <false, 2> and conv3_lw_kernel to 256 + scratch).  EPI 0: FAST 1 / 2 / 3 + the generic code, fp16 lo planes only -- the round-5 kernels, bit for bit.
+// EPI 1: the transformer blocks' linear layers on a hidden state with BYTE lo planes (lo8): FAST 2 and FAST 4 in their byte forms + the generic code reading / writing
+// bytes.  EPI 2: a residual with an fp16 lo plane and no lo plane out (the feed-forward's second linear when lo8 is off): FAST 4 + the generic code.
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RS2, int LNM, bool EFAST, int EPI = 0>
 __device__ __forceinline__ void igemm_epilogue_f32(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab, const char* ln_rows) {
-    if constexpr (EFAST) {
-        if (p.epi_fast != 0 && rows.all_valid()) {
+    if constexpr (EFAST && EPI != 0) {
+        constexpr bool L8 = EPI == 1;
+        if (rows.all_valid() && p.res && !p.temb && p.res_lo) {
+            // (one FAST form per instantiation: the row-statistics producers -- to_out -- write both planes, the plain ones -- the feed-forward's second linear -- the hi plane)
+            if constexpr (L8 && LNM == 2) {
+                if (p.out_lo && (p.epi_fast & 1)) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST, true>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+            }
+            if constexpr (LNM == 0) {
+                if (!p.out_lo && (p.epi_fast & 2)) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 4, EFAST, L8>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
+            }
+        }
+        igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0, EFAST, L8>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+        return;
+    } else if constexpr (EFAST) {
+        if ((p.epi_fast & 1) && rows.all_valid()) {
             if (p.res && !p.temb) {
-                if (p.res_lo && p.out_lo) {
-                    if (p.lo8) igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST, true>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
-                    else igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
-                    return;
-                }
-                if (p.res_lo && !p.out_lo && (p.epi_fast & 2)) {
-                    if (p.lo8) igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 4, EFAST, true>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
-                    else igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 4, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
-                    return;
-                }
+                if (p.res_lo && p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
                 if (!p.res_lo && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 1, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
             } else if (p.temb && !p.res && !p.out_lo) { igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 3, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
         }
     }
-    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+    // (EPI 1 outside the EFAST kernels = igemm_kernel: the generic code on byte planes)
+    igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RS2, true, LNM, 0, EFAST, EPI == 1>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
 }
 
 // EFAST: the kernel (gemm_w8 / gemm_lw / conv3_lw) hands its bias through an LDS table (LTAB) and wants the FAST forms of the fp32-patch path compiled
-template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0, bool EFAST = false>
+template <bool GEGLU, int NT, int MT, int GROUP, class RowMap, int RSPLIT = 1, int LNM = 0, bool EFAST = false, int EPI = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[NT][MT], const RowMap& rows, int n_base, int lane, char* wave_lds, char* ln_tab = nullptr, const char* ln_rows = nullptr) {
     if constexpr (LNM == 2) {                           // row statistics come from the fp32 values: always the fp32-patch path
-        igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 2, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+        igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 2, EFAST, EPI>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else if constexpr (LNM == 1) {                    // a folded LayerNorm's consumer adds nothing after the product (launch_igemm_impl checks)
         igemm_epilogue_impl<GEGLU, NT, MT, GROUP, RowMap, RSPLIT, false, 1, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
+    } else if constexpr (EPI != 0) {                    // (these families always add something: launch_igemm_impl routes only such layers here)
+        igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 0, EFAST, EPI>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows);
     } else {
         if constexpr (!GEGLU) {
             if (p.temb || p.res || p.out_lo) { igemm_epilogue_f32<GEGLU, NT, MT, GROUP, RowMap, RSPLIT * 2, 0, EFAST>(p, acc, rows, n_base, lane, wave_lds, ln_tab, ln_rows); return; }
@@ -1284,7 +1297,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 // With ONE tile per CU and the operands in L2 / Infinity Cache this form is latency-free; as a general GEMM it loses to the 256 x 320 tile (twice the
 // L2 -> LDS bytes per FLOP: profiles/r03_ab_gemm_lw.txt), so launch_igemm_impl uses it only where gemm_big_kernel<false, 160> used to run.
 // ------------------------------------------------------------------------------------------------
-template <int LNM = 0>
+template <int LNM = 0, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
     constexpr int BMX = 256, BN = 160, NT = BN / 16, MT = 4, NWB = 3;
     constexpr int A_BYTES = BMX * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1423,7 +1436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));            // (the epilogue's reads of the accumulators stay behind the padding: hipcc may move consumers of an asm result up between volatile statements)
     __builtin_amdgcn_s_barrier();                                               // E
-    igemm_epilogue<false, NT, MT, NT, LinearRows, 2, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264, LNM == 1 ? lnx + BMX * 8 : lnx, LNM == 1 ? lnx + wm * 64 * 8 : nullptr);
+    igemm_epilogue<false, NT, MT, NT, LinearRows, 2, LNM, true, EPI>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk, lane, smem + w * 11264, LNM == 1 ? lnx + BMX * 8 : lnx, LNM == 1 ? lnx + wm * 64 * 8 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1444,7 +1457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_lw_kernel(IgemmParams p) {
 // bit-identical, 0 .. -4 % per launch, UNet forward unchanged (profiles/r04_ab_gemm_persist.txt), removed.  Two things ate the prologue it was meant to hide: hipcc
 // puts s_waitcnt vmcnt(0) in front of the epilogue's first LDS access while an LDS-DMA it knows of is in flight (it cannot tell the patch from the stage), and the wait
 // for the prefetched stage at the top of the next tile also waits for the epilogue's stores -- vmcnt counts loads, stores and LDS-DMA together, in issue order.)
-template <bool GEGLU, int LNM = 0>
+template <bool GEGLU, int LNM = 0, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     constexpr int BMX = 256, BNX = 320, NT = BNX / 32, MT = 4;
     constexpr int A_BYTES = BMX * 128, B_BYTES = BNX * 128, STAGE = A_BYTES + B_BYTES;      // 32 KB + 40 KB
@@ -1577,7 +1590,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8_kernel(IgemmParams p) {
     char* const ln_tab = LNM == 1 ? lnx + BMX * 8 + wn * (2 * (BNX / 2) * 4) : lnx + wn * (BNX / 2) * 2;      // (LNM != 1: the wave's half of the bias table)
     const char* const ln_rows = LNM == 1 ? lnx + wm * 64 * 8 : nullptr;
     if constexpr (GEGLU) igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
-    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2, LNM, true>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
+    else igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 2, LNM, true, EPI>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BNX / 2), lane, smem + w * 11264, ln_tab, ln_rows);
 }
 
 // row statistics of a [M][C] tensor (value = x + x_lo when x_lo != null): stats[M][1][2] = (sum, sum of squares) per row.  The fallback of IgemmArgs::row_stats
@@ -1888,7 +1901,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(IgemmParams p) {
     if (p.debug & 16384) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_stamp(p.debug, blockIdx.x, 4); }
 }
 
-template <int BN, bool CONV3, bool GEGLU, int LNM = 0>
+template <int BN, bool CONV3, bool GEGLU, int LNM = 0, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int NT = BN / 32;          // 16-wide n tiles per wave (wave tile = 64 x BN/2)
     constexpr int MT = 4;
@@ -2026,14 +2039,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         return;
     }
     // (no FAST forms of the fp32-patch epilogue here: their registers cost this kernel a wave of occupancy per SIMD, 4 -> 3 / 3 -> 2)
-    igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264, LNM == 1 ? smem + 4 * 11264 + w * 1280 : nullptr);
+    igemm_epilogue<GEGLU, NT, MT, NT, LinearRows, 1, LNM, false, EPI>(p, acc, LinearRows{m_blk + wm * 64, p.M}, n_blk + wn * (BN / 2), lane, smem + w * 11264, LNM == 1 ? smem + 4 * 11264 + w * 1280 : nullptr);
 }
 
-template <int BN, bool CONV3, bool GEGLU, int LNM = 0>
+template <int BN, bool CONV3, bool GEGLU, int LNM = 0, int EPI = 0>
 int launch_variant(const IgemmParams& p, hipStream_t s, int splits = 1) {
     constexpr size_t lds = 2 * (BM * BK * 2 + BN * BK * 2);
     static bool configured = false;
-    auto kfn = igemm_kernel<BN, CONV3, GEGLU, LNM>;
+    auto kfn = igemm_kernel<BN, CONV3, GEGLU, LNM, EPI>;
     if (!configured) {
         CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
@@ -2122,11 +2135,15 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
         p.KT = 2 * p.KTh;                                  // Ktot (row length of w) stays cin: the lo k steps re-read the same weight columns
     }
     if (a.geglu && a.out_lo) CS_FAIL(CS_E_ARG, "igemm: the GEGLU epilogue writes no lo plane");
+    if (p.lo8 && (a.taps != 1 || a.temb || a.geglu || a.ln_stats)) CS_FAIL(CS_E_ARG, "igemm: 8-bit lo planes (lo8) are built for plain 1x1 / linear layers (the transformer hidden state)");
+    p.epi_fast = tune().epi_fast;
+    // the epilogue family (igemm_epilogue_f32, EPI): 1 = byte lo planes, or a residual with an fp16 lo plane and no lo plane out (FAST 4) -- separate kernel instantiations
+    const int epi = (a.taps == 1 && !a.geglu && !a.ln_stats && !a.temb) ? (p.lo8 ? 1 : (p.res && p.res_lo && !p.out_lo && (p.epi_fast & 2)) ? 2 : 0) : 0;
     p.debug = tune().debug; p.partial = nullptr;
     // GroupNorm statistics of the output: by the epilogue where the chosen kernel runs one (not the split-K forms), else by the caller below
     const bool stats_ok = a.gn_stats && !a.geglu && p.HoWo % 64 == 0 && tune().gn_fuse != 0;
     p.gn_stats = stats_ok ? a.gn_stats : nullptr;
-    p.gm = 1; p.pn = 0; p.epi_fast = tune().epi_fast;
+    p.gm = 1; p.pn = 0;
     const double a_bytes = 2.0 * a.B * a.Hi * a.Wi * cin, w_bytes = 2.0 * a.N * a.taps * cin;
     const int tiles_m = (p.M + BM - 1) / BM;
     int bn;
@@ -2234,16 +2251,17 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
             }
             // round 3: the hand-scheduled k loop (gemm_w8_kernel) whenever 32-bit byte offsets reach every operand row
             const bool off32 = (double)p.M * (a.c0 > a.c1 ? a.c0 : a.c1) * 2 < 4.0e9 && (double)a.N * p.Ktot * 2 < 4.0e9;
-            if ((split_a || lnm) && !(tune().gemm_w8 && off32 && !tune().debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging and no LayerNorm epilogues
+            if ((split_a || lnm || epi == 1) && !(tune().gemm_w8 && off32 && !tune().debug)) goto generic_tiles;       // gemm_big_kernel has no lo-plane staging, no LayerNorm epilogues, no byte planes
             if (tune().gemm_w8 && off32 && !tune().debug) {
                 typedef void (*w8_fn)(IgemmParams);
-                static const w8_fn w8[5] = {gemm_w8_kernel<false, 0>, gemm_w8_kernel<true, 0>, gemm_w8_kernel<false, 1>, gemm_w8_kernel<true, 1>, gemm_w8_kernel<false, 2>};
+                static const w8_fn w8[8] = {gemm_w8_kernel<false, 0>, gemm_w8_kernel<true, 0>, gemm_w8_kernel<false, 1>, gemm_w8_kernel<true, 1>, gemm_w8_kernel<false, 2>,
+                                            gemm_w8_kernel<false, 0, 1>, gemm_w8_kernel<false, 2, 1>, gemm_w8_kernel<false, 0, 2>};
                 static bool configured_w8 = false;
                 if (!configured_w8) {
                     for (w8_fn f : w8) CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + LN_LDS_W8)));
                     configured_w8 = true;
                 }
-                hipLaunchKernelGGL(w8[lnm == 2 ? 4 : 2 * lnm + (a.geglu ? 1 : 0)], dim3(p.nblk), dim3(512), lds + LN_LDS_W8, s, p);
+                hipLaunchKernelGGL(w8[epi == 1 ? (lnm == 2 ? 6 : 5) : (epi == 2 && lnm == 0) ? 7 : lnm == 2 ? 4 : 2 * lnm + (a.geglu ? 1 : 0)], dim3(p.nblk), dim3(512), lds + LN_LDS_W8, s, p);
                 CS_CHECK_LAUNCH();
                 return CS_OK;
             }
@@ -2265,17 +2283,17 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
                 CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 configured = true;
             }
-            if ((split_a || lnm) && !(tune().gemm_lw && !tune().debug)) goto generic_tiles;
+            if ((split_a || lnm || epi == 1) && !(tune().gemm_lw && !tune().debug)) goto generic_tiles;
             if (tune().gemm_lw && !tune().debug) {                    // round 3: the loader-wave form (three 52 KB stages)
                 constexpr size_t lds_lw = 3 * (256 * BK * 2 + 160 * BK * 2);
                 typedef void (*lw_fn)(IgemmParams);
-                static const lw_fn lwk[3] = {gemm_lw_kernel<0>, gemm_lw_kernel<1>, gemm_lw_kernel<2>};
+                static const lw_fn lwk[6] = {gemm_lw_kernel<0>, gemm_lw_kernel<1>, gemm_lw_kernel<2>, gemm_lw_kernel<0, 1>, gemm_lw_kernel<2, 1>, gemm_lw_kernel<0, 2>};
                 static bool configured_lw = false;
                 if (!configured_lw) {
                     for (lw_fn f : lwk) CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_lw + LN_LDS_LW)));
                     configured_lw = true;
                 }
-                hipLaunchKernelGGL(lwk[lnm], dim3(p.nblk), dim3(512), lds_lw + LN_LDS_LW, s, p);
+                hipLaunchKernelGGL(lwk[epi == 1 ? (lnm == 2 ? 4 : 3) : (epi == 2 && lnm == 0) ? 5 : lnm], dim3(p.nblk), dim3(512), lds_lw + LN_LDS_LW, s, p);
                 CS_CHECK_LAUNCH();
                 return CS_OK;
             }
@@ -2300,6 +2318,10 @@ generic_tiles:
     li->row_groups = (splits == 1 && !conv3) ? a.N / (bn / 2) : 0;          // igemm_kernel: 64 x bn / 2 wave tiles; the split-K reduce leaves no row statistics
     if (conv3) return bn == 128 ? launch_variant<128, true, false>(p, s, splits) : launch_variant<160, true, false>(p, s, splits);
     const int lk = splits > 1 ? 0 : lnm;            // (split-K: raw partial sums leave the main kernel; the reduce kernel applies a folded LayerNorm itself)
+    if (epi == 1 && splits == 1) {                  // byte planes (split-K: the reduce kernel handles the planes, the main kernel writes raw partial sums)
+        if (bn == 128) return lk == 2 ? launch_variant<128, false, false, 2, 1>(p, s, splits) : launch_variant<128, false, false, 0, 1>(p, s, splits);
+        return lk == 2 ? launch_variant<160, false, false, 2, 1>(p, s, splits) : launch_variant<160, false, false, 0, 1>(p, s, splits);
+    }
     if (bn == 128) return lk == 1 ? launch_variant<128, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<128, false, false, 2>(p, s, splits) : launch_variant<128, false, false>(p, s, splits);
     return lk == 1 ? launch_variant<160, false, false, 1>(p, s, splits) : lk == 2 ? launch_variant<160, false, false, 2>(p, s, splits) : launch_variant<160, false, false>(p, s, splits);
 }

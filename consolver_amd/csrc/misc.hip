@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const f16* __restrict__ la
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x, int B, int Cin, int H, int W,
                                                        const f16* __restrict__ w, const f16* __restrict__ bias, f16* __restrict__ out,
-                                                       int postprocess) {
+                                                       int postprocess, int out_f32) {
     const int lane = threadIdx.x & 63;
     const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= (long)B * H * W) return;
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x
         for (int o = 0; o < COUT; ++o) if (lane == o) v = acc[o];
         v += (float)bias[lane];
         if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
-        out[(((size_t)b * COUT + lane) * H + yo) * W + xo] = (f16)v;
+        const size_t oi = (((size_t)b * COUT + lane) * H + yo) * W + xo;
+        if (out_f32) reinterpret_cast<float*>(out)[oi] = v; else out[oi] = (f16)v;
     }
 }
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const f16* __restrict__ x
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restrict__ x, int Cin, int H, int W, const f16* __restrict__ w,
-                                                             const f16* __restrict__ bias, f16* __restrict__ out, int postprocess) {
+                                                             const f16* __restrict__ bias, f16* __restrict__ out, int postprocess, int out_f32) {
     __shared__ __attribute__((aligned(16))) f16 halo[324 * 64];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int PX = W >> 4;
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restri
     for (int o = 0; o < COUT; ++o) {
         float v = acc[o] + (float)bias[o];
         if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
-        out[(((size_t)b * COUT + o) * H + y) * W + xx] = (f16)v;
+        const size_t oi = (((size_t)b * COUT + o) * H + y) * W + xx;
+        if (out_f32) reinterpret_cast<float*>(out)[oi] = v; else out[oi] = (f16)v;
     }
 }
 
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restri
 // of the chunk being multiplied (register prefetch, single LDS buffer: 41.5 KB, three workgroups per CU).  What remains is the streaming read.
 template <int COUT>
 __global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __restrict__ x, int Cin, int H, int W, const f16* __restrict__ w,
-                                                            const f16* __restrict__ bias, f16* __restrict__ out, int postprocess) {
+                                                            const f16* __restrict__ bias, f16* __restrict__ out, int postprocess, int out_f32) {
     static_assert(COUT >= 1 && COUT <= 16, "one 16-column MFMA tile");
     __shared__ __attribute__((aligned(16))) f16 halo[324 * 64];
     __shared__ __attribute__((aligned(16))) f16 wts[COUT * 9 * 64];      // this chunk's filters [COUT][tap][64]: staged with the halo, so that the fragment reads wait on lgkmcnt --
@@ -289,24 +291,26 @@ __global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __rest
         for (int mt = 0; mt < 4; ++mt) {
             const int y = y0 + wave * 4 + mt;
             typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 o;
+            f16x4 o; f32x4 of;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[mt][r] + bv;
                 if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
-                o[r] = (f16)v;
+                o[r] = (f16)v; of[r] = v;
             }
-            *reinterpret_cast<f16x4*>(out + (((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4) = o;
+            const size_t oi = (((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4;
+            if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + oi) = of;      // (the UNet's eps head for the native engine: no fp16 rounding of the denoiser's output)
+            else *reinterpret_cast<f16x4*>(out + oi) = o;
         }
     }
 }
 
 // 16 x 16-patch conv_out: the MFMA form (default) or the v_dot2 one (cs_set_tuning("conv_out_mfma", 0))
 template <int COUT>
-static void launch_conv_out_patch(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s) {
+static void launch_conv_out_patch(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, f16* out, int postprocess, hipStream_t s, int out_f32 = 0) {
     const dim3 grid((H / 16) * (W / 16), B);
-    if (tune().conv_out_mfma) hipLaunchKernelGGL(conv_out_mfma_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
-    else hipLaunchKernelGGL(conv_out_patch_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess);
+    if (tune().conv_out_mfma) hipLaunchKernelGGL(conv_out_mfma_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess, out_f32);
+    else hipLaunchKernelGGL(conv_out_patch_kernel<COUT>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, out, postprocess, out_f32);
 }
 
 
@@ -495,7 +499,7 @@ int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16* w, c
         return CS_OK;
     }
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, postprocess);
+    hipLaunchKernelGGL(conv_out_kernel<3>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, postprocess, 0);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -533,17 +537,17 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
     return CS_OK;
 }
 
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s) {
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, int out_f32) {
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out: null pointer");
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
     if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
-        launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s);
+        launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s, out_f32);
         CS_CHECK_LAUNCH();
         return CS_OK;
     }
     const long M = (long)B * H * W;
-    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0);
+    hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0, out_f32);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

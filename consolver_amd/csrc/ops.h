@@ -27,6 +27,10 @@ struct TuneSet {
     // CS_RESIDUAL_F16X2 only: which GEMMs that consume the residual stream DIRECTLY read hi + lo (two passes of the k loop, IgemmArgs::a0_lo) instead of the hi
     // plane: bit 0 the resnet shortcut 1x1 (default: its operand rounding is the largest single stream-level error left), bit 1 proj_out
     int x2_split_a = 1;
+    // bit i: the i-th resnet shortcut 1x1 (creation order: down blocks, then up blocks) reads the hi plane ONLY even when x2_split_a bit 0 is set.  Default 0x78 on the
+    // SD1.5 topology = up_blocks.0.resnets.1 / .2 and up_blocks.1.resnets.0 / .1 (the 2560 -> 1280 shortcuts at the 8 x 8 / 16 x 16 levels): together +0.9 % per-forward
+    // error for a quarter of the shortcuts' second k pass (tools/sim_precision_r06.py: per-layer error of dropping the lo operand against M K N)
+    int x2_sc_skip = 0x78;
     // 1: the transformer blocks' LayerNorms are folded into the linear layers that consume them (gamma in the packed weights, (mean, rstd) applied in the
     // GEMM epilogue from row statistics the producing layer's epilogue left): no LayerNorm kernel, no normalised copy of the hidden state.  0: ln_kernel + plain GEMMs.
     int ln_fold = 1;
@@ -161,8 +165,9 @@ int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16* b,
 int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias,
                    int Cout, f16* out, hipStream_t s, f16* out_lo = nullptr);
 // conv_out: NHWC [B][H][W][Cin] -> NCHW [B][Cout][H][W], 3x3 pad 1 (Cout small)
+// out_f32 != 0: `out` is an fp32 tensor (the same NCHW layout)
 int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias, int Cout,
-                    f16* out, hipStream_t s);
+                    f16* out, hipStream_t s, int out_f32 = 0);
 
 // ---- transformer (FLUX DiT) ops, f16 or bf16 (dtype = CS_F16 / CS_BF16) -------------------------------------
 struct Gemm2Args {

@@ -67,6 +67,22 @@ template <> struct Io<bf16_tag> {
     __device__ static float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 };
 
+// the low-precision copy of a result vector (CsStepArgs::x_out_lp): V = 4 or 8 values as fp16 (lp_bf16 == 0) or bf16, one 8- / 16-byte store
+template <int V>
+__device__ __forceinline__ void store_lp(void* p, int64_t i, const float (&o)[V], int lp_bf16) {
+    unsigned w[V / 2];
+#pragma unroll
+    for (int j = 0; j < V / 2; ++j) {
+        if (lp_bf16) w[j] = (unsigned)f32_to_bf16(o[2 * j]) | ((unsigned)f32_to_bf16(o[2 * j + 1]) << 16);
+        else { union { f16 h[2]; unsigned u; } c; c.h[0] = (f16)o[2 * j]; c.h[1] = (f16)o[2 * j + 1]; w[j] = c.u; }
+    }
+    if constexpr (V == 8) *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p) + i) = u32x4{w[0], w[1], w[2], w[3]};
+    else { typedef unsigned u32x2v __attribute__((ext_vector_type(2))); *reinterpret_cast<u32x2v*>(reinterpret_cast<u16*>(p) + i) = u32x2v{w[0], w[1]}; }
+}
+__device__ __forceinline__ void store_lp1(void* p, int64_t i, float v, int lp_bf16) {
+    if (lp_bf16) reinterpret_cast<u16*>(p)[i] = f32_to_bf16(v); else reinterpret_cast<f16*>(p)[i] = (f16)v;
+}
+
 struct StepParams {
     const void* x; const void* ec; const void* eu; float g;
     const void* hist[CS_MAX_ORDER];
@@ -76,6 +92,8 @@ struct StepParams {
     void* x_out; void* eps_out;
     float sat, s1mat, sap, s1map; int vpred; float dt;
     int x_f32;   // x is fp32 although eps / history are TI (scheduler_fmppo.py:354 upcasts the sample, not the model output)
+    void* x_lp;  // optional 16-bit copy of an fp32 result (CsStepArgs::x_out_lp)
+    int lp_bf16; // ... as bf16 (else fp16)
 };
 
 // coefficient fix-up, identical for every thread of a sample (b is block-uniform)
@@ -166,6 +184,7 @@ __global__ __launch_bounds__(256) void lms_step_kernel(StepParams p) {
 #pragma unroll
             for (int j = 0; j < V; ++j) Io<TO>::store1(p.x_out, i + j, o[j]);
         }
+        if (p.x_lp) store_lp<V>(p.x_lp, i, o, p.lp_bf16);        // (block-uniform) the 16-bit view of an fp32 state: what `x.to(model dtype)` would round the stored result to
     }
     // scalar tail (elems % V != 0): handled by the last block of each sample
     if (blockIdx.x == 0) {
@@ -177,7 +196,9 @@ __global__ __launch_bounds__(256) void lms_step_kernel(StepParams p) {
 #pragma unroll
             for (int k = 0; k < CS_MAX_ORDER - 1; ++k) hh[k] = (k < p.m - 1) ? Io<TI>::load1(p.hist[k], i) : 0.f;
             if (p.eps_out) Io<TI>::store1(p.eps_out, i, e);
-            Io<TO>::store1(p.x_out, i, solve_one<TI, TO, EULER, false>(p, x, e, hh, c, sc0, sc1));
+            const float r = solve_one<TI, TO, EULER, false>(p, x, e, hh, c, sc0, sc1);
+            Io<TO>::store1(p.x_out, i, r);
+            if (p.x_lp) store_lp1(p.x_lp, i, r, p.lp_bf16);
         }
     }
 }
@@ -206,6 +227,9 @@ int launch_step(const CsStepArgs* a, void* stream) {
     p.sat = a->sqrt_at; p.s1mat = a->sqrt_1mat; p.sap = a->sqrt_ap; p.s1map = a->sqrt_1map;
     p.vpred = a->v_prediction; p.dt = a->dt;
     p.x_f32 = (a->x_is_f32 != 0 && a->io_dtype != CS_F32);
+    p.x_lp = a->x_out_lp; p.lp_bf16 = a->lp_dtype == CS_BF16;
+    if (a->x_out_lp && (a->out_dtype != CS_F32 || (a->lp_dtype != CS_F16 && a->lp_dtype != CS_BF16)))
+        CS_FAIL(CS_E_ARG, "x_out_lp is the 16-bit copy (lp_dtype CS_F16 or CS_BF16) of an fp32 result (out_dtype CS_F32)");
     const int vec = (a->io_dtype == CS_F32) ? 4 : 8;
     int64_t nvec = a->elems / vec;
     int gx = (int)((nvec + 255) / 256);

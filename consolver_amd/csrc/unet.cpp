@@ -46,7 +46,7 @@ struct HostTensor { std::vector<int64_t> shape; std::vector<f16> data; };
 
 struct Conv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; };
 struct Norm { f16* g = nullptr; f16* b = nullptr; int c = 0; float eps = 1e-5f; };
-struct Resnet { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; };
+struct Resnet { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; int sc_index = -1; };      // sc_index: position among the shortcut convs in creation order (knob x2_sc_skip)
 struct LnLinear { f16* w = nullptr; float* s = nullptr; float* b = nullptr; };     // a linear layer with the LayerNorm in front of it folded in (IgemmArgs::ln_*)
 struct Xformer {
     Norm gn, ln1, ln2, ln3;
@@ -125,6 +125,7 @@ struct CsUNet {
     Conv down_samp[4], up_samp[4]; bool has_down[4] = {}, has_up[4] = {};
     Resnet mid_res[2]; Xformer mid_att;
     size_t kv_halfs_per_token = 0;
+    int n_shortcuts = 0;
     // run state
     Arena arena;
     bool profiling = false;
@@ -133,6 +134,7 @@ struct CsUNet {
     double prof_ms[P_COUNT] = {}, prof_flops[P_COUNT] = {}, prof_bytes[P_COUNT] = {}; int prof_launches[P_COUNT] = {};
     double dry_flops = 0;
     int residual = CS_RESIDUAL_F16X2;   // cs_unet_set_residual_precision (default: the mode that meets the 1e-3 latent gate)
+    int out_dtype = CS_F16;             // cs_unet_set_output_dtype: CS_F16 (the model dtype, what the reference's UNet returns) or CS_F32 (the native engine's choice)
     std::map<std::string, int> tune;    // cs_unet_set_tuning: knob values THIS handle's forwards run with (on top of the process-wide cs_set_tuning state)
 };
 
@@ -264,7 +266,7 @@ bool make_resnet(CsUNet* u, const std::string& p, Resnet& r, std::vector<f16>& t
               make_conv(u, p + ".conv2", r.c2);
     r.cin = r.c1.cin; r.cout = r.c1.cout;
     r.has_sc = u->host.count(p + ".conv_shortcut.weight") > 0;
-    if (r.has_sc) ok = ok && make_conv(u, p + ".conv_shortcut", r.sc);
+    if (r.has_sc) { ok = ok && make_conv(u, p + ".conv_shortcut", r.sc); r.sc_index = u->n_shortcuts++; }
     r.temb_off = (int)tpb.size();
     const HostTensor& tw = T(u, p + ".time_emb_proj.weight");
     tpw.insert(tpw.end(), tw.data.begin(), tw.data.end());
@@ -333,6 +335,7 @@ struct Run {
     int v_ln_fold = 1;             // snapshot of tune().ln_fold
     int v_conv_in_mfma = 1;        // snapshot of tune().conv_in_mfma
     int v_lo8 = 1;                 // snapshot of tune().lo8
+    int v_sc_skip = 0;             // snapshot of tune().x2_sc_skip
     // the transformer hidden state's lo plane as bytes: only where every consumer of that plane adds it (folded LayerNorms: ln_kernel reads an fp16 lo plane;
     // proj_out not reading hi + lo as its operand)
     bool h_lo8() const { return split && v_lo8 != 0 && v_ln_fold != 0 && !(v_split_a & 2); }
@@ -476,7 +479,8 @@ struct Run {
         St out = salloc(M * r.cout);
         St res = x;
         if (r.has_sc) {                                      // split mode: the 1x1 multiplies hi + lo of [x | skip] (two passes of its k loop over the same weights)
-            const bool sa = split && (v_split_a & 1) && x.lo && (!cs || skip.lo);
+            // (x2_sc_skip: the shortcuts whose hi + lo operand buys the least per microsecond read the hi plane only -- tools/sim_precision_r06.py)
+            const bool sa = split && (v_split_a & 1) && !((v_sc_skip >> r.sc_index) & 1) && x.lo && (!cs || skip.lo);
             conv(r.sc, x.hi, cx, skip.hi, cs, H, W, H, W, 1, 0, nullptr, St(), out, false, nullptr, sa ? x.lo : nullptr, sa ? skip.lo : nullptr);
             res = out;
         }
@@ -629,7 +633,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = tune().x2_split_a; R.count_executed = count_executed;
-    R.v_lo8 = var.lo8;
+    R.v_lo8 = var.lo8; R.v_sc_skip = tune().x2_sc_skip;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -736,7 +740,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     f16* n = R.alloc((size_t)B * H * W * ch);
     R.group_norm(u->norm_out, h, ch, St(), 0, H * W, true, n);
     R.srelease(h);
-    R.launch(P_MISC, 2.0 * B * H * W * 9.0 * ch * c.out_channels, 2.0 * B * H * W * ch, [&] { return launch_conv_out(n, B, ch, H, W, u->conv_out.w, u->conv_out.b, c.out_channels, out, s); });
+    R.launch(P_MISC, 2.0 * B * H * W * 9.0 * ch * c.out_channels, 2.0 * B * H * W * ch, [&] { return launch_conv_out(n, B, ch, H, W, u->conv_out.w, u->conv_out.b, c.out_channels, out, s, u->out_dtype == CS_F32); });
     R.release(n); R.release(tscratch); R.release(temb); R.release(tproj);
     return R.rc;
 }
@@ -932,6 +936,14 @@ int cs_unet_set_residual_precision(CsUNet* u, int mode) {
     return CS_OK;
 }
 int cs_unet_get_residual_precision(const CsUNet* u) { return u ? u->residual : -1; }
+
+int cs_unet_set_output_dtype(CsUNet* u, int dtype) {
+    if (!u) CS_FAIL(CS_E_ARG, "unet is NULL");
+    if (dtype != CS_F16 && dtype != CS_F32) CS_FAIL(CS_E_DTYPE, "unet output dtype %d: CS_F16 or CS_F32", dtype);
+    u->out_dtype = dtype;
+    return CS_OK;
+}
+int cs_unet_get_output_dtype(const CsUNet* u) { return u ? u->out_dtype : -1; }
 
 int cs_unet_set_profiling(CsUNet* u, int on) { if (!u) return CS_E_ARG; u->profiling = on != 0; return CS_OK; }
 int cs_unet_profile_entries(const CsUNet* u) { return u ? P_COUNT : 0; }

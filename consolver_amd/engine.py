@@ -25,10 +25,18 @@ from . import _lib as L
 
 
 class SDSamplingEngine:
-    def __init__(self, unet, scheduler, guidance_scale=3.0, vae=None, latents_dtype=torch.float32):
+    def __init__(self, unet, scheduler, guidance_scale=3.0, vae=None, latents_dtype=torch.float32, eps_dtype=None):
         if latents_dtype not in (torch.float32, torch.float16):
             raise ValueError("latents_dtype must be torch.float32 (default) or torch.float16")
+        # Round 6: the denoiser's OUTPUT is taken in fp32 too when the state is fp32 (cs_unet_set_output_dtype: conv_out stores its accumulator unrounded) -- the eps
+        # tensors, the CFG combine and the history ring then carry no fp16 rounding (2.8e-4 relative each for eps and for the combined eps).  eps_dtype=torch.float16
+        # is the reference pipeline's own class (the UNet returns the model dtype).
+        if eps_dtype is None:
+            eps_dtype = torch.float32 if latents_dtype == torch.float32 else torch.float16
+        if eps_dtype not in (torch.float32, torch.float16) or (eps_dtype == torch.float32 and latents_dtype != torch.float32):
+            raise ValueError("eps_dtype must be torch.float16, or torch.float32 together with an fp32 solver state")
         self.latents_dtype = latents_dtype
+        self.eps_dtype = eps_dtype
         self.unet = unet
         self.vae = vae                  # HipAutoencoderKL for output_type="pt" (decode_latents, utils.py:6-34)
         self.decode_events = None       # optional list collecting (start, stop) events around the VAE decode
@@ -40,7 +48,7 @@ class SDSamplingEngine:
         self.forward_events = None      # optional list collecting (start, stop) events around UNet forwards
 
     def _buffers(self, B, shape, device):
-        key = (B, tuple(shape), str(device), self.latents_dtype)
+        key = (B, tuple(shape), str(device), self.latents_dtype, self.eps_dtype)
         if self._bufs is None or self._bufs["key"] != key:
             order = self.scheduler.config.order_dim
             C, H, W = shape
@@ -49,8 +57,8 @@ class SDSamplingEngine:
                 key=key,
                 lat=[torch.empty(B, C, H, W, dtype=self.latents_dtype, device=device) for _ in range(2)],
                 lat16=torch.empty(B, C, H, W, dtype=torch.float16, device=device) if self.latents_dtype != torch.float16 else None,
-                ring=[torch.empty(B, C, H, W, dtype=torch.float16, device=device) for _ in range(order)],
-                eps=torch.empty(2 * B, C, H, W, dtype=torch.float16, device=device))
+                ring=[torch.empty(B, C, H, W, dtype=self.eps_dtype, device=device) for _ in range(order)],
+                eps=torch.empty(2 * B, C, H, W, dtype=self.eps_dtype, device=device))
         return self._bufs
 
     def _loop(self, ctx, bufs, n, B, do_cfg):
@@ -62,7 +70,8 @@ class SDSamplingEngine:
             if self.forward_events is not None:
                 a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
                 a.record()
-            xin = x if bufs["lat16"] is None else bufs["lat16"].copy_(x)          # the denoiser's fp16 view of the fp32 solver state
+            # the denoiser's fp16 view of the fp32 solver state: one cast for the initial noise, afterwards written by the update kernel itself (step(out_lp=...))
+            xin = x if bufs["lat16"] is None else (bufs["lat16"].copy_(x) if i == 0 else bufs["lat16"])
             eps = unet(xin, t_dev[i:i + 1], encoder_hidden_states=ctx, dup=2 if do_cfg else 1, reuse_kv=(i > 0),
                        out=bufs["eps"] if do_cfg else bufs["eps"][:B])[0]
             if self.forward_events is not None:
@@ -71,12 +80,12 @@ class SDSamplingEngine:
             nxt = bufs["lat"][cur ^ 1]
             if do_cfg:
                 sch.step(eps[B:], sch.timesteps[i], x, return_dict=False, eps_uncond=eps[:B],
-                         guidance_scale=self.guidance_scale, eps_out=bufs["ring"][i % len(bufs["ring"])], out=nxt)
+                         guidance_scale=self.guidance_scale, eps_out=bufs["ring"][i % len(bufs["ring"])], out=nxt, out_lp=bufs["lat16"])
             else:
                 # the history keeps a reference to the model output: copy it out of the reused buffer
                 slot = bufs["ring"][i % len(bufs["ring"])]
                 slot.copy_(eps)
-                sch.step(slot, sch.timesteps[i], x, return_dict=False, out=nxt)
+                sch.step(slot, sch.timesteps[i], x, return_dict=False, out=nxt, out_lp=bufs["lat16"])
             x = nxt
             cur ^= 1
         return x

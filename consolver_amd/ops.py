@@ -333,3 +333,14 @@ def xattn_block(h, ln_gamma, ln_beta, wq, kv, wo, bo, heads=8, eps=1e-5, hw=None
 def set_tuning(key, value):
     """kernel-selection knob, e.g. set_tuning("conv_halo", 2) forces the halo-resident conv3x3 kernel."""
     L.check(L.lib().cs_set_tuning(key.encode(), int(value)))
+
+
+def get_tuning(key):
+    v = C.c_int(0)
+    L.check(L.lib().cs_get_tuning(key.encode(), C.byref(v)))
+    return v.value
+
+
+def reset_tuning():
+    """every kernel-selection knob back to its default"""
+    L.check(L.lib().cs_reset_tuning())

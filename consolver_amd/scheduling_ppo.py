@@ -56,8 +56,16 @@ class HistoryMixin:
         return probs3, actions, aprobs, idx
 
     def _masks(self, B, A, m, device):
-        masks = torch.empty(B, A, dtype=torch.float32, device=device)
-        L.check(L.lib().cs_step_masks(B, A, m, self.config.order_dim, L.ptr(masks), L.stream_ptr(device)))
+        """[B, A] 0 / 1 mask of the action dims a step with m history entries uses.  A function of (B, A, m, order) only: computed once per shape and device
+        (cs_step_masks) and handed out again -- callers treat step outputs as read-only (the rollout stacks them)."""
+        cache = self.__dict__.setdefault("_mask_cache", {})
+        key = (B, A, m, self.config.order_dim, str(device))
+        masks = cache.get(key)
+        if masks is None:
+            masks = torch.empty(B, A, dtype=torch.float32, device=device)
+            L.check(L.lib().cs_step_masks(B, A, m, self.config.order_dim, L.ptr(masks), L.stream_ptr(device)))
+            if not torch.cuda.is_current_stream_capturing():      # (a tensor created under capture belongs to the graph's pool)
+                cache[key] = masks
         return masks
 
     def _stack(self, B, elems, like):
@@ -69,7 +77,7 @@ class HistoryMixin:
                                          L.stream_ptr(like.device)))
         return out
 
-    def _fill_step_args(self, a, sample, eps_text, eps_uncond, guidance, actions, out, eps_out, out_dtype):
+    def _fill_step_args(self, a, sample, eps_text, eps_uncond, guidance, actions, out, eps_out, out_dtype, out_lp=None):
         B = sample.shape[0]
         hist = self.ets[::-1]  # newest first, hist[0] is the eps just pushed
         a.x, a.eps_text = sample.data_ptr(), eps_text.data_ptr()
@@ -86,6 +94,11 @@ class HistoryMixin:
         a.x_is_f32 = int(sample.dtype == torch.float32 and eps_text.dtype != torch.float32)
         a.x_out = out.data_ptr()
         a.eps_out = eps_out.data_ptr() if eps_out is not None else None
+        if out_lp is not None:
+            # the model-dtype copy of an fp32 prev_sample, written by the same kernel pass (CsStepArgs::x_out_lp): what the denoiser reads at the next step
+            if out_lp.dtype not in (torch.float16, torch.bfloat16) or out.dtype != torch.float32 or out_lp.shape != out.shape or not out_lp.is_contiguous():
+                raise ValueError("step(out_lp=...) is the contiguous fp16 / bf16 copy of an fp32 prev_sample of the same shape")
+            a.x_out_lp, a.lp_dtype = out_lp.data_ptr(), L.dtype_code(out_lp.dtype)
 
 
 class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
@@ -216,6 +229,20 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
             return torch.tensor([[t, prev_t]], dtype=dtype).to(torch.float32).to(device)
         return dev[i:i + 1]
 
+    def _cond_rows(self, t, cond_row, B, dtype):
+        """conds['x'] = the (t, prev_t) row in the model dtype, repeated for the batch (scheduler_ppo.py:207): a function of (t, B, dtype), cached per grid entry
+        like the masks (two tiny launches per step otherwise); read-only by convention"""
+        cache = self.__dict__.setdefault("_cond_rows_cache", {})
+        key = (int(t), B, dtype, str(cond_row.device), self.num_inference_steps)
+        rows = cache.get(key)
+        if rows is None:
+            rows = cond_row.to(dtype).repeat(B, 1)
+            if not torch.cuda.is_current_stream_capturing():
+                if len(cache) > 256:
+                    cache.clear()
+                cache[key] = rows
+        return rows
+
     def _ddim_scalars(self, t, prev_t):
         a_t = self._ac[t]
         a_p = self._ac[prev_t] if prev_t >= 0 else self._ac[0]
@@ -223,10 +250,11 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         return (float(np.sqrt(a_t)), float(np.sqrt(one - a_t)), float(np.sqrt(a_p)), float(np.sqrt(one - a_p)))
 
     def step(self, model_output, timestep, sample, return_dict=True, *, eps_uncond=None, guidance_scale=1.0,
-             eps_out=None, out=None):
+             eps_out=None, out=None, out_lp=None):
         """scheduler_ppo.py:178-299.  Extension (keyword-only): pass the two CFG branches as
         ``model_output`` (text) + ``eps_uncond`` and the combine u + g (c - u) is fused into the
-        update kernel; ``eps_out`` receives the combined eps (the history entry)."""
+        update kernel; ``eps_out`` receives the combined eps (the history entry); ``out_lp`` (with an fp32 sample) receives the
+        model-dtype rounding of ``prev_sample`` in the same kernel pass (the denoiser's input at the next step)."""
         if self.num_inference_steps is None:
             raise ValueError("Number of inference steps is 'None'. Call 'set_timesteps' first.")
         if self.config.prediction_type not in ("epsilon", "v_prediction"):
@@ -276,7 +304,7 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
         if prev.dtype != sample.dtype:
             raise ValueError(f"step(out=...) must have the sample's dtype {sample.dtype}, got {prev.dtype}")
         a = L.CsStepArgs()
-        self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, actions, prev, eps_out, sample.dtype)
+        self._fill_step_args(a, sample, model_output, eps_uncond, guidance_scale, actions, prev, eps_out, sample.dtype, out_lp)
         a.sqrt_at, a.sqrt_1mat, a.sqrt_ap, a.sqrt_1map = self._ddim_scalars(t, prev_t)
         a.v_prediction = int(self.config.prediction_type == "v_prediction")
         L.check(L.lib().cs_lms_ddim_step(C.byref(a), L.stream_ptr(dev)))
@@ -284,7 +312,7 @@ class PPOScheduler(HistoryMixin, SchedulerMixin, ConfigMixin):
                 and not torch.cuda.is_current_stream_capturing()):
             self.verify_timesteps()       # end of the trajectory: one device->host read, before the caller consumes the result
 
-        conds = {"x": cond_row.to(model_output.dtype).repeat(B, 1),
+        conds = {"x": self._cond_rows(t, cond_row, B, model_output.dtype),
                  "epsilon": self._stack(B, a.elems, current) if (self.record_conds or net.use_conv) else None}
         if self.verbose:
             print(f"T={t} -> {prev_t} | actions: {actions[0].tolist()} | Prob: {aprobs[0].tolist()}")

@@ -55,6 +55,7 @@ class HipUNet2DConditionModel:
         self._kv_batch = -1
         self._finalized = False
         self._t_buf = None
+        self._out_code = L.dtype_code(torch.float16)      # the handle's output dtype (cs_unet_set_output_dtype), switched on demand by __call__
         self.residual = "f16x2"                       # the library's default (CS_RESIDUAL_F16X2)
         if residual != "f16x2":
             self.set_residual_precision(residual)
@@ -149,8 +150,10 @@ class HipUNet2DConditionModel:
             out[name] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
         return out
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=False, dup=1, reuse_kv=None, out=None,
+    def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=False, dup=1, reuse_kv=None, out=None, out_dtype=None,
                  **_ignored):
+        """``out_dtype`` (or the dtype of ``out``): torch.float16 (default: the model dtype, what the reference's UNet returns) or torch.float32 -- conv_out stores its
+        fp32 accumulator unrounded (cs_unet_set_output_dtype): the native engine's choice."""
         if not self._finalized:
             raise RuntimeError("weights not loaded")
         L.require_cuda(sample, "sample")
@@ -183,8 +186,14 @@ class HipUNet2DConditionModel:
             if reuse_kv and not kv_valid:
                 raise RuntimeError("reuse_kv=True but no K/V cache exists for this batch size")
         if out is None:
-            out = torch.empty(B, self.config["out_channels"], sample.shape[2], sample.shape[3], dtype=torch.float16,
+            out = torch.empty(B, self.config["out_channels"], sample.shape[2], sample.shape[3], dtype=out_dtype or torch.float16,
                               device=sample.device)
+        if out.dtype not in (torch.float16, torch.float32) or not out.is_contiguous() or (out_dtype is not None and out.dtype != out_dtype):
+            raise ValueError("out must be a contiguous fp16 or fp32 tensor (of out_dtype when both are given)")
+        want = L.dtype_code(out.dtype)
+        if want != self._out_code:
+            L.check(L.lib().cs_unet_set_output_dtype(self._h, want))
+            self._out_code = want
         L.check(L.lib().cs_unet_forward(self._h, L.ptr(sample), n_lat, dup, L.ptr(t), t.numel(), L.ptr(ctx), L.ptr(out),
                                         L.ptr(ws), ws.numel(), int(kv_valid), L.stream_ptr(sample.device)))
         self._kv_ctx_ref, self._kv_ctx_version, self._kv_batch = encoder_hidden_states, ctx._version, B

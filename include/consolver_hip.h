@@ -140,6 +140,10 @@ typedef struct CsStepArgs {
     /* nonzero: x is fp32 while eps_* / hist stay io_dtype (scheduler_fmppo.py:354 upcasts the sample
        before the update and rounds only the result); ABI version 2 */
     int x_is_f32;
+    /* optional (may be NULL): a second, 16-bit copy of an fp32 result (out_dtype = CS_F32), [B, elems] in lp_dtype (CS_F16 | CS_BF16) -- the view of an fp32 solver
+       state that the denoiser reads at the next step, written in the same pass instead of by a cast kernel per step; ABI version 3 */
+    void* x_out_lp;
+    int lp_dtype;
 } CsStepArgs;
 
 int cs_lms_ddim_step(const CsStepArgs* args, void* stream);
@@ -206,9 +210,14 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
 #define CS_RESIDUAL_F16   0
 #define CS_RESIDUAL_F16X2 1
 int cs_unet_set_residual_precision(CsUNet* u, int mode);
-/* Kernel-selection knobs for THIS handle (keys and ranges: cs_set_tuning in consolver_hip_ops.h): cs_unet_forward applies them for the duration of its host call and
- * restores the process-wide values afterwards, under the lock cs_set_tuning takes -- two handles in one process can run different knob sets (their forwards'
- * host calls serialize; the GPU work does not).  The workspace size does not depend on them (cs_unet_workspace_bytes covers every variant).  Unknown keys and
+/* dtype of cs_unet_forward's `out` tensor: CS_F16 (default: the model dtype, what the reference's `unet(...)[0]` returns, denoise_ppo.py:89-94) or CS_F32: conv_out
+ * stores its fp32 accumulator unrounded.  The native engine asks for CS_F32: an fp16 eps tensor carries 2.8e-4 of relative rounding, and the CFG combine
+ * u + g (c - u) of two such tensors (rounded again as the history entry) more -- both gone from the 1e-3 latent budget for 128 KiB per image and step. */
+int cs_unet_set_output_dtype(CsUNet* u, int dtype);
+int cs_unet_get_output_dtype(const CsUNet* u);
+/* Kernel-selection knobs for THIS handle (keys and ranges: cs_set_tuning in consolver_hip_ops.h): cs_unet_forward runs with the process-wide values overridden by the
+ * handle's entries for the duration of its host call -- a per-thread knob set, the process-wide one is not written -- so two handles in one process can run
+ * different knob sets concurrently.  The workspace size does not depend on them (cs_unet_workspace_bytes covers every variant).  Unknown keys and
  * out-of-range values are rejected.  cs_unet_clear_tuning drops the handle's overrides. */
 int cs_unet_set_tuning(CsUNet* u, const char* key, int value);
 int cs_unet_clear_tuning(CsUNet* u);

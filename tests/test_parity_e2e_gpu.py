@@ -193,13 +193,13 @@ def _oracle_sched(w):
 
 
 def _hip_trajectory(unet, sch, idx, noise, ctx_d, B, n, g):
-    """the product's loop, step by step as SDSamplingEngine runs it (fp32 solver state, the denoiser reads its fp16 copy; per-step latents kept for the drift table)"""
+    """the product's loop, step by step as SDSamplingEngine runs it (fp32 solver state and fp32 eps, the denoiser reads the state's fp16 copy; per-step latents kept for the drift table)"""
     sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
     sch.set_timesteps(n, device=DEV)
     x = noise.to(DEV).float()
     traj = []
     for i, t in enumerate(sch.timesteps):
-        eps = unet(x.half(), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0))[0]
+        eps = unet(x.half(), t, encoder_hidden_states=ctx_d, dup=2, reuse_kv=(i > 0), out_dtype=torch.float32)[0]      # (round 6: the engine takes the denoiser's output in fp32)
         x = sch.step(eps[B:], t, x, return_dict=False, eps_uncond=eps[:B], guidance_scale=g)[0]
         assert x.dtype == torch.float32
         traj.append(x.float().cpu().numpy())

@@ -215,6 +215,104 @@ def test_xattn_block_x2_residual_is_fp32_class():
     assert hi_is_rounding(oh, ol)
 
 
+# ---- 8-bit lo planes (round 6): value = hi (fp16) + lo8 (e5m2), 14 significant bits -----------------------------------------------------------------
+LO8_TOL = 3e-5      # hi + lo8 of a unit-scale tensor: ~1.5e-5 rms (fp16 alone: 2.4e-4; hi + fp16 lo: 1e-7)
+
+
+def test_lo8_representation_and_hardware_format():
+    """(a) hi + lo8 is a 14-bit representation; (b) the hardware's e5m2 conversion (v_cvt_pk_bf8_f32, round to nearest even) writes the bytes torch.float8_e5m2
+    holds: a linear layer whose fp32 result is EXACT (operands on a 2^-8 / 2^-6 grid) must leave exactly torch's (fp16, e5m2) split of that result."""
+    x = rnd(1 << 16, seed=1, scale=3.0, dtype=torch.float32)
+    hi, lo8 = ops.lo8_split(x)
+    e = rel_l2(ops.lo8_value(hi, lo8), x)
+    assert 3e-6 < e < LO8_TOL, e
+    g = torch.Generator().manual_seed(2)
+    M, K, N = 512, 64, 320
+    xi = (torch.randint(-1024, 1025, (M, K), generator=g).float() / 256).half().to(DEV)
+    wi = (torch.randint(-128, 129, (N, K), generator=g).float() / 64).half().to(DEV)
+    ref = xi.float() @ wi.float().t()                                  # multiples of 2^-14 below 2^9: exact in fp32 in any summation order
+    assert torch.equal(ref, (xi.double() @ wi.double().t()).float())
+    oh, ol8 = ops.linear_lo8(xi, wi)
+    wh, wl8 = ops.lo8_split(ref)
+    assert torch.equal(oh, wh)
+    assert torch.equal(ol8, wl8), float((ol8 != wl8).float().mean())
+    assert float((wl8 != 0).float().mean()) > 0.5                      # (the lo plane is exercised: most results do not fit fp16)
+
+
+@pytest.mark.parametrize("case", [c for c in LINEAR_CASES if c[4]] + [(8192, 320, 320, True, False, False)])
+def test_linear_lo8(case):
+    """every linear kernel family with 8-bit lo planes: residual hi + lo8 in, hi + lo8 out (to_out), hi only out (the feed-forward's second linear: FAST 4), no
+    residual (proj_in).  The reference adds the residual's REPRESENTED value, so the tolerance sees the output's 14-bit storage only."""
+    M, K, N, use_b, use_r, _ = case
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3, scale=0.1) if use_b else None
+    ref = x.float() @ w.float().t()
+    if use_b:
+        ref = ref + b.float()
+    rh = rl8 = None
+    if use_r:
+        rh, rl8 = ops.lo8_split(rnd(M, N, seed=4, scale=2.0, dtype=torch.float32))
+        ref = ref + ops.lo8_value(rh, rl8)
+    oh, ol8 = ops.linear_lo8(x, w, b, res=rh, res_lo8=rl8)
+    e = rel_l2(ops.lo8_value(oh, ol8), ref)
+    assert e < LO8_TOL, (case, e)
+    assert float((oh != ops.lo8_value(oh, ol8).half()).float().mean()) < 2e-3      # hi is the fp16 rounding of the represented value: the plane a GEMM may read alone
+    if use_r:
+        o1, none = ops.linear_lo8(x, w, b, res=rh, res_lo8=rl8, want_lo=False)
+        assert none is None and torch.equal(o1, oh)                     # the hi-only form stores the same fp16 rounding of the same fp32 sum
+        # the 8-bit residual plane is really read: dropping it is visible
+        o2, l2 = ops.linear_lo8(x, w, b, res=rh, res_lo8=None)
+        assert rel_l2(ops.lo8_value(o2, l2), ref) > 3 * LO8_TOL
+        # the generic (load-where-added) epilogue agrees bit for bit with the FAST forms
+        ops.set_tuning("epi_fast", 0)
+        try:
+            g1, g2 = ops.linear_lo8(x, w, b, res=rh, res_lo8=rl8)
+            g3, _ = ops.linear_lo8(x, w, b, res=rh, res_lo8=rl8, want_lo=False)
+        finally:
+            ops.set_tuning("epi_fast", 3)
+        assert torch.equal(g1, oh) and torch.equal(g2, ol8) and torch.equal(g3, oh)
+
+
+def test_linear_x2_hi_only_fast_form_is_bit_identical():
+    """FAST 4 (round 6): residual + its fp16 lo plane, no lo plane out -- what the feed-forward's second linear runs in the split mode -- against the generic epilogue"""
+    for (M, K, N) in ((8192, 1280, 320), (4096, 2560, 640), (2048, 5120, 1280)):
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+        rh, rl = ops.split_f16(rnd(M, N, seed=4, scale=2.0, dtype=torch.float32))
+        a, _ = ops.linear_x2(x, w, b, res=rh, res_lo=rl, want_lo=False)
+        ops.set_tuning("epi_fast", 1)
+        try:
+            c, _ = ops.linear_x2(x, w, b, res=rh, res_lo=rl, want_lo=False)
+        finally:
+            ops.set_tuning("epi_fast", 3)
+        assert torch.equal(a, c), (M, K, N)
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+def test_xattn_block_lo8(tile):
+    B, HW, C, Nk = 2, 1024, 320, 77
+    M = B * HW
+    hh, hl8 = ops.lo8_split(rnd(M, C, seed=1, scale=4.0, dtype=torch.float32))
+    h = ops.lo8_value(hh, hl8)
+    g, b = (1.0 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
+    wq, wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, C, seed=5, scale=C ** -0.5), rnd(C, seed=6, scale=0.1)
+    kv = rnd(B, Nk, 2 * C, seed=7)
+    ops.set_tuning("xattn_tile", tile)
+    try:
+        oh, ol8, rs = ops.xattn_block_lo8(hh, hl8, g, b, wq, kv, wo, bo, hw=HW, row_stats=True)
+        plain = ops.xattn_block(hh, g, b, wq, kv, wo, bo, hw=HW)
+    finally:
+        ops.set_tuning("xattn_tile", 64)
+    got = ops.lo8_value(oh, ol8)
+    delta = plain.float() - hh.float()                        # the branch's contribution as the plain kernel computes it (fp16 class)
+    assert rel_l2(got - h, delta) < 3e-3
+    assert rel_l2(got, h + delta) < 1.5e-4
+    assert float((oh != got.half()).float().mean()) < 2e-3
+    # the row statistics (norm3 folded into the GEGLU GEMM) are those of the fp32 values the planes were rounded from
+    want = torch.stack([got.sum(1), (got * got).sum(1)], 1)
+    assert rel_l2(rs.reshape(M, 2), want) < 1e-4
+    assert rel_l2(ops.row_stats_lo8(oh, ol8).reshape(M, 2), want) < 1e-5
+
+
 def _small_unet(residual):
     cfg = dict(layers_per_block=1, sample_size=16)
     return get_unet(cfg, seed=3, residual=residual)
@@ -243,6 +341,34 @@ def test_unet_x2_mode_is_closer_to_the_fp32_oracle_and_api_round_trips():
     c = u16(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].clone()
     assert torch.equal(a, c) and not torch.equal(a, b)
     assert torch.equal(b, ux2(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0])
+
+
+def test_unet_lo8_hidden_state_matches_the_fp16_lo_plane():
+    """knob lo8: the transformer blocks' hidden state with an 8-bit lo plane (default) against an fp16 one -- 14 vs 22 bits on tensors whose storage error is two
+    orders below the branch tensors' fp16 roundings: the eps outputs agree far inside the per-forward error, and both sit at the same distance from the oracle"""
+    cfg = dict(layers_per_block=1, sample_size=32)
+    u, _ = get_unet(cfg, seed=3, residual="f16x2")
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(1)).half()
+    ctx = torch.cat([synthetic_prompt_embeds(2, seed=5), synthetic_prompt_embeds(2, seed=6)]).half()
+    want = get_oracle(cfg, seed=3)(torch.cat([lat.float()] * 2), 499, ctx.float())
+    run = lambda: u(lat.to(DEV), 499, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].float().cpu()
+    a = run()
+    outs = {}
+    for knobs in (dict(lo8=0), dict(lo8=1, cfg_share=0), dict(lo8=1, xattn_fused=0), dict(lo8=1, ln_fold=0), dict(lo8=1, x2_split_a=3)):
+        for k, v in knobs.items():
+            ops.set_tuning(k, v)
+        try:
+            outs[tuple(knobs.items())] = run()
+        finally:
+            ops.reset_tuning()
+    b = outs[(("lo8", 0),)]
+    ea, eb = rel_l2(a, want), rel_l2(b, want)
+    print(f"\nreduced UNet (32 x 32) eps error vs the fp32 oracle: lo8 hidden state {ea:.4e}, fp16 lo plane {eb:.4e}; the two outputs differ by {rel_l2(a, b):.2e}")
+    assert rel_l2(a, b) < 2e-4 and abs(ea - eb) < 0.03 * eb
+    assert torch.equal(outs[(("lo8", 1), ("cfg_share", 0))], a)                       # the shared CFG prefix stays bit-identical with byte planes
+    assert rel_l2(outs[(("lo8", 1), ("xattn_fused", 0))], a) < 1.5e-3                 # unfused cross-attention: igemm epilogues carry the byte planes
+    for k in ((("lo8", 1), ("ln_fold", 0)), (("lo8", 1), ("x2_split_a", 3))):       # consumers that need an fp16 lo plane switch the byte planes off by themselves
+        assert rel_l2(outs[k], a) < 1.5e-3 and torch.isfinite(outs[k]).all()
 
 
 @pytest.mark.parametrize("knobs", [dict(cfg_share=0), dict(xattn_fused=0), dict(gn_fuse=0), dict(cfg_share=0, xattn_fused=0)])

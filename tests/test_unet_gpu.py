@@ -233,6 +233,55 @@ def test_forward_does_not_read_uninitialised_workspace(residual):
                 assert torch.isfinite(b.float()).all() and torch.equal(a, b), (S, dup, fill)
 
 
+def test_fp32_output_is_the_unrounded_fp16_output_and_threads_keep_their_knob_sets():
+    """(a) cs_unet_set_output_dtype (round 6): the fp32 eps is the conv_out accumulator the fp16 eps is rounded from -- rounding it gives the fp16 output bit for bit,
+    on both conv_out kernels and on the one-wave-per-pixel fallback; the handle switches back and forth.  (b) per-handle knobs are a per-THREAD set (ops.h, TuneSet): a
+    thread running a handle with overrides does not change what another thread's forwards on a plain handle see."""
+    import threading
+    from consolver_amd import ops
+    for S in (32, 8):                                                   # 16 x 16 patch kernels / the fallback kernel
+        cfg = dict(layers_per_block=1, sample_size=S)
+        u, _ = get_unet(cfg, seed=3)
+        lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(2)).half().to(DEV)
+        ctx = synthetic_prompt_embeds(4, seed=31).half().to(DEV)
+        for mfma in (1, 0):
+            ops.set_tuning("conv_out_mfma", mfma)
+            try:
+                y16 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+                y32 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False, out_dtype=torch.float32)[0].clone()
+                again = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0]
+            finally:
+                ops.set_tuning("conv_out_mfma", 1)
+            assert y16.dtype == torch.float16 and y32.dtype == torch.float32 and torch.equal(y32.half(), y16) and torch.equal(again, y16)
+            assert float((y32 - y16.float()).abs().max()) > 0             # (the fp32 tensor does carry the bits the fp16 one drops)
+    with pytest.raises(ValueError):
+        u(lat, 499, encoder_hidden_states=ctx, dup=2, out=torch.empty(4, 4, 8, 8, device=DEV, dtype=torch.bfloat16))
+    # ---- (b)
+    cfg = dict(layers_per_block=1, sample_size=32)
+    a, sd = get_unet(cfg, seed=3)
+    b = HipUNet2DConditionModel(cfg, device=DEV)
+    b.load_state_dict(sd)
+    b.set_tuning("xattn_fused", 0).set_tuning("ln_fold", 0)
+    lat = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(2)).half().to(DEV)
+    ctx = synthetic_prompt_embeds(4, seed=31).half().to(DEV)
+    run = lambda m: m(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+    base, alt = run(a), run(b)
+    assert not torch.equal(base, alt)
+    bad = []
+
+    def worker(m, want, n):
+        torch.cuda.set_device(0)
+        for _ in range(n):
+            if not torch.equal(run(m), want):
+                bad.append(m is b)
+    ts = [threading.Thread(target=worker, args=(a, base, 12)), threading.Thread(target=worker, args=(b, alt, 12))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad
+
+
 def test_two_handles_run_different_knob_sets_in_one_process():
     """cs_unet_set_tuning (round 5): kernel-selection knobs per HANDLE.  Two models of the same weights, one with the fused cross-attention block and the folded LayerNorm
     switched off for itself: each reproduces, bit for bit, what the process-wide knobs give when set to its values -- in either call order, with the process-wide state
