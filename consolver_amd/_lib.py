@@ -126,6 +126,10 @@ SYMBOLS = {
                                   C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "cs_unet_set_residual_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_unet_get_residual_precision": (C.c_int, [C.c_void_p]),
+    "cs_unet_calibrate_ln_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_float, C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_float)]),
+    "cs_unet_set_ln_unfold_mask": (C.c_int, [C.c_void_p, C.c_uint]),
+    "cs_unet_get_ln_unfold_mask": (C.c_uint, [C.c_void_p]),
     "cs_unet_set_output_dtype": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_unet_get_output_dtype": (C.c_int, [C.c_void_p]),
     "cs_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -247,15 +247,21 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
     const long MS = f->mod_total;
 
     // ---- embedders ---------------------------------------------------------------------------------------------
-    if (I2 > 0)
-        Rn.gemm_pair(FRun::gargs(f->x_emb, hidden, c.in_channels, B * I1, img, D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I1, I, 0),
-                     FRun::gargs(f->x_emb, hidden2, c.in_channels, B * I2, img, D, 0, 0, nullptr, nullptr, 0, 0, 0, 0, 0, I2, I, I1));
-    else
-        Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D);
-    Rn.gemm(f->c_emb, enc, c.joint_attention_dim, B * T, ctx, D);
+    // split stream (round 6): the embedders' outputs ARE the initial hidden states -- rounding them to one plane of the model dtype put 2^-9 of relative error on the
+    // whole stream before the first block.  They run the gated-residual epilogue's split form onto zeroed planes (no gate: hi + lo = the fp32 product + bias).
+    const void* ires = nullptr; const void* cres = nullptr;
     if (split && !dry && Rn.rc == CS_OK) {
+        hipok(hipMemsetAsync(img, 0, (size_t)B * I * D * e, s), "memset img"); hipok(hipMemsetAsync(ctx, 0, (size_t)B * T * D * e, s), "memset ctx");
         hipok(hipMemsetAsync(img_lo, 0, (size_t)B * I * D * e, s), "memset img_lo"); hipok(hipMemsetAsync(ctx_lo, 0, (size_t)B * T * D * e, s), "memset ctx_lo");
     }
+    if (split) { ires = img; cres = ctx; }
+    void* const ilo = split ? (void*)img_lo : nullptr; void* const clo = split ? (void*)ctx_lo : nullptr;
+    if (I2 > 0)
+        Rn.gemm_pair(FRun::with_lo(FRun::gargs(f->x_emb, hidden, c.in_channels, B * I1, img, D, 0, 0, ires, nullptr, 0, 0, 0, 0, 0, I1, I, 0), ilo),
+                     FRun::with_lo(FRun::gargs(f->x_emb, hidden2, c.in_channels, B * I2, img, D, 0, 0, ires, nullptr, 0, 0, 0, 0, 0, I2, I, I1), ilo));
+    else
+        Rn.gemm(f->x_emb, hidden, c.in_channels, B * I, img, D, 0, 0, ires, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, ilo);
+    Rn.gemm(f->c_emb, enc, c.joint_attention_dim, B * T, ctx, D, 0, 0, cres, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, clo);
 
     // ---- double-stream blocks -----------------------------------------------------------------------------------
     for (auto& k : f->dbl) {

@@ -2345,6 +2345,31 @@ int launch_igemm(const IgemmArgs& a, hipStream_t s) {
     return launch_gn_stats64(a.out, a.B, a.Ho * a.Wo, a.N, a.gn_stats, s);
 }
 
+// cs_unet_calibrate_ln_fold: *dst += sum over rows of mean^2 / (var + eps) from the row statistics rs[M][G][2] a producer left (IgemmArgs::row_stats) -- how many sigma
+// the rows of a hidden state sit away from zero.  A threshold decision: the order of the float atomics does not matter.
+__global__ __launch_bounds__(256) void ln_dc_ratio_kernel(const float* __restrict__ rs, int M, int G, float inv_c, float eps, float* __restrict__ dst) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < M; m += gridDim.x * 256) {
+        float s1, s2;
+        ln_row_moments(rs + (size_t)m * G * 2, G, s1, s2);
+        const float mean = s1 * inv_c, var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+        acc += mean * mean / (var + eps);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+}
+
+int launch_ln_dc_ratio(const float* rs, int M, int G, int C, float eps, float* dst, hipStream_t s) {
+    if (!rs || !dst || M <= 0 || G < 1 || C <= 0) CS_FAIL(CS_E_ARG, "ln_dc_ratio: bad arguments");
+    int blocks = (M + 255) / 256; if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(ln_dc_ratio_kernel, dim3(blocks), dim3(256), 0, s, rs, M, G, 1.0f / (float)C, eps, dst);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
 int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s, int lo8) {
     if (!x || !stats || C % 8) CS_FAIL(CS_E_ARG, "row_stats: x, stats required; C %% 8 == 0");
     if (M <= 0) return M < 0 ? CS_E_SHAPE : CS_OK;

@@ -102,6 +102,8 @@ double igemm_flops(const IgemmArgs& a);
 void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out);
 // (sum, sum of squares) per row of x [M][C] (+ x_lo): stats[M][1][2]; the statistics pass behind IgemmArgs::row_stats and after the fused cross-attention block
 int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s, int lo8 = 0);
+// *dst += sum over the M rows of mean^2 / (var + eps), rows described by their statistics rs[M][G][2] over C channels (cs_unet_calibrate_ln_fold)
+int launch_ln_dc_ratio(const float* rs, int M, int G, int C, float eps, float* dst, hipStream_t s);
 
 struct AttnArgs {
     const f16* q; int q_stride;   // [B, Nq, H*dh] rows of q_stride halfs

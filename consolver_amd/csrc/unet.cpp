@@ -56,6 +56,7 @@ struct Xformer {
     f16 *wq2 = nullptr, *wkv2 = nullptr, *wo2 = nullptr, *bo2 = nullptr;
     f16 *wff1 = nullptr, *bff1 = nullptr, *wff2 = nullptr, *bff2 = nullptr;
     int c = 0; size_t kv_off = 0;   // offset (halfs, per batch row of 1 sample... scaled at run time) into the KV cache
+    int index = 0;                  // position among the transformer blocks in creation order (cs_unet_calibrate_ln_fold: bit of ln_unfold_mask, slot of the calibration buffer)
 };
 
 // first-fit allocator over the caller's workspace (host bookkeeping only; deterministic, so the
@@ -125,7 +126,11 @@ struct CsUNet {
     Conv down_samp[4], up_samp[4]; bool has_down[4] = {}, has_up[4] = {};
     Resnet mid_res[2]; Xformer mid_att;
     size_t kv_halfs_per_token = 0;
-    int n_shortcuts = 0;
+    int n_shortcuts = 0, n_xformers = 0;
+    // cs_unet_calibrate_ln_fold: transformer blocks (bit = Xformer::index) whose LayerNorms run UNFOLDED (ln_kernel on hi + lo, plain GEMMs) although ln_fold is on: their
+    // hidden states carry a DC offset of several sigma, where the folded form -- rstd (h_fp16 W' - mean s) -- cancels in fp16-rounded operands
+    unsigned ln_unfold_mask = 0;
+    float* calib = nullptr;             // device [3 * n_xformers] sums over rows of mean^2 / var (written only during a calibration forward)
     // run state
     Arena arena;
     bool profiling = false;
@@ -318,6 +323,7 @@ bool make_xformer(CsUNet* u, const std::string& p, Xformer& x) {
     ok = ok && make_ln_linear(u, pw, pb, T(u, t + ".norm3.weight"), T(u, t + ".norm3.bias"), (int)(8 * C), (int)C, x.f_ff1);      // (row-wise: commutes with the GEGLU row permutation)
     x.wff2 = upload(u, T(u, t + ".ff.net.2.weight").data); x.bff2 = upload(u, T(u, t + ".ff.net.2.bias").data);
     x.kv_off = u->kv_halfs_per_token; u->kv_halfs_per_token += 2 * (size_t)x.c;
+    x.index = u->n_xformers++;
     return ok && x.wqkv && x.wo1 && x.bo1 && x.wq2 && x.wkv2 && x.wo2 && x.bo2 && x.wff1 && x.bff1 && x.wff2 && x.bff2;
 }
 
@@ -338,8 +344,15 @@ struct Run {
     int v_sc_skip = 0;             // snapshot of tune().x2_sc_skip
     // the transformer hidden state's lo plane as bytes: only where every consumer of that plane adds it (folded LayerNorms: ln_kernel reads an fp16 lo plane;
     // proj_out not reading hi + lo as its operand)
-    bool h_lo8() const { return split && v_lo8 != 0 && v_ln_fold != 0 && !(v_split_a & 2); }
-    St salloc_h(size_t elems) { St t; t.hi = alloc(elems); t.lo8 = h_lo8(); t.lo = split ? alloc(t.lo8 ? (elems + 1) / 2 : elems) : nullptr; return t; }
+    bool fold_of(const Xformer& X) const { return v_ln_fold != 0 && !((u->ln_unfold_mask >> X.index) & 1u); }
+    bool h_lo8(bool fold) const { return split && v_lo8 != 0 && fold && !(v_split_a & 2); }
+    St salloc_h(size_t elems, bool fold) { St t; t.hi = alloc(elems); t.lo8 = h_lo8(fold); t.lo = split ? alloc(t.lo8 ? (elems + 1) / 2 : elems) : nullptr; return t; }
+    float* calib = nullptr;        // calibration forward: per (block, LayerNorm) sums of mean^2 / var over the rows of the hidden state in front of that LayerNorm
+    void calib_point(const Xformer& X, int which, const float* rs, int M, int G, int C, float eps) {
+        if (!calib || !rs) return;
+        float* dst = calib + 3 * X.index + which;
+        launch(P_MISC, 0, 0, [&] { return launch_ln_dc_ratio(rs, M, G, C, eps, dst, s); });
+    }
     bool count_executed = false;   // dry run behind cs_unet_flops_executed: count what is ISSUED (padding included), not the reference graph's FLOPs
     // row statistics [M][<= C / 64 groups][2] floats a producer leaves for a folded LayerNorm (IgemmArgs::row_stats)
     float* alloc_rowstats(int M, int C) { return (float*)alloc((size_t)M * (C / 64) * 2 * 2); }
@@ -494,11 +507,12 @@ struct Run {
         const int C = X.c, HW = H * W, L = u->cfg.ctx_len; const int M = B * HW;
         f16* g = alloc((size_t)M * C);
         group_norm(X.gn, x, C, St(), 0, HW, false, g);
-        St h = salloc_h((size_t)M * C);
         // folded LayerNorms: every layer that writes the hidden state leaves its row statistics in rs (G column groups), the next LayerNorm's consumer reads them
-        const bool fold = v_ln_fold != 0;
+        const bool fold = fold_of(X);
+        St h = salloc_h((size_t)M * C, fold);
         float* rs = fold ? alloc_rowstats(M, C) : nullptr; int G = 1;
         conv(X.proj_in, g, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h, false, nullptr, nullptr, nullptr, rs, &G);
+        calib_point(X, 0, rs, M, G, C, X.ln1.eps);
         // self attention
         f16* qkv = alloc((size_t)M * 3 * C);
         if (fold) linear_ln(h.hi, M, C, X.f_qkv, rs, G, X.ln1.eps, 3 * C, qkv, 0);
@@ -511,6 +525,7 @@ struct Run {
         if (xattn_fusable(X, HW)) {
             xattn_fused(X, h, h, kvl, HW, rs); G = 1;        // (its own norm2 stays inside the kernel; it leaves the statistics norm3's consumer needs)
         } else {
+            calib_point(X, 1, rs, M, G, C, X.ln2.eps);
             f16* q = alloc((size_t)M * C);
             if (fold) linear_ln(h.hi, M, C, X.f_q2, rs, G, X.ln2.eps, C, q, 0);
             else { layer_norm(X.ln2, h, M, g); linear(g, M, C, X.wq2, nullptr, C, St(), St(q), 0); }
@@ -519,6 +534,7 @@ struct Run {
             linear(g, M, C, X.wo2, X.bo2, C, h, h, 0, rs, &G);
         }
         // feed forward (GEGLU fused into the first GEMM's epilogue)
+        calib_point(X, 2, rs, M, G, C, X.ln3.eps);
         f16* ff = alloc((size_t)M * 4 * C);
         if (fold) linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
         else { layer_norm(X.ln3, h, M, g); linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
@@ -558,10 +574,11 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     R.B = n_lat;
     f16* g1 = R.alloc((size_t)M1 * C);
     R.group_norm(X.gn, x_half, C, St(), 0, HW, false, g1);
-    St h1 = R.salloc_h((size_t)M1 * C);
-    const bool fold = R.v_ln_fold != 0;
+    const bool fold = R.fold_of(X);
+    St h1 = R.salloc_h((size_t)M1 * C, fold);
     float* rs = fold ? R.alloc_rowstats(M, C) : nullptr; int G = 1;          // (sized for the full batch: the halves' statistics land side by side later)
     R.conv(X.proj_in, g1, C, nullptr, 0, H, W, H, W, 1, 0, nullptr, St(), h1, false, nullptr, nullptr, nullptr, rs, &G);
+    R.calib_point(X, 0, rs, M1, G, C, X.ln1.eps);
     f16* qkv = R.alloc((size_t)M1 * 3 * C);
     if (fold) R.linear_ln(h1.hi, M1, C, X.f_qkv, rs, G, X.ln1.eps, 3 * C, qkv, 0);
     else { R.layer_norm(X.ln1, h1, M1, g1); R.linear(g1, M1, C, X.wqkv, nullptr, 3 * C, St(), St(qkv), 0); }
@@ -573,7 +590,7 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
     if (R.xattn_fusable(X, HW)) {
         // the fused sub-block reads the shared residual stream and writes each half's own copy: no duplication copy, LN2 / to_q run per half
         R.release(g1);
-        h = R.salloc_h((size_t)M * C);
+        h = R.salloc_h((size_t)M * C, fold);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half)
             R.xattn_fused(X, h1, h.at((size_t)half * M1 * C), kvl + (size_t)half * n_lat * L * 2 * C, HW, rs ? rs + (size_t)half * M1 * 2 : nullptr);
@@ -581,12 +598,13 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         R.srelease(h1);
         R.B = Bfull;
     } else {
+        R.calib_point(X, 1, rs, M1, G, C, X.ln2.eps);
         f16* q = R.alloc((size_t)M1 * C);
         if (fold) R.linear_ln(h1.hi, M1, C, X.f_q2, rs, G, X.ln2.eps, C, q, 0);
         else { R.layer_norm(X.ln2, h1, M1, g1); R.linear(g1, M1, C, X.wq2, nullptr, C, St(), St(q), 0); }
         R.release(g1);
         // ---- the halves diverge: cross attention against each half's own K/V, residual stream duplicated ----
-        h = R.salloc_h((size_t)M * C);
+        h = R.salloc_h((size_t)M * C, fold);
         g = R.alloc((size_t)M * C);
         for (int half = 0; half < 2; ++half) {
             if (!R.dry && R.rc == CS_OK) {
@@ -600,6 +618,7 @@ St Run_xformer_cfg_shared(Run& R, const Xformer& X, St x_half, int H, int W, int
         R.B = Bfull;
         R.linear(g, M, C, X.wo2, X.bo2, C, h, h, 0, rs, &G);
     }
+    R.calib_point(X, 2, rs, M, G, C, X.ln3.eps);
     f16* ff = R.alloc((size_t)M * 4 * C);
     if (fold) R.linear_ln(h.hi, M, C, X.f_ff1, rs, G, X.ln3.eps, 8 * C, ff, 1);
     else { R.layer_norm(X.ln3, h, M, g); R.linear(g, M, C, X.wff1, X.bff1, 8 * C, St(), St(ff), 1); }
@@ -623,7 +642,7 @@ struct Variant { int gn_fuse, xattn_fused, cfg_share, ln_fold, conv_in_mfma, lo8
 static Variant current_variant() { return Variant{tune().gn_fuse, tune().xattn_fused, tune().cfg_share, tune().ln_fold, tune().conv_in_mfma, tune().lo8}; }
 
 int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, const float* t, int nt, const f16* ctx, f16* out,
-                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant(), bool count_executed = false) {
+                char* ws, size_t ws_bytes, int kv_valid, hipStream_t s, Variant var = current_variant(), bool count_executed = false, float* calib = nullptr) {
     const CsUNetConfig& c = u->cfg;
     const int B = n_lat * dup;
     const size_t kvb = kv_cache_bytes(u, B), gnb = gn_ws_bytes(u, B) + sk_ws_bytes(u, B);
@@ -633,7 +652,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = tune().x2_split_a; R.count_executed = count_executed;
-    R.v_lo8 = var.lo8; R.v_sc_skip = tune().x2_sc_skip;
+    R.v_lo8 = var.lo8; R.v_sc_skip = tune().x2_sc_skip; R.calib = dry ? nullptr : calib;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -918,6 +937,64 @@ int cs_unet_forward(CsUNet* u, const void* latents, int n_lat, int dup, const fl
     }
     return rc;
 }
+
+int cs_unet_calibrate_ln_fold(CsUNet* u, const void* latents, int n_lat, int dup, const float* timesteps, int n_timesteps, const void* ctx, void* out,
+                              void* workspace, size_t workspace_bytes, float bound, void* stream, unsigned* mask_out, float* worst_ratio_out) {
+    if (!u) CS_FAIL(CS_E_ARG, "unet is NULL");
+    if (!u->finalized) CS_FAIL(CS_E_STATE, "cs_unet_finalize has not been called");
+    if (n_lat <= 0 || (dup != 1 && dup != 2) || !latents || !timesteps || !ctx || !out || !workspace) CS_FAIL(CS_E_ARG, "calibrate_ln_fold: bad arguments");
+    if (n_timesteps != 1 && n_timesteps != n_lat * dup) CS_FAIL(CS_E_SHAPE, "n_timesteps must be 1 or the batch size");
+    if (!(bound > 0.f)) CS_FAIL(CS_E_ARG, "calibrate_ln_fold: bound must be positive");
+    const int nslots = 3 * u->n_xformers;
+    if (u->n_xformers > 32) CS_FAIL(CS_E_UNSUPPORTED, "calibrate_ln_fold: more than 32 transformer blocks");
+    if (nslots == 0) { if (mask_out) *mask_out = 0; if (worst_ratio_out) *worst_ratio_out = 0.f; return CS_OK; }
+    if (!u->calib) {
+        void* d = nullptr;
+        CS_CHECK_HIP(hipMalloc(&d, nslots * sizeof(float)));
+        u->dev_allocs.push_back(d); u->calib = (float*)d;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // measured on the FOLDED graph (every producer of the hidden state leaves its row statistics): the mask is cleared for the calibration forward
+    const unsigned keep = u->ln_unfold_mask;
+    u->ln_unfold_mask = 0;
+    CS_CHECK_HIP(hipMemsetAsync(u->calib, 0, nslots * sizeof(float), s));
+    u->ev_used = 0;
+    TuneSet mine = g_tune;
+    for (auto& kv : u->tune) tune_apply(mine, kv.first.c_str(), kv.second);
+    mine.ln_fold = 1; mine.cfg_share = 0;        // (every row of the batch through every statistics point)
+    int rc;
+    {
+        TuneScope scope(&mine);
+        rc = run_forward(u, false, (const f16*)latents, n_lat, dup, timesteps, n_timesteps, (const f16*)ctx, (f16*)out, (char*)workspace, workspace_bytes, 0, s,
+                         current_variant(), false, u->calib);
+    }
+    if (rc != CS_OK) { u->ln_unfold_mask = keep; return rc; }
+    std::vector<float> host(nslots);
+    CS_CHECK_HIP(hipStreamSynchronize(s));
+    CS_CHECK_HIP(hipMemcpy(host.data(), u->calib, nslots * sizeof(float), hipMemcpyDeviceToHost));
+    // slot = sum over the hidden state's rows of mean^2 / var; the rows of a level: B * HW -- recovered per block from its level below
+    unsigned mask = 0; float worst = 0.f;
+    auto visit = [&](const Xformer& X, int HW) {
+        const double rows = (double)n_lat * dup * HW;
+        for (int k = 0; k < 3; ++k) {
+            const float ratio = (float)std::sqrt((double)host[3 * X.index + k] / rows);      // RMS over rows of |mean| / sigma
+            worst = std::max(worst, ratio);
+            if (ratio > bound) mask |= 1u << X.index;
+        }
+    };
+    {
+        int H = u->cfg.sample_size;
+        for (int i = 0; i < 4; ++i) { for (auto& X : u->down_att[i]) visit(X, H * H); if (u->has_down[i]) H /= 2; }
+        visit(u->mid_att, H * H);
+        for (int i = 0; i < 4; ++i) { for (auto& X : u->up_att[i]) visit(X, H * H); if (u->has_up[i]) H *= 2; }
+    }
+    u->ln_unfold_mask = mask;
+    if (mask_out) *mask_out = mask;
+    if (worst_ratio_out) *worst_ratio_out = worst;
+    return CS_OK;
+}
+int cs_unet_set_ln_unfold_mask(CsUNet* u, unsigned mask) { if (!u) CS_FAIL(CS_E_ARG, "unet is NULL"); u->ln_unfold_mask = mask; return CS_OK; }
+unsigned cs_unet_get_ln_unfold_mask(const CsUNet* u) { return u ? u->ln_unfold_mask : 0u; }
 
 int cs_unet_set_tuning(CsUNet* u, const char* key, int value) {
     if (!u || !key) CS_FAIL(CS_E_ARG, "unet / key is NULL");

@@ -79,6 +79,45 @@ class HipUNet2DConditionModel:
         L.check(L.lib().cs_unet_clear_tuning(self._h))
         return self
 
+    def calibrate_ln_fold(self, sample, timestep, encoder_hidden_states, dup=1, bound=4.0):
+        """cs_unet_calibrate_ln_fold: one forward on representative inputs; transformer blocks whose hidden states sit more than ``bound`` sigma (RMS over rows) away
+        from zero in front of a LayerNorm run their LayerNorms UNFOLDED from then on (the folded form cancels in fp16-rounded operands there).  Returns
+        ``dict(mask=..., worst_ratio=...)``; call once after ``load_state_dict`` of a real checkpoint (synthetic weights: mask 0).  The workspace is re-sized."""
+        if not self._finalized:
+            raise RuntimeError("weights not loaded")
+        L.require_cuda(sample, "sample")
+        ctx = L.require_cuda(encoder_hidden_states, "encoder_hidden_states").to(torch.float16).contiguous()
+        sample = sample.to(torch.float16).contiguous()
+        n_lat = sample.shape[0]
+        B = n_lat * dup
+        if ctx.shape[0] != B:
+            raise ValueError(f"encoder_hidden_states batch {ctx.shape[0]} != {B}")
+        t = (timestep.to(torch.float32).reshape(-1) if isinstance(timestep, torch.Tensor) else torch.tensor([float(timestep)], dtype=torch.float32)).to(sample.device)
+        # the workspace covers every mask only after the mask is known: size it for the all-unfolded graph as well (the larger of the two), then drop it
+        lib = L.lib()
+        L.check(lib.cs_unet_set_ln_unfold_mask(self._h, 0))
+        ws = torch.empty(int(lib.cs_unet_workspace_bytes(self._h, B)), dtype=torch.uint8, device=self.device)
+        out = torch.empty(B, self.config["out_channels"], sample.shape[2], sample.shape[3], dtype=torch.float16, device=sample.device)
+        if self._out_code != L.dtype_code(torch.float16):
+            L.check(lib.cs_unet_set_output_dtype(self._h, L.dtype_code(torch.float16)))
+            self._out_code = L.dtype_code(torch.float16)
+        mask, worst = C.c_uint(0), C.c_float(0.0)
+        L.check(lib.cs_unet_calibrate_ln_fold(self._h, L.ptr(sample), n_lat, dup, L.ptr(t), t.numel(), L.ptr(ctx), L.ptr(out), L.ptr(ws), ws.numel(), float(bound),
+                                              L.stream_ptr(sample.device), C.byref(mask), C.byref(worst)))
+        self._ws, self._ws_batch = None, 0
+        self.invalidate_kv()
+        return dict(mask=int(mask.value), worst_ratio=float(worst.value))
+
+    @property
+    def ln_unfold_mask(self):
+        return int(L.lib().cs_unet_get_ln_unfold_mask(self._h))
+
+    @ln_unfold_mask.setter
+    def ln_unfold_mask(self, mask):
+        L.check(L.lib().cs_unet_set_ln_unfold_mask(self._h, int(mask)))
+        self._ws, self._ws_batch = None, 0
+        self.invalidate_kv()
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

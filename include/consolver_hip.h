@@ -215,6 +215,18 @@ int cs_unet_set_residual_precision(CsUNet* u, int mode);
  * u + g (c - u) of two such tensors (rounded again as the history entry) more -- both gone from the 1e-3 latent budget for 128 KiB per image and step. */
 int cs_unet_set_output_dtype(CsUNet* u, int dtype);
 int cs_unet_get_output_dtype(const CsUNet* u);
+/* The folded LayerNorm (knob ln_fold, default on) evaluates LN(h) W^T as rstd (h_fp16 W'^T - mean s) + b': exact algebra, but on hidden states whose rows sit many
+ * sigma away from zero the two terms cancel in fp16-rounded operands (error ~ 1.6e-4 x |mean| / sigma on that layer's output; synthetic N(0, 1/fan_in) weights
+ * never get there, a trained checkpoint's outlier channels can).  cs_unet_calibrate_ln_fold runs ONE forward on representative inputs (same arguments as
+ * cs_unet_forward, which it also performs: `out` is valid afterwards), measures per transformer block the RMS over rows of |mean| / sigma of the hidden state in front
+ * of each of its LayerNorms -- from the row statistics the producers leave anyway -- and marks the blocks above `bound` (4.0 is the measured default: there the
+ * folded form's error is about twice an fp16 LayerNorm output's rounding) to run UNFOLDED from then on (LayerNorm kernel on hi + lo, plain GEMMs) while every other
+ * block keeps the fold.  One device -> host read, at load time; the mask is part of the handle (get / set for checkpoints whose mask is known) and changes
+ * cs_unet_workspace_bytes(): query it again. */
+int cs_unet_calibrate_ln_fold(CsUNet* u, const void* latents, int n_lat, int dup, const float* timesteps, int n_timesteps, const void* ctx, void* out,
+                              void* workspace, size_t workspace_bytes, float bound, void* stream, unsigned* mask_out, float* worst_ratio_out);
+int cs_unet_set_ln_unfold_mask(CsUNet* u, unsigned mask);
+unsigned cs_unet_get_ln_unfold_mask(const CsUNet* u);
 /* Kernel-selection knobs for THIS handle (keys and ranges: cs_set_tuning in consolver_hip_ops.h): cs_unet_forward runs with the process-wide values overridden by the
  * handle's entries for the duration of its host call -- a per-thread knob set, the process-wide one is not written -- so two handles in one process can run
  * different knob sets concurrently.  The workspace size does not depend on them (cs_unet_workspace_bytes covers every variant).  Unknown keys and
