@@ -102,6 +102,35 @@ static void unet_part() {
         EXPECT(cs_unet_forward(u, lat.data(), 2, 1, &t, 1, ctx.data(), out.data(), ws, small, 0, nullptr) != CS_OK);
         free(ws);
     }
+    // round 6, with the handle's own overrides cleared (folded LayerNorms on): byte lo planes of the transformer hidden state (knob lo8: the arena hands out HALF-size
+    // planes, the stubs touch exactly that many bytes), per-block unfold masks (cs_unet_calibrate_ln_fold's result), the fp32 output tensor, the calibration forward
+    for (int B : {2, 4}) {
+        for (unsigned mask : {0u, 0x5u, 0xffffu}) {
+            EXPECT(cs_unet_set_ln_unfold_mask(u, mask) == CS_OK && cs_unet_get_ln_unfold_mask(u) == mask);
+            const size_t wsb = cs_unet_workspace_bytes(u, B);
+            char* ws = (char*)malloc(wsb);
+            std::vector<char> lat((size_t)B * 4 * S * S * 2), ctx((size_t)B * 77 * 768 * 2), out((size_t)B * 4 * S * S * 2), out32((size_t)B * 4 * S * S * 4);
+            float t = 499.f;
+            for (const char* k : {"", "lo8", "cfg_share", "xattn_fused", "x2_sc_skip", "cfg_copy_async"}) {
+                if (*k) EXPECT(cs_set_tuning(k, 0) == CS_OK);
+                EXPECT(cs_unet_forward(u, lat.data(), B, 1, &t, 1, ctx.data(), out.data(), ws, wsb, 0, nullptr) == CS_OK);
+                EXPECT(cs_unet_forward(u, lat.data(), B / 2, 2, &t, 1, ctx.data(), out.data(), ws, wsb, 0, nullptr) == CS_OK);
+                EXPECT(cs_reset_tuning() == CS_OK);
+            }
+            EXPECT(cs_unet_set_output_dtype(u, 9) != CS_OK && cs_unet_set_output_dtype(u, CS_F32) == CS_OK && cs_unet_get_output_dtype(u) == CS_F32);
+            EXPECT(cs_unet_forward(u, lat.data(), B / 2, 2, &t, 1, ctx.data(), out32.data(), ws, wsb, 0, nullptr) == CS_OK);
+            EXPECT(cs_unet_set_output_dtype(u, CS_F16) == CS_OK);
+            if (mask == 0u) {
+                unsigned m = 77; float worst = -1.f;
+                EXPECT(cs_unet_calibrate_ln_fold(u, lat.data(), B / 2, 2, &t, 1, ctx.data(), out.data(), ws, wsb, 4.0f, nullptr, &m, &worst) == CS_OK && m != 77u && worst >= 0.f);   // (the stubs touch the statistics, they do not compute them)
+                EXPECT(cs_unet_set_ln_unfold_mask(u, 0) == CS_OK);
+                EXPECT(cs_unet_calibrate_ln_fold(u, lat.data(), B / 2, 2, &t, 1, ctx.data(), out.data(), ws, wsb, 0.0f, nullptr, &m, &worst) != CS_OK);
+                EXPECT(cs_unet_calibrate_ln_fold(nullptr, lat.data(), B / 2, 2, &t, 1, ctx.data(), out.data(), ws, wsb, 4.0f, nullptr, &m, &worst) != CS_OK);
+            }
+            free(ws);
+        }
+    }
+    EXPECT(cs_unet_set_ln_unfold_mask(u, 0) == CS_OK);
     cs_unet_destroy(u);
     cs_unet_destroy(nullptr);
 }

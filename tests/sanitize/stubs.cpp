@@ -11,10 +11,6 @@
 #include <cstdlib>
 #include <cstring>
 
-int g_tune_attn_lw = 1, g_tune_attn_prio = -1, g_tune_attn_qt40 = 4, g_tune_biggemm = 1, g_tune_conv_lw = 1, g_tune_debug = 0, g_tune_gemm2_prio = 0,
-    g_tune_gemm2_w8 = 1, g_tune_gemm_gm = -1, g_tune_gemm_lw = 1, g_tune_gemm_w8 = 1, g_tune_gn_fuse = 1, g_tune_halo = 1, g_tune_xcd_grid = 1, g_tune_epi_fast = 1,
-    g_tune_xattn_tile = 64;
-
 // ---- HIP runtime -------------------------------------------------------------------------------------------------------
 extern "C" {
 hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
@@ -27,6 +23,10 @@ hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { free((void*)s); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { free((void*)e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
@@ -44,15 +44,17 @@ int launch_igemm(const IgemmArgs& a, hipStream_t) {
     rd(a.a0, Min * a.c0 * 2); rd(a.a1, Min * a.c1 * 2); rd(a.a0_lo, Min * a.c0 * 2); rd(a.a1_lo, Min * a.c1 * 2);
     rd(a.w, (size_t)a.N * a.taps * (a.c0 + a.c1) * 2); rd(a.bias, (size_t)a.N * 2);
     if (a.temb) rd(a.temb, ((size_t)(a.temb_stride ? a.B - 1 : 0) * a.temb_stride + a.N) * 2);
-    rd(a.res, M * Nout * 2); rd(a.res_lo, M * Nout * 2);
-    wr(a.out, M * Nout * 2); wr(a.out_lo, M * Nout * 2);
+    const size_t lob = a.lo8 ? 1 : 2;                  // (an 8-bit lo plane holds one byte per element: the executor allocates exactly that)
+    rd(a.res, M * Nout * 2); rd(a.res_lo, M * Nout * lob);
+    wr(a.out, M * Nout * 2); wr(a.out_lo, M * Nout * lob);
     if (a.gn_stats) wr(a.gn_stats, (size_t)a.B * (a.Ho * a.Wo / 64) * a.N * sizeof(float));
     if (a.row_stats) { const int G = a.N % 160 == 0 ? a.N / 160 : a.N / 64; wr(a.row_stats, M * G * 2 * sizeof(float)); *a.row_stats_groups = G; }   // (the widest layout a kernel may pick is N / 64 groups)
     if (a.ln_stats) { rd(a.ln_stats, M * a.ln_groups * 2 * sizeof(float)); rd(a.ln_s, (size_t)a.N * 4); rd(a.ln_b, (size_t)a.N * 4); }
     if (a.splitk_ws) wr(a.splitk_ws, a.splitk_ws_bytes);
     return CS_OK;
 }
-int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(stats, (size_t)M * 8); return CS_OK; }
+int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t, int lo8) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * (lo8 ? 1 : 2)); wr(stats, (size_t)M * 8); return CS_OK; }
+int launch_ln_dc_ratio(const float* rs, int M, int G, int, float, float* dst, hipStream_t) { rd(rs, (size_t)M * G * 8); wr(dst, 4); return CS_OK; }
 int launch_attention(const AttnArgs& a, hipStream_t) {
     const size_t C = (size_t)a.H * a.dh;
     rd(a.q, (((size_t)a.B * a.Nq - 1) * a.q_stride + C) * 2); rd(a.k, (((size_t)a.B * a.Nk - 1) * a.k_stride + C) * 2);
@@ -76,7 +78,8 @@ int launch_layer_norm(const f16* x, const f16* g, const f16* b, f16* out, int M,
 }
 int launch_xattn_block(const XattnArgs& a, hipStream_t) {
     const size_t n = (size_t)a.M * a.C * 2;
-    rd(a.h, n); rd(a.h_lo, n); wr(a.out, n); wr(a.out_lo, n); wr(a.row_stats, (size_t)a.M * 8); rd(a.kv, (size_t)(a.M / a.HW) * a.Nk * 2 * a.C * 2); rd(a.wq, (size_t)a.C * a.C * 2); rd(a.wo, (size_t)a.C * a.C * 2);
+    const size_t nl = a.lo8 ? n / 2 : n;
+    rd(a.h, n); rd(a.h_lo, nl); wr(a.out, n); wr(a.out_lo, nl); wr(a.row_stats, (size_t)a.M * 8); rd(a.kv, (size_t)(a.M / a.HW) * a.Nk * 2 * a.C * 2); rd(a.wq, (size_t)a.C * a.C * 2); rd(a.wo, (size_t)a.C * a.C * 2);
     return CS_OK;
 }
 int launch_time_embedding(const float* t, int Bt, int C0, int D, const f16* w1, const f16*, const f16* w2, const f16*, f16* scratch, f16* out, hipStream_t) {
@@ -86,7 +89,7 @@ int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16*, i
 int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, f16* out_lo) {
     rd(lat, (size_t)n_lat * Cin * H * W * 2); wr(out, (size_t)B * H * W * Cout * 2); wr(out_lo, (size_t)B * H * W * Cout * 2); return CS_OK;
 }
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * 2); return CS_OK; }
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, int out_f32) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * (out_f32 ? 4 : 2)); return CS_OK; }
 int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, f16* out, int, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * 3 * H * W * 2); return CS_OK; }
 int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * 2); return CS_OK; }
 int launch_pixel_linear_nchw(const f16* x, const f16*, const f16*, f16* out, int B, int C, int HW, float, float, hipStream_t) { rd(x, (size_t)B * C * HW * 2); wr(out, (size_t)B * C * HW * 2); return CS_OK; }
