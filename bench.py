@@ -305,6 +305,22 @@ def extra_solver(dev, sch):
         for i in range(n):
             sch.step(eps[B:], sch.timesteps[i], xs[i & 1], return_dict=False, eps_uncond=eps[:B], guidance_scale=3.0, eps_out=ring[i % 4], out=xs[(i & 1) ^ 1], out_lp=x16)
     chain_ms, _ = _timed_ms(chain, 20, warm=2)
+    # the same chain as the GPU sees it: captured into one hipGraph (no host in the loop), replayed back to back
+    chain_gpu_us = None
+    try:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            chain()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            chain()
+        gms, _ = _timed_ms(gr.replay, 50, warm=3)
+        chain_gpu_us = gms * 1e3 / n
+        del gr
+    except Exception as e:
+        chain_gpu_us = f"{type(e).__name__}: {e}"
     if keep[0] is not None:
         sch.set_timesteps(keep[0], device=dev)
     return {"k1_us_at_batch16": us16, "k1_gbps_at_batch16": gb16, "k1_us_at_1GB": us4k, "k1_gbps_at_1GB": gb4k,
@@ -312,9 +328,10 @@ def extra_solver(dev, sch):
             "batch 16 (8.9 MB) is launch-latency bound, the 2.3 GB working set is what the kernel sustains when HBM-bound",
             "policy_mlp_us_at_batch16": pol_ms * 1e3, "policy_note": "cs_factor_probs, hidden 256, one conditioning row broadcast to 16 samples; "
             "wall per call incl. the host launch path (back-to-back launches)",
-            "solver_chain_us_per_step": chain_ms * 1e3 / n,
+            "solver_chain_us_per_step": chain_ms * 1e3 / n, "solver_chain_gpu_us_per_step": chain_gpu_us,
             "solver_chain_note": "PPOScheduler.step on a CFG pair at batch 16, fp32 state and eps: policy MLP + torch.rand + inverse-CDF sample + fused update (incl. the fp16 copy of the "
-            "latents); 4 launches per step (round 5: 8 -- masks, two conds launches and the fp32 -> fp16 cast are gone); wall per call incl. the host launch path"}
+            "latents); 4 launches per step (round 5: 8 -- masks, two conds launches and the fp32 -> fp16 cast are gone).  solver_chain_us_per_step = wall per Python call, back to back (the host "
+            "path: in the sampling loop it runs ahead under the 28 ms denoiser forward); solver_chain_gpu_us_per_step = the same 8 steps captured in one hipGraph and replayed: what the chain costs the GPU"}
 
 
 def extra_rollout(unet, vae, dev, B=80, n=8, epochs=4, iters=2):

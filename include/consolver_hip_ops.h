@@ -192,8 +192,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *   "epi_fast":  bit 0: conv / linear epilogues that add a residual (+ its lo plane) or a time embedding issue those loads ahead of their use, branch-free
  *                (igemm_epilogue_impl FAST), bit 1 (round 6): also the form "residual + its lo plane, no lo plane out" (the feed-forward's second linear in the
  *                split mode); 3 (default), 0 the generic load-where-added code; bit-identical, see profiles/r04_ab_epi_fast_*.txt;
- *   "x2_sc_skip": bit i: the i-th resnet shortcut 1x1 (creation order) reads the hi plane only although x2_split_a bit 0 is set (default 0x78: the four 2560 -> 1280
- *                shortcuts at the 8 x 8 / 16 x 16 levels whose hi + lo operand buys the least, tools/sim_precision_r06.py);
+ *   "x2_sc_skip": bit i: the i-th resnet shortcut 1x1 (creation order) reads the hi plane only although x2_split_a bit 0 is set (default 0; 0x78 = the four 2560 -> 1280
+ *                shortcuts at the 8 x 8 / 16 x 16 levels whose hi + lo operand buys the least: -0.12 ms per forward, +3.5 % on the tightest gated number);
  *   "lo8":       1 (default) inside cs_unet_forward (CS_RESIDUAL_F16X2) the transformer blocks' hidden state carries an 8-bit e5m2 lo plane (cs_op_linear_lo8),
  *                0 an fp16 one;
  *   "cfg_copy_async": 1 (default) cs_unet_forward with dup = 2 and the shared CFG prefix copies conv_in's output to the batch's second half on a side stream (needed
