@@ -42,7 +42,6 @@ struct TuneSet {
     // 1: conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
     // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
     int conv_in_mfma = 1;
-    int cfg_copy_async = 1; // 1: CFG dual batch with the shared prefix: the second-half copy of conv_in's output runs on a side stream (forked after conv_in, joined in front of the last up resnet), 0: in line
     int conv_out_mfma = 1;  // 1: the 16 x 16-patch conv_out kernels (UNet 320 -> 4, VAE 128 -> 3) on v_mfma_f32_16x16x32_f16 (conv_out_mfma_kernel), 0: the v_dot2 patch kernel
     int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 };

@@ -22,7 +22,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"gemm2_prio", &TuneSet::gemm2_prio, -1, 1, false}, {"attn_prio", &TuneSet::attn_prio, -1, 1, false}, {"attn_qt40", &TuneSet::attn_qt40, 2, 4, true},
         {"x2_split_a", &TuneSet::x2_split_a, 0, 3, false}, {"x2_sc_skip", &TuneSet::x2_sc_skip, 0, 0xffff, false}, {"ln_fold", &TuneSet::ln_fold, 0, 1, false}, {"xcd_grid", &TuneSet::xcd_grid, 0, 1, false}, {"epi_fast", &TuneSet::epi_fast, 0, 3, false}, {"lo8", &TuneSet::lo8, 0, 1, false},
         {"conv_in_mfma", &TuneSet::conv_in_mfma, 0, 1, false}, {"xattn_tile", &TuneSet::xattn_tile, 64, 128, true},
-        {"conv_out_mfma", &TuneSet::conv_out_mfma, 0, 1, false}, {"cfg_copy_async", &TuneSet::cfg_copy_async, 0, 1, false},
+        {"conv_out_mfma", &TuneSet::conv_out_mfma, 0, 1, false},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;

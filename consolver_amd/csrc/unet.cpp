@@ -131,9 +131,6 @@ struct CsUNet {
     // hidden states carry a DC offset of several sigma, where the folded form -- rstd (h_fp16 W' - mean s) -- cancels in fp16-rounded operands
     unsigned ln_unfold_mask = 0;
     float* calib = nullptr;             // device [3 * n_xformers] sums over rows of mean^2 / var (written only during a calibration forward)
-    // CFG dual batch: the second half's copy of conv_in's output (a skip connection read at full batch by the LAST up resnet only) runs on a side stream, forked after
-    // conv_in and joined in front of that resnet -- 30 us of copies off the forward's critical path (capturable: the side stream joins and leaves the capture with the events)
-    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // run state
     Arena arena;
     bool profiling = false;
@@ -683,7 +680,6 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     }
 
     // ---- down path -----------------------------------------------------------------------------------
-    bool skip0_async = false;      // the second half of conv_in's output is being written by the side stream
     std::vector<std::pair<St, int>> skips;
     St h = R.salloc((size_t)B * H * W * c0);
     // CFG dual batch with one timestep: the first resnet and the first transformer block up to its cross attention are shared
@@ -703,19 +699,13 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
         R.release(z);
         if (dup == 2 && !dry && R.rc == CS_OK) {
             const size_t half = (size_t)n_lat * H * W * c0;
-            // with the shared CFG prefix the first resnet reads the first half only: the copies are needed by the last up resnet, a whole forward later
+            // (round 6 tried these three copies on a side stream -- forked here, joined in front of the last up resnet, their only full-batch reader: the forward got
+            //  0.15 ms SLOWER, 29.35 -> 29.50 ms alternating on one box (profiles/r06_ab_copy_async.txt): a second queue's blit kernels take CU slots and bandwidth
+            //  from the conv they run beside, and the fork / join events are not free.  In line they cost 30 us.)
             hipStream_t cs = s;
-            if (share && tune().cfg_copy_async) {
-                if (!u->side) {
-                    if (hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming) != hipSuccess) { cs_set_error("unet: side stream / events"); R.rc = CS_E_HIP; }
-                }
-                if (R.rc == CS_OK && hipEventRecord(u->ev_fork, s) == hipSuccess && hipStreamWaitEvent(u->side, u->ev_fork, 0) == hipSuccess) { cs = u->side; skip0_async = true; }
-            }
             hipMemcpyAsync(h.hi + half, h.hi, half * sizeof(f16), hipMemcpyDeviceToDevice, cs);
             if (h.lo) hipMemcpyAsync(h.lo + half, h.lo, half * sizeof(f16), hipMemcpyDeviceToDevice, cs);
             if (st) { const size_t sh = (size_t)n_lat * (H * W / 64) * c0; hipMemcpyAsync(st + sh, st, sh * sizeof(float), hipMemcpyDeviceToDevice, cs); }
-            if (skip0_async && hipEventRecord(u->ev_join, u->side) != hipSuccess) { cs_set_error("unet: event record on the side stream"); R.rc = CS_E_HIP; }
         }
         if (st) R.stat_of[h.hi] = {st, H * W / 64};
     } else {
@@ -757,10 +747,6 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     for (int i = 0; i < 4; ++i) {
         for (size_t j = 0; j < u->up_res[i].size(); ++j) {
             auto sk = skips.back(); skips.pop_back();
-            if (skip0_async && skips.empty()) {                 // conv_in's output: join the side stream's copies
-                if (hipStreamWaitEvent(s, u->ev_join, 0) != hipSuccess && R.rc == CS_OK) { cs_set_error("unet: join of the side stream"); R.rc = CS_E_HIP; }
-                skip0_async = false;
-            }
             St r = R.resnet(u->up_res[i][j], h, ch, sk.first, sk.second, H, W);
             R.srelease(h); R.srelease(sk.first);
             ch = u->up_res[i][j].cout;
@@ -808,9 +794,6 @@ int cs_unet_create(const CsUNetConfig* cfg, CsUNet** out) {
 void cs_unet_destroy(CsUNet* u) {
     if (!u) return;
     for (void* p : u->dev_allocs) hipFree(p);
-    if (u->ev_fork) hipEventDestroy(u->ev_fork);
-    if (u->ev_join) hipEventDestroy(u->ev_join);
-    if (u->side) hipStreamDestroy(u->side);
     for (auto& e : u->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     delete u;
 }

@@ -196,8 +196,6 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                shortcuts at the 8 x 8 / 16 x 16 levels whose hi + lo operand buys the least: -0.12 ms per forward, +3.5 % on the tightest gated number);
  *   "lo8":       1 (default) inside cs_unet_forward (CS_RESIDUAL_F16X2) the transformer blocks' hidden state carries an 8-bit e5m2 lo plane (cs_op_linear_lo8),
  *                0 an fp16 one;
- *   "cfg_copy_async": 1 (default) cs_unet_forward with dup = 2 and the shared CFG prefix copies conv_in's output to the batch's second half on a side stream (needed
- *                only by the last up resnet: forked after conv_in, joined there; graph-capturable), 0 in line on the caller's stream;
  *   "conv_out_mfma": 1 (default) the 16 x 16-patch conv_out kernels (cs_op_conv_out) on the matrix cores, 0 the v_dot2 patch kernel;
  *   "conv_in_mfma": 1 (default) the UNet's conv_in runs on the MFMA conv kernel over latents zero-padded to 64 channels, 0 the scalar conv_in kernel;
  *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),

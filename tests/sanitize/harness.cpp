@@ -111,7 +111,7 @@ static void unet_part() {
             char* ws = (char*)malloc(wsb);
             std::vector<char> lat((size_t)B * 4 * S * S * 2), ctx((size_t)B * 77 * 768 * 2), out((size_t)B * 4 * S * S * 2), out32((size_t)B * 4 * S * S * 4);
             float t = 499.f;
-            for (const char* k : {"", "lo8", "cfg_share", "xattn_fused", "x2_sc_skip", "cfg_copy_async"}) {
+            for (const char* k : {"", "lo8", "cfg_share", "xattn_fused", "x2_sc_skip"}) {
                 if (*k) EXPECT(cs_set_tuning(k, 0) == CS_OK);
                 EXPECT(cs_unet_forward(u, lat.data(), B, 1, &t, 1, ctx.data(), out.data(), ws, wsb, 0, nullptr) == CS_OK);
                 EXPECT(cs_unet_forward(u, lat.data(), B / 2, 2, &t, 1, ctx.data(), out.data(), ws, wsb, 0, nullptr) == CS_OK);
