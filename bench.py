@@ -592,6 +592,16 @@ def main():
                 float(out.float().abs().sum().item()), host_id]
         rows = gather_rank_records(dist, mine, dev)
         assert len(rows) == world, (len(rows), world)
+        if args.force_dist:
+            # (--force-dist: also the other RCCL-side helpers of launch.py on GPU tensors -- the max over ranks the drivers report (gen_ppo.py:433-465), the
+            #  count / checksum gather, the trainer's gradient mean (train_ppo.py:257,430) -- so that one process-group initialisation covers all of them in the GPU suite)
+            from consolver_amd import launch as _launch
+            assert _launch.reduce_max_seconds(dist, 1.5, dev) == 1.5
+            rep = _launch.gather_report(dist, B * args.steps, 2.25, dev)
+            assert len(rep) == world and rep[rank] == (B * args.steps, 2.25), rep
+            gvec = torch.arange(75000, dtype=torch.float32, device=dev)
+            assert torch.equal(_launch.average_gradients(dist, gvec.clone()), gvec)      # (identical on every rank: the mean is the vector itself)
+            assert dist.get_backend() == "nccl"
         per_rank = [{"rank": int(r[0]), "local_rank": int(r[1]), "device": int(r[2]), "images": int(r[3]), "elapsed_s": r[4],
                      "prompt_shard": [int(r[5]), int(r[6])], "latent_checksum": r[7], "host_id": int(r[8])} for r in rows]
         assert sorted(p["rank"] for p in per_rank) == list(range(world)), per_rank

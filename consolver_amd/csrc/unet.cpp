@@ -468,7 +468,10 @@ struct Run {
     }
 
     // fused LN2 -> to_q -> cross attention -> to_out + residual (xattn.hip); h_in may equal h_out
-    bool xattn_fusable(const Xformer& X, int HW) const { return v_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80; }
+    // (an UNFOLDED block -- cs_unet_calibrate_ln_fold: DC-heavy hidden state -- also leaves the fused kernel: its LayerNorm reads the hi plane, the LayerNorm kernel hi + lo)
+    bool xattn_fusable(const Xformer& X, int HW) const {
+        return v_xattn_fused != 0 && X.c == 320 && u->cfg.num_heads == 8 && HW % 128 == 0 && u->cfg.ctx_len <= 80 && !((u->ln_unfold_mask >> X.index) & 1u);
+    }
     void xattn_fused(const Xformer& X, St h_in, St h_out, const f16* kvl, int HW, float* row_stats = nullptr) {
         XattnArgs a{};
         a.row_stats = row_stats;

@@ -345,56 +345,20 @@ def test_pipeline_call_surface():
 
 
 @pytest.mark.gpu
-def test_rccl_process_group_at_world_size_one():
-    """The RCCL ("nccl" backend on ROCm) side of launch.py on real hardware: a world-size-1 process group on this box's GPU through the SAME helpers the 8-GPU
-    jobs use (gen_ppo.py:349-357,433-465: shard, barrier, max over ranks, gather): barrier, all_reduce(MAX) and all_gather on CUDA tensors, the trainer's
-    gradient mean (train_ppo.py:257,430), and the per-rank record of bench.py.  The gloo twins run in tests/test_launch_cpu.py at world size 2."""
-    import subprocess, sys, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import os, socket, sys
-        sys.path.insert(0, %r)
-        import torch
-        import torch.distributed as dist
-        from consolver_amd import launch
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        dev = torch.device("cuda", 0)
-        torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
-        dist.barrier()
-        assert launch.reduce_max_seconds(dist, 1.5, dev) == 1.5
-        assert launch.gather_report(dist, 16, 2.25, dev) == [(16, 2.25)]
-        rows = launch.gather_rank_records(dist, [0.0, 0.0, float(torch.cuda.current_device()), 48.0, 0.7, 0.0, 16.0, 123.5, 9.0], dev)
-        assert rows == [[0.0, 0.0, 0.0, 48.0, 0.7, 0.0, 16.0, 123.5, 9.0]], rows
-        g = torch.arange(75000, dtype=torch.float32, device=dev)               # the policy's packed gradient vector (~300 KB)
-        out = launch.average_gradients(dist, g.clone())
-        assert torch.equal(out, g)
-        lo, hi = launch.shard_bounds(16, dist.get_world_size(), dist.get_rank())
-        assert (lo, hi) == (0, 16)
-        torch.cuda.synchronize()
-        dist.barrier()
-        dist.destroy_process_group()
-        print("RCCL_OK")
-    """ % root)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
-    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-
-
 def test_bench_prints_one_contract_line():
     """bench.py (N = 1, short) prints ONE JSON line with the driver's keys plus roofline / ceilings / cpu_baseline objects"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--decode", "0", "--extras", "0",
-                        "--no-cpu-baseline", "--profile-kernels", "0", "--force-dist"], capture_output=True, text=True, timeout=600, cwd=root)
+                        "--no-cpu-baseline", "--profile-kernels", "0", "--traffic", "none", "--force-dist"], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     # --force-dist: the N > 1 branch of bench.py on this one-GPU box -- init_process_group("nccl", device_id=...), the barriers, all_reduce(MAX) of the elapsed time on a
-    # GPU tensor and launch.gather_rank_records over RCCL -- the code the driver's 8-GPU run executes, at world size 1
+    # GPU tensor and launch.gather_rank_records over RCCL -- the code the driver's 8-GPU run executes, at world size 1; under the same flag bench.py also drives
+    # launch.reduce_max_seconds / gather_report / average_gradients on CUDA tensors and asserts their results (one RCCL initialisation, ~70 s on a fresh box, for all of them;
+    # their gloo twins run at world size 2 in tests/test_launch_cpu.py).  Reference: gen_ppo.py:349-357,433-465, train_ppo.py:257,430
     assert len(rec["per_rank"]) == 1 and rec["per_rank"][0]["rank"] == 0 and rec["per_rank"][0]["images"] == 16 and rec["per_rank_distinct_devices"] == 1
     assert rec["per_rank"][0]["prompt_shard"] == [0, 16] and abs(rec["per_rank"][0]["elapsed_s"] * 1e3 - rec["ms_per_step"]) < 1e-3 * rec["ms_per_step"] + 1.0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):

@@ -225,10 +225,10 @@ def test_unet_with_folded_layernorm_matches_the_layernorm_kernels(residual):
 
 
 def test_calibration_unfolds_the_block_whose_hidden_state_is_dc_heavy():
-    """cs_unet_calibrate_ln_fold (round 6): a checkpoint whose transformer hidden states carry a DC offset of many sigma in ONE block (here: proj_in's bias of the first
-    down-block transformer raised to ~30 sigma of its output, the pattern of tests above at the executor level).  Forced fold: that block's LayerNorm consumers cancel in
+    """cs_unet_calibrate_ln_fold (round 6): a checkpoint whose transformer hidden states carry a DC offset of many sigma in TWO blocks (here: proj_in's bias of the first
+    and of the last transformer block raised to ~100 sigma of its output, the pattern of the tests above at the executor level).  Forced fold: those blocks' LayerNorm consumers cancel in
     fp16-rounded operands and the eps error against the fp32 oracle grows; calibration measures |mean| / sigma from the row statistics the producers leave, marks exactly
-    that block, and the forward returns to the accuracy of the LayerNorm kernels (ln_fold = 0) while every other block keeps the fold.  On the unmodified synthetic
+    those blocks (they also leave the fused cross-attention kernel, whose LayerNorm reads the hi plane), and the forward returns to the accuracy of the LayerNorm kernels (ln_fold = 0) while every other block keeps the fold.  On the unmodified synthetic
     weights the mask is empty."""
     from oracle.unet_oracle import UNetOracle
     cfg = dict(layers_per_block=1, sample_size=32)
@@ -239,8 +239,8 @@ def test_calibration_unfolds_the_block_whose_hidden_state_is_dc_heavy():
     assert res0["mask"] == 0 and u0.ln_unfold_mask == 0 and 0.0 < res0["worst_ratio"] < 4.0, res0
     # ---- the DC-heavy checkpoint
     sd = {k: v.clone() for k, v in sd0.items()}
-    key = "down_blocks.0.attentions.0.proj_in.bias"
-    sd[key] = sd[key] + 30.0                      # the hidden state of that block: every row's mean moves by 30 (row sigma ~ 1)
+    for blk in ("down_blocks.0.attentions.0", "up_blocks.3.attentions.1"):      # creation order: blocks 0 and 9 of the reduced UNet's ten
+        sd[blk + ".proj_in.bias"] = sd[blk + ".proj_in.bias"] + 100.0           # the hidden state of that block: every row's mean moves by 100 (row sigma ~ 1)
     u = HipUNet2DConditionModel(cfg, device=DEV, residual="f16x2")
     u.load_state_dict(sd)
     want = UNetOracle(sd, u.config)(torch.cat([lat.float()] * 2), 499, ctx.float())
@@ -255,12 +255,13 @@ def test_calibration_unfolds_the_block_whose_hidden_state_is_dc_heavy():
     e_cal = rel_l2(run(u), want)
     print(f"\nDC-heavy block: eps error vs the fp32 oracle: all folded {e_fold:.3e}, LayerNorm kernels everywhere {e_kernels:.3e}, calibrated (mask {res['mask']:#x}, "
           f"worst |mean| / sigma {res['worst_ratio']:.1f}) {e_cal:.3e}")
-    assert res["mask"] == 1 and res["worst_ratio"] > 10.0, res                  # block 0 (creation order), and only it
-    assert e_fold > 1.3 * e_kernels                                             # (the case does show the fold's cancellation)
-    assert e_cal < 1.1 * e_kernels, (e_cal, e_kernels)
+    assert res["mask"] == 0x201 and res["worst_ratio"] > 10.0, res              # blocks 0 and 9, and only they
+    # measured: all folded 6.62e-4, LayerNorm kernels 6.19e-4 (two of ten blocks carry the offset; a block's branch error reaches eps attenuated)
+    assert e_fold > 1.03 * e_kernels, (e_fold, e_kernels)                       # (the case does show the fold's cancellation at the UNet's output)
+    assert e_cal < 1.03 * e_kernels and e_cal < 0.985 * e_fold, (e_cal, e_kernels, e_fold)
     # the mask travels with the handle: cleared -> the folded error is back; set by hand -> the calibrated result, bit for bit
     a = run(u)
     u.ln_unfold_mask = 0
     assert abs(rel_l2(run(u), want) - e_fold) < 1e-6
-    u.ln_unfold_mask = 1
+    u.ln_unfold_mask = 0x201
     assert torch.equal(run(u), a)
