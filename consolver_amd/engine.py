@@ -25,7 +25,7 @@ from . import _lib as L
 
 
 class SDSamplingEngine:
-    def __init__(self, unet, scheduler, guidance_scale=3.0, vae=None, latents_dtype=torch.float32, eps_dtype=None):
+    def __init__(self, unet, scheduler, guidance_scale=3.0, vae=None, latents_dtype=torch.float32, eps_dtype=None, hi_precision_steps=None):
         if latents_dtype not in (torch.float32, torch.float16):
             raise ValueError("latents_dtype must be torch.float32 (default) or torch.float16")
         # Round 6: the denoiser's OUTPUT is taken in fp32 too when the state is fp32 (cs_unet_set_output_dtype: conv_out stores its accumulator unrounded) -- the eps
@@ -37,6 +37,10 @@ class SDSamplingEngine:
             raise ValueError("eps_dtype must be torch.float16, or torch.float32 together with an fp32 solver state")
         self.latents_dtype = latents_dtype
         self.eps_dtype = eps_dtype
+        # Precision schedule of the denoiser's residual stream (round 6): the first `hi_precision_steps` forwards of a generation run the handle's own mode (f16x2: hi + lo
+        # planes), the rest the one-plane `f16` stream.  None: every step in the handle's mode.  See `_stream_mode`.
+        self.hi_precision_steps = hi_precision_steps
+        self._base_mode = None
         self.unet = unet
         self.vae = vae                  # HipAutoencoderKL for output_type="pt" (decode_latents, utils.py:6-34)
         self.decode_events = None       # optional list collecting (start, stop) events around the VAE decode
@@ -61,7 +65,22 @@ class SDSamplingEngine:
                 eps=torch.empty(2 * B, C, H, W, dtype=self.eps_dtype, device=device))
         return self._bufs
 
+    def _stream_mode(self, i):
+        """residual-stream mode of step i: the handle's mode for the first `hi_precision_steps` steps, "f16" afterwards (only when the handle runs f16x2)"""
+        if self.hi_precision_steps is None or self._base_mode != "f16x2":
+            return self._base_mode
+        return "f16x2" if i < self.hi_precision_steps else "f16"
+
     def _loop(self, ctx, bufs, n, B, do_cfg):
+        sch, unet = self.scheduler, self.unet
+        self._base_mode = getattr(unet, "residual", None)
+        try:
+            return self._loop_steps(ctx, bufs, n, B, do_cfg)
+        finally:
+            if self._base_mode is not None and getattr(unet, "residual", None) != self._base_mode:
+                unet.set_residual_precision_keep(self._base_mode)
+
+    def _loop_steps(self, ctx, bufs, n, B, do_cfg):
         sch, unet = self.scheduler, self.unet
         x = bufs["lat"][0]
         cur = 0
@@ -73,7 +92,7 @@ class SDSamplingEngine:
             # the denoiser's fp16 view of the fp32 solver state: one cast for the initial noise, afterwards written by the update kernel itself (step(out_lp=...))
             xin = x if bufs["lat16"] is None else (bufs["lat16"].copy_(x) if i == 0 else bufs["lat16"])
             eps = unet(xin, t_dev[i:i + 1], encoder_hidden_states=ctx, dup=2 if do_cfg else 1, reuse_kv=(i > 0),
-                       out=bufs["eps"] if do_cfg else bufs["eps"][:B])[0]
+                       out=bufs["eps"] if do_cfg else bufs["eps"][:B], **({"residual": self._stream_mode(i)} if self._base_mode is not None else {}))[0]
             if self.forward_events is not None:
                 b.record()
                 self.forward_events.append((a, b))

@@ -70,6 +70,14 @@ class HipUNet2DConditionModel:
         self.invalidate_kv()
         return self
 
+    def set_residual_precision_keep(self, mode):
+        """switch the mode WITHOUT dropping the workspace / K/V cache (both are sized for and shared by the two modes, `_workspace`)"""
+        if mode not in self.RESIDUAL_MODES:
+            raise ValueError(f"residual must be one of {sorted(self.RESIDUAL_MODES)}, got {mode!r}")
+        L.check(L.lib().cs_unet_set_residual_precision(self._h, self.RESIDUAL_MODES[mode]))
+        self.residual = "f16x2" if self.RESIDUAL_MODES[mode] else "f16"
+        return self
+
     def set_tuning(self, key, value):
         """kernel-selection knob for THIS model only (cs_unet_set_tuning): applied around each of its forwards, the process-wide ``ops.set_tuning`` state is untouched"""
         L.check(L.lib().cs_unet_set_tuning(self._h, key.encode(), int(value)))
@@ -165,7 +173,15 @@ class HipUNet2DConditionModel:
 
     def _workspace(self, batch):
         if self._ws is None or batch > self._ws_batch:
-            n = int(L.lib().cs_unet_workspace_bytes(self._h, batch))
+            # sized for BOTH residual-stream modes (the larger arena; the K/V cache, GroupNorm and split-K regions in front of it do not depend on the mode), so that a
+            # forward can pick its mode per call (`residual=`: the sampling engine's precision schedule) on one workspace and one K/V cache
+            lib = L.lib()
+            cur = self.RESIDUAL_MODES[self.residual]
+            n = 0
+            for mode in (0, 1):
+                L.check(lib.cs_unet_set_residual_precision(self._h, mode))
+                n = max(n, int(lib.cs_unet_workspace_bytes(self._h, batch)))
+            L.check(lib.cs_unet_set_residual_precision(self._h, cur))
             self._ws = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._ws_batch = batch
             self.invalidate_kv()
@@ -190,9 +206,10 @@ class HipUNet2DConditionModel:
         return out
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, return_dict=False, dup=1, reuse_kv=None, out=None, out_dtype=None,
-                 **_ignored):
+                 residual=None, **_ignored):
         """``out_dtype`` (or the dtype of ``out``): torch.float16 (default: the model dtype, what the reference's UNet returns) or torch.float32 -- conv_out stores its
-        fp32 accumulator unrounded (cs_unet_set_output_dtype): the native engine's choice."""
+        fp32 accumulator unrounded (cs_unet_set_output_dtype): the native engine's choice.  ``residual`` ("f16x2" | "f16"): the residual-stream mode of THIS forward (the
+        handle's mode afterwards); workspace and cached cross-attention K/V are shared by the two modes."""
         if not self._finalized:
             raise RuntimeError("weights not loaded")
         L.require_cuda(sample, "sample")
@@ -211,6 +228,11 @@ class HipUNet2DConditionModel:
         if t.numel() not in (1, B):
             raise ValueError("timestep must be a scalar or one value per sample")
         ws = self._workspace(B)
+        if residual is not None and residual != self.residual:
+            if residual not in self.RESIDUAL_MODES:
+                raise ValueError(f"residual must be one of {sorted(self.RESIDUAL_MODES)}, got {residual!r}")
+            L.check(L.lib().cs_unet_set_residual_precision(self._h, self.RESIDUAL_MODES[residual]))
+            self.residual = "f16x2" if self.RESIDUAL_MODES[residual] else "f16"
         # Cross-attention K/V of the prompt are cached across the steps of one generation.  reuse_kv=True/False
         # is the caller's explicit statement (the sampling engine and the rollout pass ``i > 0``).  With
         # reuse_kv=None the cache is reused only when the SAME tensor object, unmodified, is passed again: the
