@@ -64,7 +64,7 @@ def test_engine_trajectory_reduced_unet(use_graph):
     idx = rng.integers(0, 11, size=(n, B, 3))
     pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
     noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(43)).half()
-    eng = SDSamplingEngine(unet, sch, guidance_scale=g)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=g, hi_precision_steps="all")      # (bounds below: the split stream at every step; the schedule is gated on the full UNet, test_parity_e2e_gpu.py)
     if use_graph:
         # replay indices are baked per step by capturing with a fixed queue: use one index set for all steps
         idx[:] = idx[0]
@@ -93,7 +93,7 @@ def test_engine_use_conv_under_cfg():
     idx = np.random.default_rng(8).integers(0, 11, size=(n, B, 3))
     pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
     noise = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(44)).half()
-    eng = SDSamplingEngine(unet, sch, guidance_scale=g)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=g, hi_precision_steps="all")
     sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
     got_probs = []
     orig = sch.step
@@ -122,7 +122,7 @@ def test_engine_trajectory_full_sd15_two_steps():
     pe, ne = synthetic_prompt_embeds(B, seed=1001).half(), synthetic_prompt_embeds(B, seed=1002).half()
     noise = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(43)).half()
     sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
-    eng = SDSamplingEngine(unet, sch, guidance_scale=g)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=g, hi_precision_steps="all")
     got = eng.generate(pe.to(DEV), ne.to(DEV), latents=noise.to(DEV), num_inference_steps=n).float().cpu().numpy()
     want = oracle_run(sd, unet.config, w, noise, pe, ne, idx, n, g, cfg_over={})
     err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
