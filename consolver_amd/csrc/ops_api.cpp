@@ -168,6 +168,10 @@ int cs_op_row_stats_lo8(const void* x, const void* x_lo8, int M, int C, float* s
     return launch_row_stats((const f16*)x, (const f16*)x_lo8, M, C, stats, (hipStream_t)stream, 1);
 }
 
+int cs_op_ln_dc_ratio(const float* row_stats, int M, int groups, int C, float eps, float* sum, void* stream) {
+    return launch_ln_dc_ratio(row_stats, M, groups, C, eps, sum, (hipStream_t)stream);
+}
+
 int cs_op_conv_out(const void* x, int B, int Cin, int H, int W, const void* w, const void* bias, int Cout, void* out, int postprocess, void* stream) {
     if (postprocess && Cout != 3) CS_FAIL(CS_E_ARG, "conv_out: postprocess is the image head's (Cout 3)");
     if (Cout == 3) return launch_conv_out3((const f16*)x, B, Cin, H, W, (const f16*)w, (const f16*)bias, (f16*)out, postprocess, (hipStream_t)stream);

@@ -178,6 +178,15 @@ def row_stats_lo8(x, x_lo8):
     return st
 
 
+def ln_dc_ratio(stats, C_in, eps=1e-5):
+    """RMS over the rows of |mean| / sigma, from row statistics [M, groups, 2] (cs_op_ln_dc_ratio): the figure cs_unet_calibrate_ln_fold compares with its
+    bound to decide whether a transformer block keeps its LayerNorms folded into the consuming GEMMs"""
+    M, G, _ = stats.shape
+    acc = torch.zeros(1, dtype=torch.float32, device=stats.device)
+    L.check(L.lib().cs_op_ln_dc_ratio(L.ptr(stats), M, G, C_in, eps, L.ptr(acc), L.stream_ptr(stats.device)))
+    return float((acc / M).sqrt())
+
+
 def ln_fold_pack(w, bias, gamma, beta):
     """host-side folding of a LayerNorm (gamma, beta) into the linear layer w [N, K] (+ bias) that consumes it: returns (W' fp16 [N, K], s fp32 [N], b' fp32 [N])
     on the CPU (cs_op_ln_fold_pack; the executor packs its weights with the same function)."""

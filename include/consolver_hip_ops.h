@@ -128,6 +128,11 @@ int cs_op_xattn_block_lo8(const void* h, const void* h_lo8, const void* ln_gamma
                           int Nk, const void* wo, const void* bo, int M, int HW, int C, int heads, float scale, void* out, void* out_lo8, float* row_stats,
                           void* stream);
 int cs_op_row_stats_lo8(const void* x, const void* x_lo8, int M, int C, float* stats, void* stream);
+/* the detector behind cs_unet_calibrate_ln_fold (round 6): *sum += sum over the M rows of mean^2 / (var + eps), the moments taken from row statistics
+ * [M][groups][2] as a producer epilogue or cs_op_row_stats leaves them.  sqrt(*sum / M) is the RMS of |mean| / sigma over the rows: how many sigma the
+ * rows of a hidden state sit away from zero, i.e. how many times 2^-11 a LayerNorm folded into the next GEMM loses on them (it multiplies the hi plane).
+ * The executor unfolds a block whose figure exceeds the caller's bound (default 4).  *sum must be zeroed by the caller; float atomics, order-free. */
+int cs_op_ln_dc_ratio(const float* row_stats, int M, int groups, int C, float eps, float* sum, void* stream);
 
 /* transformer GEMM (f16 / bf16, dtype = CS_F16 1 | CS_BF16 2): out[m][n] = act(x[m,:] . w[n,:] + bias[n]) (+ res, * gate);
  * w must have ceil(N/256)*256 rows (zero padded).  act: 0 none, 1 GELU(tanh).  gate: fp32 [M / rows_per_sample][gate_stride]. */

@@ -172,6 +172,16 @@ def test_linear_ln_on_dc_heavy_and_outlier_rows(name, dc, outliers, C, N):
     if dc == 0.0:
         assert e_fold < 1.5 * e_x2 + 1e-4, (e_fold, e_x2)                         # outlier channels on zero-mean rows: as good as the hi + lo kernel
     assert e_x2 < 4e-4, e_x2                                                      # the remedy holds on every row kind
+    # round 6: the calibration's detector (cs_unet_calibrate_ln_fold, bound 4) on the same rows, and what a calibrated executor then runs on them:
+    # the LayerNorm kernel on hi + lo where the rows sit more than 4 sigma from zero, the folded form elsewhere -- asserted against the hi + lo LayerNorm
+    ratio = ops.ln_dc_ratio(ops.row_stats(hh, hl), C)
+    want_ratio = float((h32.double().mean(1) ** 2 / (h32.double().var(1, unbiased=False) + 1e-5)).mean().sqrt())
+    assert abs(ratio - want_ratio) < 0.01 * want_ratio + 1e-3, (ratio, want_ratio)
+    unfold = ratio > 4.0
+    assert unfold == (dc >= 30.0), (name, ratio)
+    e_run = e_x2 if unfold else e_fold
+    print(f"  detector: RMS |mean| / sigma = {ratio:.2f} -> {'LayerNorm kernels on hi + lo' if unfold else 'folded'}: {e_run:.3e}")
+    assert e_run < (4e-4 if unfold else 2.0 * e_x2 + 4.0 * 2.0 ** -11), (name, e_run, e_x2)    # folded rows: at most `bound` x 2^-11 over the hi + lo kernel
 
 
 def test_linear_ln_reads_grouped_statistics_from_a_producer():
