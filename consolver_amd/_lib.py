@@ -193,6 +193,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "cs_op_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cs_op_row_stats_lo8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cs_op_conv_up_fold_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "cs_op_conv_up_sub": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cs_op_ln_dc_ratio": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "cs_op_linear_lo8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),

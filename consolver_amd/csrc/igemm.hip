@@ -656,6 +656,29 @@ struct PatchRows {          // tile-local pixel -> output row
     }
 };
 
+// conv3_lw_kernel<.., SUB>: the tile's 256 pixels are INPUT pixels of a nearest-x2 upsample + 3x3 conv in its sub-pixel form; the tile computes output phase (oy, ox):
+// input pixel (y, x) -> output pixel (2 y + oy, 2 x + ox).  (y0, x0) is the patch origin in the input image, Ho x Wo the output image.
+struct SubRows {
+    int o_base, b0, y0, x0, B, Ho, Wo, tw_shift, trw_shift, oy, ox, slot_off;
+    __device__ __forceinline__ int operator()(int row) const {
+        const int o = o_base + row;
+        const int img = o >> trw_shift, rem = o & ((1 << trw_shift) - 1);
+        const int fy = rem >> tw_shift, fx = rem & ((1 << tw_shift) - 1);
+        const int b = b0 + img;
+        return b < B ? (b * Ho + 2 * (y0 + fy) + oy) * Wo + 2 * (x0 + fx) + ox : -1;
+    }
+    __device__ __forceinline__ bool all_valid() const { return b0 + ((o_base + 63) >> trw_shift) < B; }
+    // the wave's 64 pixels are one phase of a quarter input patch (or of a whole 8 x 8 input image): phase-major over the blocks of the input image
+    __device__ __forceinline__ int stat_slot(int HoWo) const {
+        const int img = o_base >> trw_shift, b = b0 + img;
+        if (b >= B || trw_shift < 6) return -1;
+        const int th_shift = trw_shift - tw_shift;
+        const int patch = ((y0 >> th_shift) * ((Wo >> 1) >> tw_shift)) + (x0 >> tw_shift);
+        const int sub = (o_base & ((1 << trw_shift) - 1)) >> 6;
+        return b * (HoWo >> 6) + slot_off + (patch << (trw_shift - 6)) + sub;
+    }
+};
+
 // KH = 2 (BN = 320): the inner step is HALF a tap (k = 32): wave tile 64 x 160 like the big GEMM (22 % fewer LDS fragment bytes per MFMA than
 // 64 x 80, half the per-tile prologue / epilogue and half the halo traffic per FLOP); the weight tile of a step is [320 rows][32 k] = 64-byte
 // rows (chunk index XOR (row >> 1) & 3: conflict-free ds_read_b128 under gfx950's lane grouping), the same 20 KB and 20 DMA instructions as
@@ -962,8 +985,15 @@ constexpr int lw_wait_count(int q, int NQ, int LA, int MT, int QB) {
 //     (output row j + tap row dy) * 18 * 128 + parity * 41 KiB < 64 Ki fits the 16-bit offset field of ds_read.
 // FAST = 2: four whole 8 x 8 images per tile (the UNet's 8 x 8 level): wave w multiplies image w, a fragment covers two image rows (lane bit 3), HALO_W = 10, 400 halo rows,
 // 50 pieces; the same column swizzle is conflict-free for it (simulated over the four 16-lane service groups of ds_read_b128 for every tap and output tile).
-template <bool UP, int BN, bool TRACE = false, int FAST = 0>
+// SUB (round 6): nearest-x2 upsample + 3x3 conv in its SUB-PIXEL form.  Output pixel (2 y + py, 2 x + px) of the upsampled conv reads the 2 x 2 input neighbourhood
+// rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px} with the 3 x 3 filter's taps summed per neighbour (cs_conv_up_fold_pack): 16 multiplies per input pixel and
+// channel pair instead of 36.  The tile is a plain (no UP) FAST tile over INPUT pixels whose k loop runs the 4 taps (py + a, px + b) of its phase out of the same
+// 18 x 18 (FAST 2: 10 x 10) halo; p.w = [4 phases][N][4 Cin]; the phase is tm & 3; the rows scatter to the phase's output pixels (SubRows).  4 steps per chunk: the
+// weight buffer of a tap is no longer a compile-time constant (4 % 3 != 0), the three address registers rotate once per chunk instead.
+template <bool UP, int BN, bool TRACE = false, int FAST = 0, bool SUB = false>
 __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
+    static_assert(!SUB || (!UP && FAST != 0 && !TRACE), "the sub-pixel form is a FAST tile over input pixels");
+    constexpr int TAPS = SUB ? 4 : 9, TL = TAPS - 1;
     unsigned long long tw_entry = 0;
     if (TRACE) tw_entry = __builtin_amdgcn_s_memrealtime();
     // (FAST with the fused nearest-x2 upsample: the 16 x 16 output patch reads an 8 x 8 input patch, HALO_W = 10, 100 halo rows, 13 pieces; output column fx
@@ -985,6 +1015,8 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     int tm, tn;
     tile_of(blockIdx.x, p.e.nblk, p.e.tiles_n, 1, p.e.pn, tm, tn);
     const int n_blk = tn * BN;
+    int phase = 0;
+    if constexpr (SUB) { phase = __builtin_amdgcn_readfirstlane(tm & 3); tm >>= 2; }                   // (the four phases of a patch are neighbours in the grid: they read the same halo)
     int b0, y0, x0;
     if (p.PP == 1) { b0 = tm << (8 - p.trw_shift); y0 = 0; x0 = 0; }
     else {
@@ -993,7 +1025,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         y0 = py << (p.trw_shift - p.tw_shift); x0 = px << p.tw_shift;
     }
     const int c_per = p.NC / p.splits, c_begin = blockIdx.y * c_per, c_end = c_begin + c_per;
-    const int nsteps = c_per * 9;
+    const int nsteps = c_per * TAPS;
     const bool btab = p.e.bias != nullptr && p.splits == 1;          // (uniform: every wave of the workgroup takes the extra barrier or none does)
 
     if (w >= 4) {
@@ -1025,7 +1057,7 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
 #pragma unroll
         for (int j = 0; j < WPL; ++j) {
             const int q = l + 4 * j, r = 8 * (q < NBQ ? q : 0) + lr;
-            wsrc[j] = p.w + (size_t)(n_blk + r) * (9 * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
+            wsrc[j] = p.w + (SUB ? (size_t)phase * p.e.N * (TAPS * p.Cin) : (size_t)0) + (size_t)(n_blk + r) * (TAPS * p.Cin) + (pch ^ ((r >> 1) & 7)) * 8;
         }
         auto issue_w = [&](int c, int t, int buf) {
             const size_t koff = (size_t)t * p.Cin + c * BK;
@@ -1058,28 +1090,41 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
             const bool halo_next = c + 1 < c_end;
             auto step = [&](auto t_tag) {
                 constexpr int T = decltype(t_tag)::value;
-                const bool last = T == 8 && !halo_next;                          // the very last step: nothing to stage, but the compute waves' step is branch-free and has its barrier
+                const bool last = T == TL && !halo_next;                         // the very last step: nothing to stage, but the compute waves' step is branch-free and has its barrier
                 // Stage g + 1 goes into buffer (g + 1) % 3, last read as stage g - 2.  Those reads were ISSUED before K(g - 2) and every compute
                 // wave has since waited for younger ones (LDS returns in order), so they are complete behind K(g - 1): the third buffer is what
                 // lets the compute waves pass their barrier without an lgkmcnt(0) (an exposed LDS latency per step with one computing wave per SIMD).
-                if (!last) issue_w(T == 8 ? c + 1 : c, T == 8 ? 0 : T + 1, wb1);
+                if (!last) issue_w(T == TL ? c + 1 : c, T == TL ? 0 : T + 1, wb1);
                 int nh = 0;
-                if constexpr (T < 8) { if (halo_next) nh = issue_h(c + 1, std::integral_constant<int, T>{}, abn); }
+                if constexpr (!SUB) { if constexpr (T < 8) { if (halo_next) nh = issue_h(c + 1, std::integral_constant<int, T>{}, abn); } }
+                else if constexpr (T < 3) {                                      // (SUB: the eight slices ride the first three of the chunk's four steps)
+                    if (halo_next) {
+                        nh = issue_h(c + 1, std::integral_constant<int, 3 * T>{}, abn) + issue_h(c + 1, std::integral_constant<int, 3 * T + 1>{}, abn);
+                        if constexpr (3 * T + 2 < 8) nh += issue_h(c + 1, std::integral_constant<int, 3 * T + 2>{}, abn);
+                    }
+                }
                 // the weights are needed behind the next barrier; the halo slice just issued is not (vmcnt counts in issue order; step (c, 8) issues
                 // no halo, so the whole halo of chunk c + 1 has landed when that step's barrier opens)
                 unsigned long long s0 = 0, s1 = 0;
                 if (TRACE) s0 = __builtin_readcyclecounter();
                 if (nh == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (nh == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (!SUB || nh == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else if (nh == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (nh == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (nh == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 if (TRACE) s1 = __builtin_readcyclecounter();
                 __builtin_amdgcn_s_barrier();                                    // K(g)
                 if (TRACE) { const unsigned long long s2 = __builtin_readcyclecounter(); tl_wait += s1 - s0; tl_bar += s2 - s1; }
                 ++g; wb1 = wb1 == NWB - 1 ? 0 : wb1 + 1;
             };
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 3>{});
+            if constexpr (!SUB) {
+                step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            }
         }
         if (trl) { g_trace[blockIdx.x * CS_TRACE_W + 9] = tl_wait; g_trace[blockIdx.x * CS_TRACE_W + 10] = tl_bar; }
         __builtin_amdgcn_s_barrier();                                           // E: the stage buffers become the epilogue patches
@@ -1147,29 +1192,47 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
         // first halo row of this lane's fragments: the wave's four output rows of the 16 x 16 patch, or (FAST 2) image wm of the tile, its row 0 or 1 by lane bit 3
         const unsigned rowb = FAST == 2 ? lA_base + (unsigned)(wm * 100 + ((lane >> 3) & 1) * HW_F) * 128 : lA_base + (unsigned)((UP ? 2 : 4) * wm * HW_F) * 128;
         unsigned VA[3][2], VN, WB[NWB][2];
+        if constexpr (!SUB) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int hcol = UP ? ((fxl + d - 1) >> 1) + 1 : fxl + d;                     // halo column read by this lane under tap column d
-            const unsigned sw = (unsigned)((gq ^ (hcol & 7)) << 4);
-            VA[d][0] = rowb + hcol * 128 + sw; VA[d][1] = rowb + hcol * 128 + (sw ^ 64u);
+            for (int d = 0; d < 3; ++d) {
+                const int hcol = UP ? ((fxl + d - 1) >> 1) + 1 : fxl + d;                 // halo column read by this lane under tap column d
+                const unsigned sw = (unsigned)((gq ^ (hcol & 7)) << 4);
+                VA[d][0] = rowb + hcol * 128 + sw; VA[d][1] = rowb + hcol * 128 + (sw ^ 64u);
+            }
         }
-        VN = VA[0][0] + AB_F;
 #pragma unroll
         for (int b3 = 0; b3 < NWB; ++b3) { WB[b3][0] = lB_base + b3 * B_BYTES + wfrag0; WB[b3][1] = lB_base + b3 * B_BYTES + wfrag1; }
         __builtin_amdgcn_s_barrier();                                           // K(-1): stage 0 has landed
-        // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (tap (0, 0), halo buffer 0, weight buffer 0)
-        lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowf(FAST, UP, 0, 0) * ROWB>(fa[0][0], VA[0][0]); lds_read<lw_rowf(FAST, UP, 1, 0) * ROWB>(fa[0][1], VA[0][0]);
-        lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowf(FAST, UP, 2, 0) * ROWB>(fa[0][2], VA[0][0]); lds_read<lw_rowf(FAST, UP, 3, 0) * ROWB>(fa[0][3], VA[0][0]);
+        // the k loop for one (compile-time) first tap (DY0, DX0): (0, 0), or the phase (py, px) of the sub-pixel form
+        auto kloop = [&](auto dy0_tag, auto dx0_tag) {
+        constexpr int DY0 = decltype(dy0_tag)::value, DX0 = decltype(dx0_tag)::value;
+        // SUB: a phase reads two halo columns per lane (DX0, DX0 + 1), its address registers are made here (all three columns of all four phases alive across the
+        // branch cost the FAST 2 form a spill)
+        unsigned VL[2][2];
+        if constexpr (SUB) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int hcol = fxl + d + DX0;
+                const unsigned sw = (unsigned)((gq ^ (hcol & 7)) << 4);
+                VL[d][0] = rowb + hcol * 128 + sw; VL[d][1] = rowb + hcol * 128 + (sw ^ 64u);
+            }
+        }
+#define CS_VA(dx, ks) (SUB ? VL[(dx) - DX0 < 0 ? 0 : (dx) - DX0 > 1 ? 1 : (dx) - DX0][ks] : VA[(dx) > 2 ? 2 : (dx)][ks])
+        VN = CS_VA(DX0, 0) + AB_F;
+        // prologue = the read sequence of items QB .. NQ - 1 with "next" = stage 0 (the first tap, halo buffer 0, weight buffer 0)
+        lds_read<0>(fw[0], WB[0][0]); lds_read<lw_rowf(FAST, UP, 0, DY0) * ROWB>(fa[0][0], CS_VA(DX0, 0)); lds_read<lw_rowf(FAST, UP, 1, DY0) * ROWB>(fa[0][1], CS_VA(DX0, 0));
+        lds_read<2048>(fw[1], WB[0][0]); lds_read<lw_rowf(FAST, UP, 2, DY0) * ROWB>(fa[0][2], CS_VA(DX0, 0)); lds_read<lw_rowf(FAST, UP, 3, DY0) * ROWB>(fa[0][3], CS_VA(DX0, 0));
         lds_read<2 * 2048>(fw[2], WB[0][0]);
         if constexpr (LA == 4) lds_read<3 * 2048>(fw[3], WB[0][0]);
         static_assert(LA == 3 || LA == 4, "prologue reads");
         if (TRACE) { tc_t0 = __builtin_readcyclecounter(); tc_r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         int delta = AB_F;
         for (int c = c_begin; c < c_end; ++c) {
-            static_for<9>([&](auto tc) {                                        // tap T of this chunk; the next step is tap T + 1 or tap 0 of the next chunk (other halo buffer)
+            static_for<TAPS>([&](auto tc) {                                     // tap T of this chunk; the next step is tap T + 1 or the first tap of the next chunk (other halo buffer)
                 constexpr int T = decltype(tc)::value;
-                constexpr int DY = T / 3, DX = T % 3, TN = T == 8 ? 0 : T + 1, DYN = TN / 3, DXN = TN % 3;
-                constexpr int WBC = T % 3, WBN = TN % 3;
+                constexpr int TN = T == TL ? 0 : T + 1;
+                constexpr int DY = SUB ? DY0 + T / 2 : T / 3, DX = SUB ? DX0 + T % 2 : T % 3, DYN = SUB ? DY0 + TN / 2 : TN / 3, DXN = SUB ? DX0 + TN % 2 : TN % 3;
+                constexpr int WBC = T % 3, WBN = (T + 1) % 3;                   // (9 taps: (8 + 1) % 3 == 0, the first tap's buffer; SUB: the registers rotate per chunk)
                 static_for<NQ>([&](auto qc) {
                     constexpr int q = decltype(qc)::value, ks = q / NT, i = q - ks * NT;
                     if constexpr (q == QB) __builtin_amdgcn_s_barrier();       // K(g): stage g + 1 has landed
@@ -1179,13 +1242,13 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
                         else if constexpr (r < NQ) lds_read<(r - NT) * 2048>(fw[r % RS], WB[WBC][1]);
                         else lds_read<(r - NQ) * 2048>(fw[r % RS], WB[WBN][0]);
                     }
-                    if constexpr (q < MT) lds_read<lw_rowf(FAST, UP, q, DY) * ROWB>(fa[1][q], VA[DX][1]);
+                    if constexpr (q < MT) lds_read<lw_rowf(FAST, UP, q, DY) * ROWB>(fa[1][q], CS_VA(DX, 1));
                     if constexpr (q == QB || q == QB + 1) {
                         constexpr int j0 = (q - QB) * 2;
-                        if constexpr (T == 8) {
-                            lds_read<lw_rowf(FAST, UP, j0, 0) * ROWB>(fa[0][j0], VN); lds_read<lw_rowf(FAST, UP, j0 + 1, 0) * ROWB>(fa[0][j0 + 1], VN);
+                        if constexpr (T == TL) {
+                            lds_read<lw_rowf(FAST, UP, j0, DY0) * ROWB>(fa[0][j0], VN); lds_read<lw_rowf(FAST, UP, j0 + 1, DY0) * ROWB>(fa[0][j0 + 1], VN);
                         } else {
-                            lds_read<lw_rowf(FAST, UP, j0, DYN) * ROWB>(fa[0][j0], VA[DXN][0]); lds_read<lw_rowf(FAST, UP, j0 + 1, DYN) * ROWB>(fa[0][j0 + 1], VA[DXN][0]);
+                            lds_read<lw_rowf(FAST, UP, j0, DYN) * ROWB>(fa[0][j0], CS_VA(DXN, 0)); lds_read<lw_rowf(FAST, UP, j0 + 1, DYN) * ROWB>(fa[0][j0 + 1], CS_VA(DXN, 0));
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(lw_wait_count(q, NQ, LA, MT, QB)));
@@ -1196,9 +1259,28 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
                 });
             });
             // the next chunk lives in the other halo buffer
+            if constexpr (SUB) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { VA[d][0] += delta; VA[d][1] += delta; }
+                for (int d = 0; d < 2; ++d) { VL[d][0] += delta; VL[d][1] += delta; }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { VA[d][0] += delta; VA[d][1] += delta; }
+            }
             VN -= delta; delta = -delta;
+            if constexpr (SUB) {                                                // stage 4 (c + 1) + t lives in weight buffer (c + 1 + t) % 3: what was buffer [1] is the next chunk's [0]
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) { const unsigned t0 = WB[0][k2]; WB[0][k2] = WB[1][k2]; WB[1][k2] = WB[2][k2]; WB[2][k2] = t0; }
+            }
+        }
+        };
+#undef CS_VA
+        if constexpr (!SUB) kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        else {
+            // uniform branch on the tile's phase: four copies of the loop, one executed
+            if (phase == 0) kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            else if (phase == 1) kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            else if (phase == 2) kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            else kloop(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         }
     } else {
     __builtin_amdgcn_s_barrier();                                               // K(-1): stage 0 has landed
@@ -1270,6 +1352,12 @@ __global__ __launch_bounds__(512, 2) void conv3_lw_kernel(HaloParams p) {
     }
     __builtin_amdgcn_s_barrier();                                               // E
     if (btab) __builtin_amdgcn_s_barrier();                                     // E2: loader wave 0 has put the tile's bias values into LDS
+    if constexpr (SUB) {
+        // (launch_igemm_impl: never split-K) the tile's rows are INPUT pixels; phase (py, px) writes output pixels (2 y + py, 2 x + px)
+        const SubRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift, phase >> 1, phase & 1, phase * ((p.Ho * p.Wo) >> 8)};
+        igemm_epilogue<false, NT, MT, NT, SubRows, 2, 0, true>(p.e, acc, rows, n_blk, lane, smem + w * 11264, btab ? smem + 4 * 11264 : nullptr);
+        return;
+    }
     const PatchRows rows{wm * 64, b0, y0, x0, p.B, p.Ho, p.Wo, p.tw_shift, p.trw_shift};
     if (p.splits == 1) {
         igemm_epilogue<false, NT, MT, NT, PatchRows, 2, 0, true>(p.e, acc, rows, n_blk, lane, smem + w * 11264, btab ? smem + 4 * 11264 : nullptr);
@@ -2163,6 +2251,35 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
     const bool pow2 = TW == 8 || TW == 16;
     const bool geom_ok = pow2 && TH >= 2 && (TH & (TH - 1)) == 0 && Wo % TW == 0 && Ho % TH == 0 && Ho == a.Ho && Wo == a.Wo &&
                          (!a.upsample || (TH % 2 == 0 && TW % 2 == 0 && TW / 2 + 2 >= 10));
+    // round 6: nearest-x2 upsample + 3x3 conv in the sub-pixel form (conv3_lw_kernel<.., SUB>): tiles over INPUT pixels, four phases, 4 of 9 taps each with the
+    // filter's taps pre-summed (a.w_up_sub from conv_up_fold_pack_host: one more fp16 rounding of the weights, which is why the caller decides -- tune().up_fold)
+    if (conv3 && a.upsample && a.w_up_sub && a.stride == 1 && a.c1 == 0 && a.N % 160 == 0 && !a.geglu && !a.res && !a.temb && tune().conv_lw != 0 &&
+        cin / BK <= LW_ZERO_CHUNKS && Ho == a.Ho && Wo == a.Wo && !(tune().debug & 16384)) {
+        const bool f1 = a.Wi % 16 == 0 && a.Hi % 16 == 0, f2 = a.Wi == 8 && a.Hi == 8;
+        if (f1 || f2) {
+            const int TWi = f1 ? 16 : 8, TRW = f1 ? 256 : 64, IPT = 256 / TRW;
+            const int PX = a.Wi / TWi, PY = a.Hi / TWi, PP = PX * PY;
+            const int tiles_lo = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP, tiles_m = 4 * tiles_lo, tiles_n = a.N / 160;
+            HaloParams h;
+            h.HALO_W = TWi + 2; h.HALO_IMG = (TWi + 2) * (TWi + 2); h.NHALO = IPT * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
+            h.e = p; h.e.w = a.w_up_sub; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n; h.e.row_stats = nullptr; h.e.pn = choose_xcd_grid(tiles_m, tiles_n, a_bytes, w_bytes * 16.0 / 9.0);
+            h.x = a.a0; h.w = a.w_up_sub; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = cin / BK; h.Ho = Ho; h.Wo = Wo;
+            h.tw_shift = f1 ? 4 : 3; h.trw_shift = f1 ? 8 : 6; h.PX = PX; h.PP = PP; h.splits = 1; h.partial = nullptr; h.sched = 0;
+            typedef void (*lw_fn)(HaloParams);
+            static const lw_fn sub[2] = {conv3_lw_kernel<false, 160, false, 1, true>, conv3_lw_kernel<false, 160, false, 2, true>};
+            static bool configured_sub = false;
+            if (!configured_sub) {
+                for (lw_fn f : sub)
+                    CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128))));
+                configured_sub = true;
+            }
+            const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)160 * 128);
+            hipLaunchKernelGGL(sub[f1 ? 0 : 1], dim3(h.e.nblk, 1), dim3(512), llw, s, h);
+            CS_CHECK_LAUNCH();
+            li->gn_done = stats_ok;
+            return CS_OK;
+        }
+    }
     if (use_halo && conv3 && a.stride == 1 && a.c1 == 0 && hbn && !a.geglu && geom_ok) {
         const int TRW = TH * TW, IPT = 256 / TRW;                       // output pixels per image in a tile; images per tile
         const int PX = Wo / TW, PY = Ho / TH, PP = PX * PY;

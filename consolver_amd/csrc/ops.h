@@ -42,6 +42,7 @@ struct TuneSet {
     // 1: conv_in runs on the MFMA conv kernel (latents -> NHWC with the 4 channels zero-padded to 64, weights padded alike): coalesced stores, the lo plane and the
     // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
     int conv_in_mfma = 1;
+    int up_fold = 1;        // the UNet's upsamplers (nearest x2 + 3x3 conv) in the sub-pixel form on pre-summed taps (IgemmArgs::w_up_sub): 0 never, 1 in forwards on one fp16 plane, 2 always
     int conv_out_mfma = 1;  // 1: the 16 x 16-patch conv_out kernels (UNet 320 -> 4, VAE 128 -> 3) on v_mfma_f32_16x16x32_f16 (conv_out_mfma_kernel), 0: the v_dot2 patch kernel
     int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 };
@@ -97,9 +98,14 @@ struct IgemmArgs {
     //   consumer: ln_stats (that buffer), ln_groups = G, ln_eps, ln_s, ln_b (fp32 [N]); w = W'; bias is ignored (b' holds it).  The row length is c0.
     float* row_stats; int* row_stats_groups;
     const float* ln_stats; int ln_groups; float ln_eps; const float* ln_s; const float* ln_b;
+    // optional (upsample != 0, 3x3): the filter in its sub-pixel form, [4][N][4 c0] from conv_up_fold_pack_host.  When given (and the shape fits: input 8 x 8 or a
+    // multiple of 16 x 16, N % 160 == 0, no residual / temb) the layer runs 16 instead of 36 multiplies per input pixel on pre-summed taps -- weights rounded to fp16
+    // once more, so the CALLER decides where that is acceptable (the UNet executor: one-plane forwards only, tune().up_fold).
+    const f16* w_up_sub;
 };
 int launch_igemm(const IgemmArgs& a, hipStream_t s);
 double igemm_flops(const IgemmArgs& a);
+void conv_up_fold_pack_host(const f16* w, int N, int Cin, f16* out);     // w [N][9 Cin] -> out [4][N][4 Cin]: the sub-pixel filters of IgemmArgs::w_up_sub
 void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out);
 // (sum, sum of squares) per row of x [M][C] (+ x_lo): stats[M][1][2]; the statistics pass behind IgemmArgs::row_stats and after the fused cross-attention block
 int launch_row_stats(const f16* x, const f16* x_lo, int M, int C, float* stats, hipStream_t s, int lo8 = 0);

@@ -23,6 +23,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"x2_split_a", &TuneSet::x2_split_a, 0, 3, false}, {"x2_sc_skip", &TuneSet::x2_sc_skip, 0, 0xffff, false}, {"ln_fold", &TuneSet::ln_fold, 0, 1, false}, {"xcd_grid", &TuneSet::xcd_grid, 0, 1, false}, {"epi_fast", &TuneSet::epi_fast, 0, 3, false}, {"lo8", &TuneSet::lo8, 0, 1, false},
         {"conv_in_mfma", &TuneSet::conv_in_mfma, 0, 1, false}, {"xattn_tile", &TuneSet::xattn_tile, 64, 128, true},
         {"conv_out_mfma", &TuneSet::conv_out_mfma, 0, 1, false},
+        {"up_fold", &TuneSet::up_fold, 0, 2, false},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;
@@ -89,6 +90,23 @@ int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int H
     a.temb = (const f16*)temb; a.temb_stride = temb_stride; a.res = (const f16*)res; a.out = (f16*)out;
     a.splitk_ws = (float*)splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes; a.gn_stats = gn_stats;
     if (gn_stats && (a.Ho * a.Wo) % 64) CS_FAIL(CS_E_SHAPE, "conv2d_gn: Ho * Wo = %d must be a multiple of 64", a.Ho * a.Wo);
+    return launch_igemm(a, (hipStream_t)stream);
+}
+
+int cs_op_conv_up_fold_pack(const void* w, int N, int Cin, void* out) {
+    if (!w || !out || N <= 0 || Cin <= 0) CS_FAIL(CS_E_ARG, "conv_up_fold_pack: w [N][9 Cin], out [4][N][4 Cin] (host pointers)");
+    conv_up_fold_pack_host((const f16*)w, N, Cin, (f16*)out);
+    return CS_OK;
+}
+
+int cs_op_conv_up_sub(const void* x, int Cin, int B, int Hi, int Wi, const void* w, const void* w_sub, const void* bias, int N, void* out, float* gn_stats,
+                      void* stream) {
+    IgemmArgs a{};
+    a.a0 = (const f16*)x; a.c0 = Cin; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.taps = 9; a.stride = 1; a.upsample = 1; a.N = N;
+    a.w = (const f16*)w; a.w_up_sub = (const f16*)w_sub; a.bias = (const f16*)bias; a.out = (f16*)out; a.gn_stats = gn_stats;
+    if (!w_sub) CS_FAIL(CS_E_ARG, "conv_up_sub: w_sub (cs_op_conv_up_fold_pack) required");
+    if (!((Hi == 8 && Wi == 8) || (Hi % 16 == 0 && Wi % 16 == 0)) || N % 160 || Cin % 64)
+        CS_FAIL(CS_E_SHAPE, "conv_up_sub: input 8 x 8 or a multiple of 16 x 16, N %% 160 == 0, Cin %% 64 == 0 (got %d x %d, N %d, Cin %d)", Hi, Wi, N, Cin);
     return launch_igemm(a, (hipStream_t)stream);
 }
 

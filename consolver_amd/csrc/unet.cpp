@@ -24,6 +24,31 @@
 #include <cstring>
 #include <cmath>
 
+// the sub-pixel form of nearest-x2 upsample + 3x3 conv (pad 1): output pixel (2 y + py, 2 x + px) reads input rows {y - 1 + py, y + py} and columns
+// {x - 1 + px, x + px}; neighbour (a, b) of phase (py, px) carries the SUM of the filter taps that land on it:
+//   rows:    py = 0: a = 0 <- dy {0}, a = 1 <- dy {1, 2};    py = 1: a = 0 <- dy {0, 1}, a = 1 <- dy {2}       (same for columns with px, b, dx)
+// w [N][9 Cin] (tap-major) -> out [4 phases = 2 py + px][N][4 Cin] (neighbour-major: 2 a + b), summed in fp32 and rounded to fp16 ONCE.
+void conv_up_fold_pack_host(const f16* w, int N, int Cin, f16* out) {
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b) {
+                const int dy0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), dy1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+                const int dx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), dx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+                for (int n = 0; n < N; ++n) {
+                    f16* dst = out + ((size_t)ph * N + n) * (4 * Cin) + (size_t)(2 * a + b) * Cin;
+                    const f16* src = w + (size_t)n * (9 * Cin);
+                    for (int c = 0; c < Cin; ++c) {
+                        float acc = 0.f;
+                        for (int dy = dy0; dy <= dy1; ++dy)
+                            for (int dx = dx0; dx <= dx1; ++dx) acc += (float)src[(size_t)(dy * 3 + dx) * Cin + c];
+                        dst[c] = (f16)acc;
+                    }
+                }
+            }
+    }
+}
+
 // LN(h) W^T + b = rstd (h W'^T - mean s) + b':  W' = fp16(W diag(gamma)), s = row sums of W' (of the ROUNDED values: it cancels exactly what the MFMAs summed),
 // b' = W beta + b.  Host memory; w [N][K] fp16 rows, bias may be null.  Shared by the executor's weight packing and cs_op_ln_fold_pack.
 void ln_fold_pack_host(const f16* w, const f16* bias, const f16* gamma, const f16* beta, int N, int K, f16* w_out, float* s_out, float* b_out) {
@@ -44,7 +69,7 @@ namespace {
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<f16> data; };
 
-struct Conv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; };
+struct Conv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; f16* w_sub = nullptr; };     // w_sub: an upsampler's sub-pixel filters (IgemmArgs::w_up_sub)
 struct Norm { f16* g = nullptr; f16* b = nullptr; int c = 0; float eps = 1e-5f; };
 struct Resnet { Norm n1, n2; Conv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0, temb_off = 0; int sc_index = -1; };      // sc_index: position among the shortcut convs in creation order (knob x2_sc_skip)
 struct LnLinear { f16* w = nullptr; float* s = nullptr; float* b = nullptr; };     // a linear layer with the LayerNorm in front of it folded in (IgemmArgs::ln_*)
@@ -342,6 +367,7 @@ struct Run {
     int v_conv_in_mfma = 1;        // snapshot of tune().conv_in_mfma
     int v_lo8 = 1;                 // snapshot of tune().lo8
     int v_sc_skip = 0;             // snapshot of tune().x2_sc_skip
+    int v_up_fold = 1;             // snapshot of tune().up_fold
     // the transformer hidden state's lo plane as bytes: only where every consumer of that plane adds it (folded LayerNorms: ln_kernel reads an fp16 lo plane;
     // proj_out not reading hi + lo as its operand)
     bool fold_of(const Xformer& X) const { return v_ln_fold != 0 && !((u->ln_unfold_mask >> X.index) & 1u); }
@@ -419,11 +445,16 @@ struct Run {
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.temb = temb; a.temb_stride = tstride; a.res = res.hi; a.out = out.hi; a.geglu = 0;
         a.res_lo = res.lo; a.out_lo = out.lo; a.lo8 = lo8_of(res, out);
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
+        // an upsampler in its sub-pixel form: pre-summed taps are one more fp16 rounding of the weights (~2^-12 of the output, straight onto the stream):
+        // in the forwards that run on one fp16 plane, whose stream is rounded to fp16 sixty times anyway; the split stream keeps the exact filter
+        const bool sub = up && c.w_sub && (v_up_fold == 2 || (v_up_fold == 1 && !split)) && !res.hi && !temb &&
+                         ((Hi == 8 && Wi == 8) || (Hi % 16 == 0 && Wi % 16 == 0));
+        if (sub) a.w_up_sub = c.w_sub;
         const double M = (double)B * Ho * Wo;
         const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
         // algo_flops: the REFERENCE graph's count for this layer where the executed form pads it (conv_in on the MFMA conv runs 64 input channels for 4):
         // cs_unet_flops is the algorithmic count of SURVEY 8(d), independent of how a layer is executed
-        launch(c.taps == 9 ? P_CONV3 : P_GEMM, (algo_flops >= 0 && !count_executed) ? algo_flops : igemm_flops(a) * ((count_executed && a.a0_lo) ? 2.0 : 1.0), bytes, [&] { return launch_igemm(a, s); });
+        launch(c.taps == 9 ? P_CONV3 : P_GEMM, (algo_flops >= 0 && !count_executed) ? algo_flops : igemm_flops(a) * ((count_executed && a.a0_lo) ? 2.0 : (count_executed && sub) ? 4.0 / 9.0 : 1.0), bytes, [&] { return launch_igemm(a, s); });
     }
     void linear(const f16* x, int M, int K, const f16* w, const f16* b, int N, St res, St out, int geglu, float* row_stats = nullptr, int* row_groups = nullptr) {
         IgemmArgs a{};
@@ -655,7 +686,7 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     u->dry_flops = 0;
     Run R{u, s, dry, B};
     R.split = u->residual == CS_RESIDUAL_F16X2; R.v_split_a = tune().x2_split_a; R.count_executed = count_executed;
-    R.v_lo8 = var.lo8; R.v_sc_skip = tune().x2_sc_skip; R.calib = dry ? nullptr : calib;
+    R.v_lo8 = var.lo8; R.v_sc_skip = tune().x2_sc_skip; R.v_up_fold = tune().up_fold; R.calib = dry ? nullptr : calib;
     R.v_gn_fuse = var.gn_fuse; R.v_xattn_fused = var.xattn_fused; R.v_cfg_share = var.cfg_share; R.v_ln_fold = var.ln_fold; R.v_conv_in_mfma = var.conv_in_mfma;
     R.ctx = ctx; R.kv = (f16*)ws; R.gn_ws = (float*)(ws + kvb);
     R.sk_ws = (float*)(ws + kvb + gn_ws_bytes(u, B)); R.sk_bytes = sk_ws_bytes(u, B);
@@ -867,7 +898,17 @@ int cs_unet_finalize(CsUNet* u) {
             if (c.up_has_attn[i]) ok = ok && make_xformer(u, b + ".attentions." + std::to_string(j), u->up_att[i][j]);
         }
         u->has_up[i] = i < 3;
-        if (i < 3) ok = ok && make_conv(u, b + ".upsamplers.0.conv", u->up_samp[i]);
+        if (i < 3) {
+            ok = ok && make_conv(u, b + ".upsamplers.0.conv", u->up_samp[i]);
+            // the same filter in its sub-pixel form (4 phases x 4 summed taps: 16 / 9 of the bytes), for the forwards that run on one fp16 plane (tune().up_fold)
+            Conv& uc = u->up_samp[i];
+            if (ok && uc.taps == 9 && uc.cout % 160 == 0 && uc.cin % 64 == 0) {
+                std::vector<f16> sub((size_t)4 * uc.cout * 4 * uc.cin);
+                conv_up_fold_pack_host(pack_conv(T(u, b + ".upsamplers.0.conv.weight")).data(), uc.cout, uc.cin, sub.data());
+                uc.w_sub = upload(u, sub);
+                ok = ok && uc.w_sub;
+            }
+        }
     }
     u->tp_total = (int)tpb.size();
     u->tp_w = upload(u, tpw); u->tp_b = upload(u, tpb);

@@ -53,6 +53,29 @@ def conv2d(x0, w_packed, bias=None, x1=None, taps=9, stride=1, upsample=False, t
     return out
 
 
+def conv_up_fold_pack(w_packed):
+    """the sub-pixel filters of a nearest-x2 upsample + 3x3 conv: w_packed [N, 9 Cin] (tap-major) -> [4, N, 4 Cin] on the CPU (cs_op_conv_up_fold_pack;
+    the executor packs its three upsamplers with the same function)"""
+    w = w_packed.detach().to("cpu", torch.float16).reshape(w_packed.shape[0], -1).contiguous()
+    N, K = w.shape
+    if K % 9:
+        raise ValueError("conv_up_fold_pack: a 3x3 filter packed [N, 9 Cin]")
+    out = torch.empty(4, N, 4 * (K // 9), dtype=torch.float16)
+    L.check(L.lib().cs_op_conv_up_fold_pack(C.c_void_p(w.data_ptr()), N, K // 9, C.c_void_p(out.data_ptr())))
+    return out
+
+
+def conv_up_sub(x, w_packed, w_sub, bias=None, gn_stats=False):
+    """nearest-x2 upsample + 3x3 conv through the sub-pixel kernel (cs_op_conv_up_sub): x [B, Hi, Wi, Cin] -> [B, 2 Hi, 2 Wi, N]"""
+    _f16(x, "x")
+    B, Hi, Wi, Cin = x.shape
+    N = w_packed.shape[0]
+    out = torch.empty(B, 2 * Hi, 2 * Wi, N, dtype=torch.float16, device=x.device)
+    st = torch.zeros(B, 4 * Hi * Wi // 64, N // 2, 2, dtype=torch.float32, device=x.device) if gn_stats else None
+    L.check(L.lib().cs_op_conv_up_sub(L.ptr(x), Cin, B, Hi, Wi, L.ptr(w_packed), L.ptr(w_sub), L.ptr(bias), N, L.ptr(out), L.ptr(st), L.stream_ptr(x.device)))
+    return (out, st) if gn_stats else out
+
+
 def linear(x, w, bias=None, res=None, geglu=False, out=None):
     _f16(x, "x")
     M, K = x.shape

@@ -37,6 +37,16 @@ int cs_op_conv2d(const void* x0, int c0, const void* x1, int c1, int B, int Hi, 
 int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int Hi, int Wi, int taps, int stride, int upsample,
                     const void* w, const void* bias, int N, const void* temb, int temb_stride, const void* res, void* out,
                     void* splitk_ws, size_t splitk_ws_bytes, float* gn_stats, void* stream);
+/* nearest-x2 upsample + 3x3 conv in its SUB-PIXEL form (round 6; replaces the upsample = 1 call of cs_op_conv2d for the UNet's three upsamplers,
+ * reference: diffusers Upsample2D = F.interpolate(scale 2, nearest) + Conv2d(3, pad 1), called from gen_pretrain/pipeline.py:1058-1066's UNet).  Output pixel
+ * (2 y + py, 2 x + px) reads the 2 x 2 input neighbourhood rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px}; the filter taps that land on one neighbour
+ * are summed ONCE on the host: cs_op_conv_up_fold_pack: w [N][9 Cin] (tap-major, host) -> out [4 phases = 2 py + px][N][4 Cin] (host), sums in fp32, one rounding
+ * to fp16.  16 multiplies per input pixel and channel pair instead of 36; the results differ from the plain form by that one rounding of the weights (~2^-12).
+ * cs_op_conv_up_sub: x NHWC [B, Hi, Wi, Cin] -> out [B, 2 Hi, 2 Wi, N]; input 8 x 8 or a multiple of 16 x 16, N % 160 == 0, Cin % 64 == 0; w = the plain packed
+ * filter (unused by the kernel, kept for the shapes the sub-pixel kernel does not take), gn_stats as cs_op_conv2d_gn or null. */
+int cs_op_conv_up_fold_pack(const void* w, int N, int Cin, void* out);
+int cs_op_conv_up_sub(const void* x, int Cin, int B, int Hi, int Wi, const void* w, const void* w_sub, const void* bias, int N, void* out, float* gn_stats,
+                      void* stream);
 
 /* out[M,N] = x[M,K] w[N,K]^T + bias + res ; geglu != 0: w rows pre-permuted in (16 value | 16 gate)
  * blocks (see cs_op_geglu_pack) and out[M,N/2] = value * gelu(gate). */
@@ -201,6 +211,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                shortcuts at the 8 x 8 / 16 x 16 levels whose hi + lo operand buys the least: -0.12 ms per forward, +3.5 % on the tightest gated number);
  *   "lo8":       1 (default) inside cs_unet_forward (CS_RESIDUAL_F16X2) the transformer blocks' hidden state carries an 8-bit e5m2 lo plane (cs_op_linear_lo8),
  *                0 an fp16 one;
+ *   "up_fold": the UNet's three upsamplers in the sub-pixel form (cs_op_conv_up_sub: 16 instead of 36 multiplies per input pixel, taps summed on the host and
+ *                rounded to fp16 once more): 0 never, 1 (default) in forwards whose residual stream is one fp16 plane, 2 also on the split stream;
  *   "conv_out_mfma": 1 (default) the 16 x 16-patch conv_out kernels (cs_op_conv_out) on the matrix cores, 0 the v_dot2 patch kernel;
  *   "conv_in_mfma": 1 (default) the UNet's conv_in runs on the MFMA conv kernel over latents zero-padded to 64 channels, 0 the scalar conv_in kernel;
  *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),

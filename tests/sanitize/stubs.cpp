@@ -43,6 +43,7 @@ int launch_igemm(const IgemmArgs& a, hipStream_t) {
     const size_t Min = (size_t)a.B * a.Hi * a.Wi, M = (size_t)a.B * a.Ho * a.Wo, Nout = a.geglu ? a.N / 2 : a.N;
     rd(a.a0, Min * a.c0 * 2); rd(a.a1, Min * a.c1 * 2); rd(a.a0_lo, Min * a.c0 * 2); rd(a.a1_lo, Min * a.c1 * 2);
     rd(a.w, (size_t)a.N * a.taps * (a.c0 + a.c1) * 2); rd(a.bias, (size_t)a.N * 2);
+    if (a.w_up_sub) rd(a.w_up_sub, (size_t)4 * a.N * 4 * a.c0 * 2);            // (an upsampler's sub-pixel filters: [4][N][4 Cin])
     if (a.temb) rd(a.temb, ((size_t)(a.temb_stride ? a.B - 1 : 0) * a.temb_stride + a.N) * 2);
     const size_t lob = a.lo8 ? 1 : 2;                  // (an 8-bit lo plane holds one byte per element: the executor allocates exactly that)
     rd(a.res, M * Nout * 2); rd(a.res_lo, M * Nout * lob);

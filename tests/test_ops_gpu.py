@@ -194,6 +194,63 @@ def test_conv3x3_loader_wave_kernel_fused_upsample(B, H, cin, N):
     assert float((nchw(out) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
 
 
+SUBPIXEL_CASES = [   # B, H (input), cin, N
+    (5, 8, 128, 160),      # four whole 8 x 8 input images per tile (the ragged last tile holds one)
+    (2, 8, 64, 320),
+    (1, 16, 64, 320),      # one 16 x 16 input patch per image
+    (3, 16, 192, 160),
+    (2, 32, 128, 160),     # four patches per image
+    (1, 48, 64, 160),      # nine patches: not a power of two per row
+]
+
+
+@pytest.mark.parametrize("B,H,cin,N", SUBPIXEL_CASES)
+def test_upsample_conv_subpixel_form(B, H, cin, N):
+    """cs_op_conv_up_sub (round 6): nearest x2 + 3x3 conv as four 2 x 2-tap phases over the INPUT pixels on pre-summed taps.  (1) small-integer data, where every
+    sum is exact in fp16 / fp32: bit-identical to the fused-upsample kernel -- the indexing, the borders, the phase scatter; (2) random data: within the fp16
+    rounding of the summed weights of the fp64 reference and of the plain kernel; (3) the GroupNorm statistics of the epilogue equal the sums of what it stored."""
+    gi = torch.Generator().manual_seed(11)
+    xi = torch.randint(-2, 3, (B, H, H, cin), generator=gi).to(torch.float16).to(DEV)
+    wi = torch.randint(-1, 2, (N, cin, 3, 3), generator=gi).to(torch.float16).to(DEV)
+    bi = torch.randint(-3, 4, (N,), generator=gi).to(torch.float16).to(DEV)
+    wp = ops.pack_conv_weight(wi)
+    ws = ops.conv_up_fold_pack(wp).to(DEV)
+    assert ws.shape == (4, N, 4 * cin)
+    assert float(ws.float().abs().max()) <= 4.0                     # (sums of 1, 2 or 4 taps)
+    plain = ops.conv2d(xi, wp, bi, upsample=True)
+    sub = ops.conv_up_sub(xi, wp, ws, bi)
+    ref = F.conv2d(F.interpolate(nchw(xi), scale_factor=2.0, mode="nearest"), wi.float(), bi.float(), padding=1)
+    assert float(ref.abs().max()) < 2048                            # integers below 2^11: exact in fp16
+    assert torch.equal(nchw(plain), ref)
+    assert torch.equal(sub, plain)
+    # random data
+    x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)
+    wp = ops.pack_conv_weight(w)
+    ws = ops.conv_up_fold_pack(wp).to(DEV)
+    ref = F.conv2d(F.interpolate(nchw(x).double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1).float()
+    plain = ops.conv2d(x, wp, b, upsample=True)
+    sub, st = ops.conv_up_sub(x, wp, ws, b, gn_stats=True)
+    again = ops.conv_up_sub(x, wp, ws, b)
+    assert torch.equal(sub, again)
+    e_plain, e_sub = rel_l2(nchw(plain), ref), rel_l2(nchw(sub), ref)
+    print(f"\nB={B} {H}x{H} {cin}->{N}: plain {e_plain:.3e}, sub-pixel {e_sub:.3e} vs fp64")
+    assert e_plain < 4e-4 and e_sub < 6e-4, (e_plain, e_sub)        # one fp16 rounding of the output; + one of the summed weights
+    assert float((nchw(sub) - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+    Ho = 2 * H
+    o = sub.float().reshape(B, Ho * Ho, N // 2, 2)
+    want_sum, want_sq = o.sum(dim=(1, 3)).double(), (o * o).sum(dim=(1, 3)).double()
+    got = st.double().sum(dim=1)
+    scale = want_sq.sqrt().clamp_min(1.0)
+    assert float(((got[..., 0] - want_sum).abs() / (scale * (Ho * Ho) ** 0.5)).max()) < 2e-5
+    assert float(((got[..., 1] - want_sq).abs() / want_sq.clamp_min(1e-6)).max()) < 2e-5
+    assert float(st.abs().reshape(B, -1, N).sum(-1).min()) > 0       # every 64-pixel block of every sample was written by exactly one wave
+    g, bt = (1 + 0.2 * rnd(N, seed=7)), 0.1 * rnd(N, seed=8)
+    flat = sub.reshape(B, Ho * Ho, N)
+    a = ops.group_norm(flat, g, bt, 32 if (N // 32) % 2 == 0 else 16, 1e-5, True)
+    c = ops.group_norm(flat, g, bt, 32 if (N // 32) % 2 == 0 else 16, 1e-5, True, stats0=st)
+    assert rel_l2(c.float(), a.float()) < 2e-4
+
+
 @pytest.mark.parametrize("B,H,cin,N", [(8, 8, 1280, 320), (2, 16, 512, 320), (3, 8, 256, 160), (2, 16, 512, 256), (4, 8, 256, 128)])
 def test_conv3x3_loader_wave_kernel_split_k(B, H, cin, N):
     x, w, b = rnd(B, H, H, cin, seed=1), rnd(N, cin, 3, 3, seed=2, scale=(9 * cin) ** -0.5), rnd(N, seed=3, scale=0.1)

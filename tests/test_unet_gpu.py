@@ -216,6 +216,41 @@ def test_unet_at_sizes_where_only_some_levels_take_the_fused_paths(sample_size, 
     assert torch.isfinite(got).all() and err < bound, err
 
 
+def test_upsamplers_in_the_subpixel_form_on_the_one_plane_stream():
+    """round 6 (knob up_fold, default 1): in forwards whose residual stream is one fp16 plane the upsamplers run the sub-pixel form on pre-summed taps
+    (cs_op_conv_up_sub: 4 / 9 of the multiplies; the summed weights are rounded to fp16 once more).  32 x 32 latents: the 8 x 8 -> 16 x 16 upsampler takes the
+    four-images-per-tile form, 16 x 16 -> 32 x 32 the one-patch form, 4 x 4 -> 8 x 8 stays on the fused-upsample kernel.  Against the fp32 oracle the two forms are
+    the same forward (the one-plane stream's own error is 1.5e-3); the split stream does not use the form unless asked (up_fold = 2)."""
+    cfg = dict(layers_per_block=1, sample_size=32)
+    u, _ = get_unet(cfg, seed=7, residual="f16")
+    orc = get_oracle(cfg, seed=7)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 4, 32, 32, generator=g).half()
+    ctx = synthetic_prompt_embeds(2, seed=13).half()
+    t = 401
+    want = orc(torch.cat([lat.float()] * 2), t, ctx.float())
+    run = lambda: u(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False)[0].clone()
+    try:
+        u.set_tuning("up_fold", 0); plain = run(); fl0 = u.flops_executed(1, dup=2)
+        u.set_tuning("up_fold", 1); sub = run(); fl1 = u.flops_executed(1, dup=2)
+        assert torch.equal(run(), sub)
+        e0, e1 = rel_l2(plain, want), rel_l2(sub, want)
+        print(f"\none-plane forward vs the fp32 oracle: fused-upsample kernels {e0:.3e}, sub-pixel upsamplers {e1:.3e}; between them {rel_l2(sub, plain):.3e}")
+        assert not torch.equal(sub, plain)
+        assert e1 < 1.1 * e0 and e0 < 1.8e-3, (e0, e1)
+        # executed FLOPs: the two eligible upsamplers at 4 / 9 (8 x 8 -> 16 x 16 at 1280 channels, 16 x 16 -> 32 x 32 at 640; CFG batch 2)
+        saved = 2 * 2.0 * 9 * (16 * 16 * 1280 * 1280 + 32 * 32 * 640 * 640) * 5.0 / 9.0
+        assert abs((fl0 - fl1) - saved) < 1e-6 * fl0, (fl0 - fl1, saved)
+        # the split stream keeps the exact filters
+        u.set_residual_precision("f16x2")
+        a = run(); u.set_tuning("up_fold", 0); b = run()
+        assert torch.equal(a, b)
+        u.set_tuning("up_fold", 2); c = run()
+        assert not torch.equal(c, a) and rel_l2(c, want) < 1.05 * rel_l2(a, want) + 2e-5, (rel_l2(c, want), rel_l2(a, want))
+    finally:
+        u.clear_tuning()
+
+
 @pytest.mark.parametrize("residual", ["f16x2", "f16"])
 def test_forward_does_not_read_uninitialised_workspace(residual):
     """every byte the forward reads from its workspace must have been written by THIS forward (or be the cached cross-attention K/V): the workspace is

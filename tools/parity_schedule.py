@@ -6,6 +6,10 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import test_parity_e2e_gpu as T
+from consolver_amd import ops
+for kv in os.environ.get("CS_TUNE", "").split(","):          # library knobs for the whole run: CS_TUNE="up_fold=2,..."
+    if "=" in kv:
+        ops.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 
 g, B, wseed = 3.0, int(os.environ.get("CS_SCHED_B", "1")), int(os.environ.get("CS_SCHED_SEED", "7"))
 NS = [int(v) for v in os.environ.get("CS_SCHED_NS", "4,8,12,15").split(",")]
