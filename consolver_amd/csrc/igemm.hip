@@ -2253,28 +2253,29 @@ static int launch_igemm_impl(const IgemmArgs& a, hipStream_t s, LaunchInfo* li) 
                          (!a.upsample || (TH % 2 == 0 && TW % 2 == 0 && TW / 2 + 2 >= 10));
     // round 6: nearest-x2 upsample + 3x3 conv in the sub-pixel form (conv3_lw_kernel<.., SUB>): tiles over INPUT pixels, four phases, 4 of 9 taps each with the
     // filter's taps pre-summed (a.w_up_sub from conv_up_fold_pack_host: one more fp16 rounding of the weights, which is why the caller decides -- tune().up_fold)
-    if (conv3 && a.upsample && a.w_up_sub && a.stride == 1 && a.c1 == 0 && a.N % 160 == 0 && !a.geglu && !a.res && !a.temb && tune().conv_lw != 0 &&
+    if (conv3 && a.upsample && a.w_up_sub && a.stride == 1 && a.c1 == 0 && (a.N % 160 == 0 || a.N % 128 == 0) && !a.geglu && !a.res && !a.temb && tune().conv_lw != 0 &&
         cin / BK <= LW_ZERO_CHUNKS && Ho == a.Ho && Wo == a.Wo && !(tune().debug & 16384)) {
-        const bool f1 = a.Wi % 16 == 0 && a.Hi % 16 == 0, f2 = a.Wi == 8 && a.Hi == 8;
+        const int sbn = a.N % 160 == 0 ? 160 : 128;                      // (the VAE decoder's 256 / 512-wide upsamplers: 128-column tiles)
+        const bool f1 = a.Wi % 16 == 0 && a.Hi % 16 == 0, f2 = a.Wi == 8 && a.Hi == 8 && sbn == 160;
         if (f1 || f2) {
             const int TWi = f1 ? 16 : 8, TRW = f1 ? 256 : 64, IPT = 256 / TRW;
             const int PX = a.Wi / TWi, PY = a.Hi / TWi, PP = PX * PY;
-            const int tiles_lo = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP, tiles_m = 4 * tiles_lo, tiles_n = a.N / 160;
+            const int tiles_lo = PP == 1 ? (a.B + IPT - 1) / IPT : a.B * PP, tiles_m = 4 * tiles_lo, tiles_n = a.N / sbn;
             HaloParams h;
             h.HALO_W = TWi + 2; h.HALO_IMG = (TWi + 2) * (TWi + 2); h.NHALO = IPT * h.HALO_IMG; h.NQ = (h.NHALO + 7) / 8;
             h.e = p; h.e.w = a.w_up_sub; h.e.tiles_n = tiles_n; h.e.nblk = tiles_m * tiles_n; h.e.row_stats = nullptr; h.e.pn = choose_xcd_grid(tiles_m, tiles_n, a_bytes, w_bytes * 16.0 / 9.0);
             h.x = a.a0; h.w = a.w_up_sub; h.Cin = cin; h.H = a.Hi; h.W = a.Wi; h.B = a.B; h.NC = cin / BK; h.Ho = Ho; h.Wo = Wo;
             h.tw_shift = f1 ? 4 : 3; h.trw_shift = f1 ? 8 : 6; h.PX = PX; h.PP = PP; h.splits = 1; h.partial = nullptr; h.sched = 0;
             typedef void (*lw_fn)(HaloParams);
-            static const lw_fn sub[2] = {conv3_lw_kernel<false, 160, false, 1, true>, conv3_lw_kernel<false, 160, false, 2, true>};
+            static const lw_fn sub[3] = {conv3_lw_kernel<false, 160, false, 1, true>, conv3_lw_kernel<false, 160, false, 2, true>, conv3_lw_kernel<false, 128, false, 1, true>};
             static bool configured_sub = false;
             if (!configured_sub) {
                 for (lw_fn f : sub)
                     CS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (HALO_ROWS_MAX * 128) + 3 * (160 * 128))));
                 configured_sub = true;
             }
-            const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)160 * 128);
-            hipLaunchKernelGGL(sub[f1 ? 0 : 1], dim3(h.e.nblk, 1), dim3(512), llw, s, h);
+            const size_t llw = 2 * ((size_t)h.NQ * 1024) + 3 * ((size_t)sbn * 128);
+            hipLaunchKernelGGL(sub[sbn == 128 ? 2 : f1 ? 0 : 1], dim3(h.e.nblk, 1), dim3(512), llw, s, h);
             CS_CHECK_LAUNCH();
             li->gn_done = stats_ok;
             return CS_OK;

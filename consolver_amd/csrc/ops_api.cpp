@@ -105,8 +105,9 @@ int cs_op_conv_up_sub(const void* x, int Cin, int B, int Hi, int Wi, const void*
     a.a0 = (const f16*)x; a.c0 = Cin; a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = 2 * Hi; a.Wo = 2 * Wi; a.taps = 9; a.stride = 1; a.upsample = 1; a.N = N;
     a.w = (const f16*)w; a.w_up_sub = (const f16*)w_sub; a.bias = (const f16*)bias; a.out = (f16*)out; a.gn_stats = gn_stats;
     if (!w_sub) CS_FAIL(CS_E_ARG, "conv_up_sub: w_sub (cs_op_conv_up_fold_pack) required");
-    if (!((Hi == 8 && Wi == 8) || (Hi % 16 == 0 && Wi % 16 == 0)) || N % 160 || Cin % 64)
-        CS_FAIL(CS_E_SHAPE, "conv_up_sub: input 8 x 8 or a multiple of 16 x 16, N %% 160 == 0, Cin %% 64 == 0 (got %d x %d, N %d, Cin %d)", Hi, Wi, N, Cin);
+    const bool f1 = Hi % 16 == 0 && Wi % 16 == 0 && (N % 160 == 0 || N % 128 == 0), f2 = Hi == 8 && Wi == 8 && N % 160 == 0;
+    if (!(f1 || f2) || Cin % 64)
+        CS_FAIL(CS_E_SHAPE, "conv_up_sub: input a multiple of 16 x 16 with N %% 160 == 0 or N %% 128 == 0, or 8 x 8 with N %% 160 == 0; Cin %% 64 == 0 (got %d x %d, N %d, Cin %d)", Hi, Wi, N, Cin);
     return launch_igemm(a, (hipStream_t)stream);
 }
 

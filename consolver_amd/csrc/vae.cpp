@@ -24,7 +24,7 @@
 namespace {
 
 struct HostT { std::vector<int64_t> shape; std::vector<f16> data; };
-struct VConv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; };
+struct VConv { f16* w = nullptr; f16* b = nullptr; int cin = 0, cout = 0, taps = 1; f16* w_sub = nullptr; };     // w_sub: an upsampler's sub-pixel filters (IgemmArgs::w_up_sub)
 struct VNorm { f16* g = nullptr; f16* b = nullptr; int c = 0; };
 struct VResnet { VNorm n1, n2; VConv c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
 struct VAttn { VNorm gn; f16 *wq = nullptr, *bq = nullptr, *wk = nullptr, *bk = nullptr, *wv = nullptr, *bv = nullptr, *wo = nullptr, *bo = nullptr; };
@@ -211,6 +211,8 @@ struct Run {
         IgemmArgs a{};
         a.a0 = x; a.c0 = c.cin; a.B = B; a.Hi = H; a.Wi = W; a.Ho = up ? 2 * H : H; a.Wo = up ? 2 * W : W; a.taps = c.taps; a.stride = 1;
         a.upsample = up; a.N = c.cout; a.w = c.w; a.bias = c.b; a.res = res; a.out = out;
+        // the decoder's stream is one fp16 plane: its upsamplers run the sub-pixel form (16 instead of 36 multiplies per input pixel) unless up_fold is 0
+        if (up && c.w_sub && tune().up_fold != 0 && !res && H % 16 == 0 && W % 16 == 0) a.w_up_sub = c.w_sub;
         forget_stats(out);
         a.gn_stats = c.taps == 9 ? stats_for_output(out, a.Ho * a.Wo, c.cout) : nullptr;
         launch(igemm_flops(a), [&] { return launch_igemm(a, s); });             // (a kernel without a statistics epilogue is followed by a statistics pass in the same layout)
@@ -441,7 +443,16 @@ int cs_vae_finalize(CsVae* v) {
         const std::string b = "decoder.up_blocks." + std::to_string(i);
         v->up_res[i].resize(v->cfg.layers_per_block + 1);
         for (size_t j = 0; j < v->up_res[i].size() && ok; ++j) ok = ok && make_resnet(v, b + ".resnets." + std::to_string(j), v->up_res[i][j]);
-        if (i < 3) ok = ok && make_conv(v, b + ".upsamplers.0.conv", v->up_samp[i]);
+        if (i < 3) {
+            ok = ok && make_conv(v, b + ".upsamplers.0.conv", v->up_samp[i]);
+            VConv& uc = v->up_samp[i];
+            if (ok && uc.taps == 9 && (uc.cout % 160 == 0 || uc.cout % 128 == 0) && uc.cin % 64 == 0) {
+                std::vector<f16> sub((size_t)4 * uc.cout * 4 * uc.cin);
+                conv_up_fold_pack_host(pack_conv(T(v, b + ".upsamplers.0.conv.weight")).data(), uc.cout, uc.cin, sub.data());
+                uc.w_sub = upload(v, sub);
+                ok = ok && uc.w_sub;
+            }
+        }
     }
     if (v->cfg.with_encoder && ok) {
         const int L = v->cfg.latent_channels;

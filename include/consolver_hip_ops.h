@@ -42,7 +42,8 @@ int cs_op_conv2d_gn(const void* x0, int c0, const void* x1, int c1, int B, int H
  * (2 y + py, 2 x + px) reads the 2 x 2 input neighbourhood rows {y - 1 + py, y + py} x columns {x - 1 + px, x + px}; the filter taps that land on one neighbour
  * are summed ONCE on the host: cs_op_conv_up_fold_pack: w [N][9 Cin] (tap-major, host) -> out [4 phases = 2 py + px][N][4 Cin] (host), sums in fp32, one rounding
  * to fp16.  16 multiplies per input pixel and channel pair instead of 36; the results differ from the plain form by that one rounding of the weights (~2^-12).
- * cs_op_conv_up_sub: x NHWC [B, Hi, Wi, Cin] -> out [B, 2 Hi, 2 Wi, N]; input 8 x 8 or a multiple of 16 x 16, N % 160 == 0, Cin % 64 == 0; w = the plain packed
+ * cs_op_conv_up_sub: x NHWC [B, Hi, Wi, Cin] -> out [B, 2 Hi, 2 Wi, N]; input a multiple of 16 x 16 (N % 160 == 0 or N % 128 == 0: the UNet's and the VAE decoder's
+ * widths) or 8 x 8 (N % 160 == 0), Cin % 64 == 0; w = the plain packed
  * filter (unused by the kernel, kept for the shapes the sub-pixel kernel does not take), gn_stats as cs_op_conv2d_gn or null. */
 int cs_op_conv_up_fold_pack(const void* w, int N, int Cin, void* out);
 int cs_op_conv_up_sub(const void* x, int Cin, int B, int Hi, int Wi, const void* w, const void* w_sub, const void* bias, int N, void* out, float* gn_stats,

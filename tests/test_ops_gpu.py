@@ -201,6 +201,8 @@ SUBPIXEL_CASES = [   # B, H (input), cin, N
     (3, 16, 192, 160),
     (2, 32, 128, 160),     # four patches per image
     (1, 48, 64, 160),      # nine patches: not a power of two per row
+    (1, 32, 128, 256),     # 128-column tiles (the VAE decoder's widths)
+    (2, 16, 64, 128),
 ]
 
 

@@ -77,6 +77,18 @@ def test_full_sd15_decoder_matches_oracle():
     assert (got.float().cpu() - want).abs().max() < 2e-2
     # FLOP count: ~1.26 TMAC = 2.5 TFLOP per 512x512 image for the SD1.5 decoder
     assert 2.3e12 < v.flops(1) < 2.7e12
+    # round 6: the three upsamplers ran the sub-pixel form (knob up_fold, default on: the decoder's stream is one fp16 plane); the fused-upsample kernels give
+    # the same image within the one extra fp16 rounding of the summed filter taps
+    from consolver_amd import ops
+    ops.set_tuning("up_fold", 0)
+    try:
+        plain = decode_latents(v, lat.to(DEV), batch_size=1)
+    finally:
+        ops.set_tuning("up_fold", 1)
+    e_plain = rel_l2(plain, want)
+    print("  fused-upsample kernels:", e_plain, "between the two forms:", rel_l2(got, plain.float().cpu()))
+    assert not torch.equal(plain, got)
+    assert err < 1.1 * e_plain + 1e-4 and rel_l2(got, plain.float().cpu()) < 2e-3
 
 
 def test_product_path_has_no_cpu_fallback():

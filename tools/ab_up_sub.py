@@ -25,7 +25,7 @@ for H, C in ((8, 1280), (16, 1280), (32, 640)):
         ts.append((timeit(lambda: ops.conv2d(x, wp, bias, upsample=True, gn_stats=True)), timeit(lambda: ops.conv_up_sub(x, wp, ws, bias, gn_stats=True))))
     o0, o1 = ops.conv2d(x, wp, bias, upsample=True), ops.conv_up_sub(x, wp, ws, bias)
     print(f"upsampler {H}x{H} -> {2 * H}x{2 * H}, {C} channels, batch {B} ({gf:.0f} GFLOP of the graph): fused-upsample kernel {ts[0][0]:7.1f} / {ts[1][0]:7.1f} us "
-          f"({gf / ts[1][0] * 1e-3:.0f} TFLOP/s) | sub-pixel {ts[0][1]:7.1f} / {ts[1][1]:7.1f} us ({gf / ts[1][1] * 1e-3:.0f} TFLOP/s of the graph, {gf * 4 / 9 / ts[1][1] * 1e-3:.0f} executed); "
+          f"({gf / ts[1][0] * 1e3:.0f} TFLOP/s) | sub-pixel {ts[0][1]:7.1f} / {ts[1][1]:7.1f} us ({gf / ts[1][1] * 1e3:.0f} TFLOP/s of the graph, {gf * 4 / 9 / ts[1][1] * 1e3:.0f} executed); "
           f"rel L2 between them {rel(o1, o0):.2e}", flush=True)
     del x, wp, ws
 # the UNet forward on one fp16 plane

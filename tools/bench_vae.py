@@ -4,6 +4,10 @@ import torch, time
 from consolver_amd.vae import HipAutoencoderKL, decode_latents
 from consolver_amd.synth import synthetic_vae_state_dict
 v = HipAutoencoderKL({}, device="cuda:0"); v.load_state_dict(synthetic_vae_state_dict(v.manifest()))
+from consolver_amd import ops
+for kv in os.environ.get("CS_TUNE", "").split(","):          # CS_TUNE="up_fold=0": the fused-upsample kernels instead of the sub-pixel upsamplers
+    if "=" in kv:
+        ops.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 for B in (1, 4, 16):
     lat = torch.randn(B, 4, 64, 64, device="cuda:0", dtype=torch.float16) * 0.18
     for _ in range(2): decode_latents(v, lat, B)
