@@ -192,10 +192,23 @@ class PowerSampler:
         import glob
         self.paths = {}
         cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-        # card order follows the PCI order HIP enumerates in on a single-GPU box; with several cards take the device_index-th that has a power file
         withp = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        self.matched_by = None
         if withp:
-            h = withp[min(device_index, len(withp) - 1)]
+            # the card whose PCI address is the HIP device's (a box may expose eight cards in sysfs and one GPU to the process: round 6 read an idle neighbour's
+            # 242 W / 99 MHz by index); else the device_index-th card that has a power file
+            h = None
+            try:
+                pr = torch.cuda.get_device_properties(device_index)
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+                for c in withp:
+                    if os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).lower().startswith(want):
+                        h, self.matched_by = c, "pci " + want
+                        break
+            except Exception:
+                h = None
+            if h is None:
+                h, self.matched_by = withp[min(device_index, len(withp) - 1)], f"index {device_index} of {len(withp)} cards (no PCI match)"
             for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",))):
                 for nme in names:
                     if os.path.exists(os.path.join(h, nme)):
@@ -237,7 +250,7 @@ class PowerSampler:
     def summary(self):
         if not self.paths:
             return {"available": False, "why": "no readable amdgpu hwmon power file under /sys/class/drm/card*/device/hwmon"}
-        out = {"available": True, "samples": max((len(v) for v in self.samples.values()), default=0), "source": "sysfs hwmon (amdgpu), 20 ms period"}
+        out = {"available": True, "samples": max((len(v) for v in self.samples.values()), default=0), "source": "sysfs hwmon (amdgpu), 20 ms period", "card": self.matched_by}
         if self.samples.get("power_uW"):
             v = self.samples["power_uW"]
             out["mean_socket_power_w"] = sum(v) / len(v) / 1e6
