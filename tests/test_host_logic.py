@@ -35,6 +35,37 @@ def test_library_exports_every_declared_symbol():
     assert l.cs_error_string(-6) == b"not implemented"
 
 
+def test_upsampler_subpixel_filter_pack_is_the_upsampled_conv():
+    """cs_op_conv_up_fold_pack (host code behind the C ABI): the four 2 x 2-tap phase filters it writes are the per-neighbour SUMS of the 3 x 3 taps, rounded to fp16
+    once, and a conv of the INPUT with them, scattered to the phases, is F.interpolate(nearest, x2) + conv2d(pad 1) of the reference graph (diffusers Upsample2D)."""
+    import torch
+    import torch.nn.functional as F
+    from consolver_amd import ops
+    g = torch.Generator().manual_seed(0)
+    N, C, H = 16, 8, 6
+    w = torch.randn(N, C, 3, 3, generator=g).half()
+    ws = ops.conv_up_fold_pack(ops.pack_conv_weight(w))
+    assert ws.shape == (4, N, 4 * C) and ws.dtype == torch.float16
+    ws = ws.float().reshape(4, N, 4, C)
+    taps = {0: [[0], [1, 2]], 1: [[0, 1], [2]]}                 # phase -> neighbour -> filter taps that land on it
+    x = torch.randn(2, C, H, H, generator=g, dtype=torch.float64)
+    xp = F.pad(x, (1, 1, 1, 1))
+    exact = torch.zeros(2, N, 2 * H, 2 * H, dtype=torch.float64)
+    packed = torch.zeros_like(exact)
+    for py in (0, 1):
+        for px in (0, 1):
+            for a in (0, 1):
+                for b in (0, 1):
+                    wk = sum(w.double()[:, :, dy, dx] for dy in taps[py][a] for dx in taps[px][b])
+                    assert torch.equal(ws[2 * py + px, :, 2 * a + b, :], wk.float().half().float())
+                    sl = xp[:, :, py + a:py + a + H, px + b:px + b + H]       # input rows y - 1 + py + a
+                    exact[:, :, py::2, px::2] += torch.einsum("nc,bchw->bnhw", wk, sl)
+                    packed[:, :, py::2, px::2] += torch.einsum("nc,bchw->bnhw", ws[2 * py + px, :, 2 * a + b, :].double(), sl)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w.double(), padding=1)
+    assert float((exact - ref).abs().max()) < 1e-12
+    assert float((packed - ref).norm() / ref.norm()) < 4e-4        # the one fp16 rounding of the summed taps
+
+
 def test_struct_layout_matches_header():
     # field order / sizes mirrored by hand in _lib.py; a C-side sizeof check guards it
     assert ctypes.sizeof(_lib.CsFactorNet) == 6 * 8 + 4 * 4 + 2 * 4
