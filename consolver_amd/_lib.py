@@ -148,6 +148,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cs_flux_set_residual_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "cs_flux_get_residual_precision": (C.c_int, [C.c_void_p]),
+    "cs_flux_set_output_dtype": (C.c_int, [C.c_void_p, C.c_int]),
+    "cs_flux_get_output_dtype": (C.c_int, [C.c_void_p]),
     "cs_flux_forward_joint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     # include/consolver_hip_ops.h

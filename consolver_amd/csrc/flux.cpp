@@ -58,6 +58,7 @@ struct CsFlux {
     u16* mod_w = nullptr; u16* mod_b = nullptr; long mod_total = 0; long mod_final = 0;
     std::vector<DoubleBlk> dbl; std::vector<SingleBlk> sgl;
     Arena2 arena; double dry_flops = 0;
+    int out_f32 = 0;                    // cs_flux_set_output_dtype: 1 = the forward's `out` is fp32 (split stream only: the head's two planes summed)
     int residual = CS_RESIDUAL_F16X2;   // cs_flux_set_residual_precision: the hidden-state stream as hi + lo planes of the model dtype (default) or one plane
 };
 
@@ -165,9 +166,9 @@ struct FRun {
         if (dry) { f->dry_flops += 2.0 * Rr * (double)N * K; return; }
         if (rc == CS_OK) rc = launch_small_linear(x, Rr, K, w, b, (int)N, out, silu_in, silu_out, dt, s);
     }
-    void lnmod(const void* x, void* y, int M, int C, int rps, const float* shift, const float* scale, long stride, const void* x_lo = nullptr) {
+    void lnmod(const void* x, void* y, int M, int C, int rps, const float* shift, const float* scale, long stride, const void* x_lo = nullptr, void* y_lo = nullptr) {
         if (dry || rc != CS_OK) return;
-        rc = launch_ln_modulate(x, y, M, C, rps, shift, scale, stride, 1e-6f, dt, s, x_lo);
+        rc = launch_ln_modulate(x, y, M, C, rps, shift, scale, stride, 1e-6f, dt, s, x_lo, y_lo);
     }
     static Gemm2Args with_lo(Gemm2Args g, void* lo) { g.res_lo = lo; g.out_lo = lo; return g; }
     void attn(const u16* qkv, int B, int S, u16* out, long out_stride) {
@@ -312,8 +313,26 @@ int flux_forward(CsFlux* f, bool dry, const void* hidden, int B, int I, const vo
             if (split) hipok(hipMemcpyAsync(img_lo + (size_t)b * I1 * D, hs_lo + ((size_t)b * S + T) * D, (size_t)I1 * D * e, hipMemcpyDeviceToDevice, s), "copy joint_lo -> img_lo");
         }
     const float* mf = mod + f->mod_final;                                         // AdaLayerNormContinuous: [scale, shift]
-    Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS, img_lo);
-    Rn.gemm(f->proj_out, nimg, D, B * I1, out, c.in_channels);
+    if (!split) {
+        Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS, img_lo);
+        Rn.gemm(f->proj_out, nimg, D, B * I1, out, c.in_channels);
+        return Rn.rc;
+    }
+    // Split stream (round 6): the head's two tensors were the last places where the stream's value passed through ONE plane of the model dtype -- the modulated
+    // LayerNorm output (proj_out's operand) and proj_out's result: 3.42e-3 per forward at full depth with them, 2.53e-3 without (tools/sim_precision_flux.py: the
+    // emulation with exactly these two rounding points gives 3.41e-3).  The LayerNorm writes hi + lo; proj_out runs twice into one pair of planes -- W n_hi + b onto
+    // zeroed planes, then W n_lo onto those (the gated-residual epilogue's split form, no gate) -- and `out` is the hi plane (= the rounding of the fp32-class value)
+    // or, cs_flux_set_output_dtype(CS_F32), the sum of the two planes in fp32.  64 output columns: 0.1 % of a block's GEMM work.
+    const size_t on = (size_t)B * I1 * c.in_channels;
+    u16* nlo = (u16*)Rn.alloc((size_t)B * I1 * D * e);
+    u16* oh = f->out_f32 ? (u16*)Rn.alloc(on * e) : (u16*)out;
+    u16* ol = (u16*)Rn.alloc(on * e);
+    Rn.lnmod(img, nimg, B * I1, D, I1, mf + D, mf, MS, img_lo, nlo);
+    if (!dry && Rn.rc == CS_OK) { hipok(hipMemsetAsync(oh, 0, on * e, s), "memset head hi"); hipok(hipMemsetAsync(ol, 0, on * e, s), "memset head lo"); }
+    Rn.gemm(f->proj_out, nimg, D, B * I1, oh, c.in_channels, 0, 0, oh, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, ol);
+    Lin nb = f->proj_out; nb.b = nullptr;                                          // (the bias went in with the first product)
+    Rn.gemm(nb, nlo, D, B * I1, oh, c.in_channels, 0, 0, oh, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, ol);
+    if (f->out_f32 && !dry && Rn.rc == CS_OK) Rn.rc = launch_planes_to_f32(oh, ol, (float*)out, (long)on, c.dtype, s);
     return Rn.rc;
 }
 
@@ -449,6 +468,7 @@ int cs_flux_forward(CsFlux* f, const void* hidden_states, int batch, int img_len
     if (!hidden_states || !encoder_hidden_states || !pooled_f32 || !timestep || !rope_cos || !rope_sin || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
     if (f->cfg.guidance_embeds && !guidance) CS_FAIL(CS_E_ARG, "guidance is required (guidance_embeds)");
     if (img_len <= 0 || txt_len <= 0) CS_FAIL(CS_E_SHAPE, "sequence lengths must be positive");
+    if (f->out_f32 && f->residual != CS_RESIDUAL_F16X2) CS_FAIL(CS_E_STATE, "flux: an fp32 output (cs_flux_set_output_dtype) is the split stream's (CS_RESIDUAL_F16X2)");
     return flux_forward(f, false, hidden_states, batch, img_len, encoder_hidden_states, txt_len, pooled_f32, timestep, guidance, rope_cos, rope_sin, out,
                         (char*)workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -461,6 +481,14 @@ int cs_flux_set_residual_precision(CsFlux* f, int mode) {
 }
 int cs_flux_get_residual_precision(const CsFlux* f) { return f ? f->residual : -1; }
 
+int cs_flux_set_output_dtype(CsFlux* f, int dtype) {
+    if (!f) CS_FAIL(CS_E_ARG, "flux is NULL");
+    if (dtype != CS_F32 && dtype != f->cfg.dtype) CS_FAIL(CS_E_DTYPE, "flux output dtype %d: the model dtype (%d) or CS_F32", dtype, f->cfg.dtype);
+    f->out_f32 = dtype == CS_F32;
+    return CS_OK;
+}
+int cs_flux_get_output_dtype(const CsFlux* f) { return f ? (f->out_f32 ? CS_F32 : f->cfg.dtype) : -1; }
+
 int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const void* image_latents, int image_len, int batch,
                           const void* encoder_hidden_states, int txt_len, const float* pooled_f32, const float* timestep, const float* guidance,
                           const float* rope_cos, const float* rope_sin, void* out, void* workspace, size_t workspace_bytes, void* stream) {
@@ -468,6 +496,7 @@ int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const voi
     if (!f->finalized) CS_FAIL(CS_E_STATE, "cs_flux_finalize has not been called");
     if (batch <= 0) return batch < 0 ? CS_E_SHAPE : CS_OK;
     if (!latents || !encoder_hidden_states || !pooled_f32 || !timestep || !rope_cos || !rope_sin || !out || !workspace) CS_FAIL(CS_E_ARG, "null pointer");
+    if (f->out_f32 && f->residual != CS_RESIDUAL_F16X2) CS_FAIL(CS_E_STATE, "flux: an fp32 output (cs_flux_set_output_dtype) is the split stream's (CS_RESIDUAL_F16X2)");
     if (f->cfg.guidance_embeds && !guidance) CS_FAIL(CS_E_ARG, "guidance is required (guidance_embeds)");
     if (lat_len <= 0 || txt_len <= 0 || image_len < 0) CS_FAIL(CS_E_SHAPE, "sequence lengths must be positive");
     if (image_len > 0 && !image_latents) CS_FAIL(CS_E_ARG, "image_latents is NULL but image_len > 0");

@@ -8,10 +8,11 @@ namespace {
 
 // y = LN_noaffine(x) * (1 + scale[b]) + shift[b]; one wave per token row, row kept in registers
 // SPLIT: x is a split residual stream (value = x + x_lo, two planes of T)
+// y_lo (SPLIT only, optional): the output as two planes too, y_lo = T(o - float(T(o))) -- the output head's LayerNorm, whose result is the A operand of proj_out
 template <typename T, int MAXV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict__ x, u16* __restrict__ y, int M, int C, int rows_per_sample,
                                                           const float* __restrict__ shift, const float* __restrict__ scale, long mod_stride, float eps,
-                                                          const u16* __restrict__ x_lo = nullptr) {
+                                                          const u16* __restrict__ x_lo = nullptr, u16* __restrict__ y_lo = nullptr) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + w;
     if (row >= M) return;
@@ -62,8 +63,23 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const u16* __restrict_
             }
             const u32x4 pk = {pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7])};
             *reinterpret_cast<u32x4*>(y + (size_t)row * C + cv * 8) = pk;
+            if constexpr (SPLIT) {
+                if (y_lo) {
+                    float r[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { r[2 * k] = o[2 * k] - El<T>::tof((u16)(pk[k] & 0xffff)); r[2 * k + 1] = o[2 * k + 1] - El<T>::tof((u16)(pk[k] >> 16)); }
+                    *reinterpret_cast<u32x4*>(y_lo + (size_t)row * C + cv * 8) = u32x4{pack2<T>(r[0], r[1]), pack2<T>(r[2], r[3]), pack2<T>(r[4], r[5]), pack2<T>(r[6], r[7])};
+                }
+            }
         }
     }
+}
+
+// out[i] = float(hi[i]) + float(lo[i]): a tensor kept as two planes of the model dtype, handed out in fp32 (the output head's velocity)
+template <typename T>
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const u16* __restrict__ hi, const u16* __restrict__ lo, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = El<T>::tof(hi[i]) + El<T>::tof(lo[i]);
 }
 
 // one wave per (token row, group of 64 / (2 dh/8) heads): every lane holds 8 dims of q or k of one head (dh = 128: lanes 0-15 q(h), 16-31 k(h),
@@ -210,14 +226,26 @@ template <typename T> __global__ void cast_kernel(const float* x, u16* out, long
 
 }  // namespace
 
+int launch_planes_to_f32(const void* hi, const void* lo, float* out, long n, int dtype, hipStream_t s) {
+    if (!hi || !lo || !out) CS_FAIL(CS_E_ARG, "planes_to_f32: null pointer");
+    if (n <= 0) return CS_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (dtype == CS_BF16) hipLaunchKernelGGL(planes_to_f32_kernel<bf16_el>, grid, block, 0, s, (const u16*)hi, (const u16*)lo, out, n);
+    else if (dtype == CS_F16) hipLaunchKernelGGL(planes_to_f32_kernel<f16>, grid, block, 0, s, (const u16*)hi, (const u16*)lo, out, n);
+    else CS_FAIL(CS_E_DTYPE, "planes_to_f32: dtype");
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
 int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
-                       float eps, int dtype, hipStream_t s, const void* x_lo) {
+                       float eps, int dtype, hipStream_t s, const void* x_lo, void* y_lo) {
     if (!x || !y || !shift || !scale) CS_FAIL(CS_E_ARG, "ln_modulate: null pointer");
+    if (y_lo && !x_lo) CS_FAIL(CS_E_ARG, "ln_modulate: y_lo is the split form's (x_lo required)");
     if (C % 8 || C > 8 * 64 * 8) CS_FAIL(CS_E_SHAPE, "ln_modulate: C=%d unsupported", C);
     if (M <= 0) return CS_OK;
     const dim3 grid((M + 3) / 4), block(256);
     const int nv = (C / 8 + 63) / 64;
-#define LNM(T, V) do { if (x_lo) hipLaunchKernelGGL((ln_modulate_kernel<T, V, true>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps, (const u16*)x_lo); \
+#define LNM(T, V) do { if (x_lo) hipLaunchKernelGGL((ln_modulate_kernel<T, V, true>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps, (const u16*)x_lo, (u16*)y_lo); \
                        else hipLaunchKernelGGL((ln_modulate_kernel<T, V, false>), grid, block, 0, s, (const u16*)x, (u16*)y, M, C, rows_per_sample, shift, scale, mod_stride, eps, (const u16*)nullptr); } while (0)
     if (dtype == CS_BF16) { if (nv <= 1) LNM(bf16_el, 1); else if (nv <= 2) LNM(bf16_el, 2); else if (nv <= 4) LNM(bf16_el, 4); else if (nv <= 6) LNM(bf16_el, 6); else LNM(bf16_el, 8); }
     else if (dtype == CS_F16) { if (nv <= 1) LNM(f16, 1); else if (nv <= 2) LNM(f16, 2); else if (nv <= 4) LNM(f16, 4); else if (nv <= 6) LNM(f16, 6); else LNM(f16, 8); }

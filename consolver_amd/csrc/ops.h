@@ -200,8 +200,11 @@ int launch_small_linear(const float* x, int R, int K, const void* w, const void*
                         int dtype, hipStream_t s);
 // y = LayerNorm_noaffine(x) * (1 + scale[b]) + shift[b] ; x,y [M][C] (dtype), scale/shift fp32 rows of stride mod_stride
 // x_lo: optional lo plane of a split stream (value = x + x_lo)
+// y_lo (with x_lo): the result as two planes too, y_lo = T(o - float(y)) (the output head, whose LayerNorm output is proj_out's A operand)
 int launch_ln_modulate(const void* x, void* y, int M, int C, int rows_per_sample, const float* shift, const float* scale, long mod_stride,
-                       float eps, int dtype, hipStream_t s, const void* x_lo = nullptr);
+                       float eps, int dtype, hipStream_t s, const void* x_lo = nullptr, void* y_lo = nullptr);
+// out[i] = float(hi[i]) + float(lo[i]) (two planes of `dtype` -> fp32)
+int launch_planes_to_f32(const void* hi, const void* lo, float* out, long n, int dtype, hipStream_t s);
 // in place on a fused qkv buffer [S_total rows][ld]: per head RMSNorm(q) * wq, RMSNorm(k) * wk, then RoPE (pairs) with cos/sin [S][dh/2]
 int launch_qk_norm_rope(void* qkv, long ld, int rows, int seq, int heads, int dh, int q_col, int k_col, const void* wq, const void* wk,
                         const void* wq_ctx, const void* wk_ctx, int ctx_rows, const float* cosv, const float* sinv, float eps, int dtype,

@@ -97,6 +97,7 @@ class HipFluxTransformer2DModel:
         self._ws_key = None
         self._rope = {}
         self.residual = "split"
+        self._out_f32 = False
         if residual != "split":
             self.set_residual_precision(residual)
 
@@ -172,14 +173,16 @@ class HipFluxTransformer2DModel:
 
     def __call__(self, hidden_states, timestep, guidance=None, pooled_projections=None, encoder_hidden_states=None,
                  txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False, out=None, image_latents=None,
-                 **_ignored):
+                 out_dtype=None, **_ignored):
         """the reference's call (edit_ppo/pipeline.py:1087-1097): ``hidden_states`` [B, I, 64] (the caller's
         ``cat([latents, image_latents], 1)``) -> [B, I, 64].
 
         Extension used by the native edit loop: ``image_latents=`` [B, I2, 64] passes the Kontext reference-image
         tokens as a second buffer -- the joint sequence [hidden_states | image_latents] is read in place (no per-step
         ``torch.cat``) and the result holds the rows of ``hidden_states`` only ([B, I, 64], i.e. the reference's
-        ``noise_pred[:, :latents.size(1)]`` without the slice copy); ``img_ids`` cover I + I2 tokens."""
+        ``noise_pred[:, :latents.size(1)]`` without the slice copy); ``img_ids`` cover I + I2 tokens.
+        ``out_dtype=torch.float32`` (split stream only; cs_flux_set_output_dtype): the prediction as the unrounded sum of the output head's two planes instead of
+        their hi plane in the model dtype."""
         if not self._finalized:
             raise RuntimeError("weights not loaded")
         L.require_cuda(hidden_states, "hidden_states")
@@ -208,13 +211,22 @@ class HipFluxTransformer2DModel:
         cos, sin = self._rope_dev(txt_ids, img_ids)
         if cos.shape[0] != T + I + I2:
             raise ValueError(f"ids cover {cos.shape[0]} tokens, expected {T + I + I2}")
-        key = (B, T, I + I2)
+        want_f32 = out_dtype == torch.float32 or (out_dtype is None and out is not None and out.dtype == torch.float32)
+        if out_dtype not in (None, torch.float32, self.dtype):
+            raise ValueError(f"out_dtype must be the model dtype {self.dtype} or torch.float32, got {out_dtype}")
+        if want_f32 != self._out_f32:
+            L.check(L.lib().cs_flux_set_output_dtype(self._h, L.CS_F32 if want_f32 else L.dtype_code(self.dtype)))
+            self._out_f32 = want_f32
+        key = (B, T, I + I2, want_f32)
         if self._ws_key != key:
             n = int(L.lib().cs_flux_workspace_bytes(self._h, B, T, I + I2))
             self._ws = torch.empty(n, dtype=torch.uint8, device=hs.device)
             self._ws_key = key
+        odt = torch.float32 if want_f32 else self.dtype
         if out is None:
-            out = torch.empty(B, I, self.config["in_channels"], dtype=self.dtype, device=hs.device)
+            out = torch.empty(B, I, self.config["in_channels"], dtype=odt, device=hs.device)
+        elif out.dtype != odt or tuple(out.shape) != (B, I, self.config["in_channels"]) or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous {odt} tensor of shape {(B, I, self.config['in_channels'])}")
         if il is None:
             L.check(L.lib().cs_flux_forward(self._h, L.ptr(hs), B, I, L.ptr(enc), T, L.ptr(pooled), L.ptr(t), L.ptr(g), L.ptr(cos),
                                             L.ptr(sin), L.ptr(out), L.ptr(self._ws), self._ws.numel(), L.stream_ptr(hs.device)))

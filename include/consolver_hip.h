@@ -294,6 +294,12 @@ int cs_flux_forward_joint(CsFlux* f, const void* latents, int lat_len, const voi
  * Changes the workspace size: query cs_flux_workspace_bytes after switching. */
 int cs_flux_set_residual_precision(CsFlux* f, int mode);
 int cs_flux_get_residual_precision(const CsFlux* f);
+/* dtype of cs_flux_forward(_joint)'s `out`: the model dtype (default: what the reference's `transformer(...)[0]` returns, edit_ppo/pipeline.py:1087-1097) or CS_F32.
+ * With the split stream the output head keeps its two tensors -- the modulated LayerNorm output and proj_out's result -- as hi + lo planes (round 6: they were the
+ * last one-plane stations of the stream's value, 3.42e-3 -> 2.5e-3 per forward at full depth): the model-dtype `out` is the hi plane, the fp32 `out` the sum of
+ * the two.  CS_F32 with CS_RESIDUAL_F16 (one plane) is refused at the forward. */
+int cs_flux_set_output_dtype(CsFlux* f, int dtype);
+int cs_flux_get_output_dtype(const CsFlux* f);
 
 /* ------------------------------------------------------------------------
  * AutoencoderKL decoder (SD1.5 VAE): latents -> images.  Replaces

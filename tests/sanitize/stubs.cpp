@@ -113,7 +113,8 @@ int launch_gemm2(const Gemm2Args& a, hipStream_t) {
 int launch_gemm2_pair(const Gemm2Args& a, const Gemm2Args& b, hipStream_t s) { launch_gemm2(a, s); return launch_gemm2(b, s); }
 size_t gemm2_tail_workspace_bytes(int tiles, int K) { return K >= 6144 && tiles % 256 ? (size_t)3 * 256 * 256 * 256 * 4 : 0; }
 int launch_small_linear(const float* x, int R, int K, const void* w, const void*, int N, float* out, int, int, int, hipStream_t) { rd(x, (size_t)R * K * 4); rd(w, (size_t)N * K * 2); wr(out, (size_t)R * N * 4); return CS_OK; }
-int launch_ln_modulate(const void* x, void* y, int M, int C, int, const float* sh, const float* sc, long, float, int, hipStream_t, const void* x_lo) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(y, (size_t)M * C * 2); rd(sh, C * 4); rd(sc, C * 4); return CS_OK; }
+int launch_planes_to_f32(const void* hi, const void* lo, float* out, long n, int, hipStream_t) { rd(hi, (size_t)n * 2); rd(lo, (size_t)n * 2); wr(out, (size_t)n * 4); return CS_OK; }
+int launch_ln_modulate(const void* x, void* y, int M, int C, int, const float* sh, const float* sc, long, float, int, hipStream_t, const void* x_lo, void* y_lo) { rd(x, (size_t)M * C * 2); rd(x_lo, (size_t)M * C * 2); wr(y, (size_t)M * C * 2); wr(y_lo, (size_t)M * C * 2); rd(sh, C * 4); rd(sc, C * 4); return CS_OK; }
 int launch_qk_norm_rope(void* qkv, long ld, int rows, int, int heads, int dh, int, int k_col, const void*, const void*, const void*, const void*, int, const float*, const float*, float, int, hipStream_t) {
     wr(qkv, (((size_t)rows - 1) * ld + k_col + (size_t)heads * dh) * 2); return CS_OK;
 }

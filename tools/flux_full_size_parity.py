@@ -68,6 +68,8 @@ def main():
     a.record(); got2 = run(); b.record(); torch.cuda.synchronize()
     assert torch.equal(got, got2)
     print(f"HIP forward at S = {T + 2 * Lq}: {a.elapsed_time(b):.1f} ms, deterministic (two runs bit-identical), residual = {m.residual}", flush=True)
+    got32 = m(lat.to(DEV), t.to(DEV), guidance=guidance.to(DEV), pooled_projections=pooled.to(DEV), encoder_hidden_states=enc.to(DEV),
+              txt_ids=txt_ids, img_ids=ids, image_latents=img.to(DEV), out_dtype=torch.float32)[0].clone()
     m.set_residual_precision("plain")
     got_plain = run()
     m.set_residual_precision("split")
@@ -81,6 +83,7 @@ def main():
     print(f"fp32 CPU oracle (streamed weights, {torch.get_num_threads()} threads): {dt:.0f} s")
     print(f"relative L2 of the velocity [1, 4096, 64] vs the fp32 oracle at {nl} + {ns} blocks x S = {T + 2 * Lq}:")
     print(f"  HIP, split hidden-state stream (default): {err:.3e}   (last 512 latent rows: {err_tail:.3e})")
+    print(f"  HIP, split stream, fp32 output:           {rel_l2(got32, want):.3e}   (cs_flux_set_output_dtype: the sum of the output head's two planes)")
     print(f"  HIP, one-plane stream:                    {err_plain:.3e}")
     print(f"  torch-bf16 graph of the same restatement: {e_t16:.3e}   (the reference pipeline's own arithmetic class)")
     assert torch.isfinite(got.float()).all() and got.shape == (B, Lq, 64)

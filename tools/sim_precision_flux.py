@@ -37,16 +37,23 @@ ids = np.concatenate([prepare_latent_image_ids(16, 16), prepare_latent_image_ids
 txt_ids = np.zeros((T, 3), np.float32)
 rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
 rb16 = lambda x: x.to(torch.bfloat16).to(x.dtype)
-def run(rs, rb):
+def run(rs, rb, rp=False, rh=False, rs17=False):
     o = FluxOracle(sd, m.config, lazy=True, device=DEV, dtype=torch.float32)
     if rs: o.rs = rb16
     if rb: o.rb = rb16
+    if rp: o.rp = rb16
+    if rh: o.rh = rb16
+    if rs17: o.rs = lambda x: rb16(x) + rb16(x - rb16(x))          # the split stream: hi + lo planes of bf16
     return o(torch.cat([lat, img], 1), t, guidance, pooled, enc, txt_ids, ids)[:, :Lq]
 want = run(False, False)
 cpu = FluxOracle(sd, m.config, lazy=True)(torch.cat([lat, img], 1).float(), t, guidance, pooled.float(), enc.float(), txt_ids, ids)[:, :Lq]
 print(f"fp32 graph on the GPU vs the fp32 CPU oracle (sanity of the emulator): {rel(want, cpu):.3e}")
 for name, rs, rb in (("residual stream in bf16, branches exact", True, False), ("branch tensors in bf16, stream exact", False, True), ("both (the bf16 storage class)", True, True)):
     print(f"{name:48s}: {rel(run(rs, rb), want):.3e}")
+# round 6: what separates the HIP split stream from "branch tensors in bf16, stream exact"
+for name, kw in (("branch + the stream as hi + lo bf16 planes", dict(rs17=True)), ("branch + softmax probabilities in bf16", dict(rp=True)),
+                 ("branch + the output head's two tensors in bf16", dict(rh=True)), ("branch + all three (what the HIP DiT stores)", dict(rs17=True, rp=True, rh=True))):
+    print(f"{name:48s}: {rel(run(False, True, **kw), want):.3e}", flush=True)
 got = m(lat.to(DEV), t.to(DEV), guidance=guidance.to(DEV), pooled_projections=pooled.to(DEV), encoder_hidden_states=enc.to(DEV), txt_ids=txt_ids, img_ids=ids, image_latents=img.to(DEV))[0]
 t16 = FluxOracle(sd, m.config, lazy=True, device=DEV, dtype=torch.bfloat16)(torch.cat([lat, img], 1), t, guidance, pooled, enc, txt_ids, ids)[:, :Lq]
 print(f"{'HIP DiT (cs_flux_forward_joint)':48s}: {rel(got.float(), want):.3e}")
