@@ -32,8 +32,9 @@ def r16(x):
 
 
 class Emu(UNetOracle):
-    def __init__(self, sd, cfg, stream=True, raw=True, norm=True, branch=True, raw_sc=None, raw_po=None, raw_ud=None, ln_fold=False):
+    def __init__(self, sd, cfg, stream=True, raw=True, norm=True, branch=True, raw_sc=None, raw_po=None, raw_ud=None, ln_fold=False, head=True):
         super().__init__(sd, cfg)
+        self.head = head          # False: conv_out reads the unrounded output of the final GroupNorm + SiLU (an operand kept as hi + lo)
         ident = lambda x: x
         self.rs = r16 if stream else ident
         self.rr = r16 if raw else ident
@@ -155,7 +156,9 @@ class Emu(UNetOracle):
             if i < 3:
                 h = F.interpolate(self.rr_ud(h), scale_factor=2.0, mode="nearest")
                 h = self.rs(self._conv(h, f"{b}.upsamplers.0.conv", padding=1))
-        h = self.rn(self._gn(h, "conv_norm_out", 1e-5, True))
+        h = self._gn(h, "conv_norm_out", 1e-5, True)
+        if self.head:
+            h = self.rn(h)
         return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 
 
