@@ -286,15 +286,18 @@ __global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __rest
     }
     // D: column = filter (lane & 15), rows = pixels 4 (lane >> 4) + r of the patch row: one 8-byte NCHW store per lane and patch row
     if (col < COUT) {
-        const float bv = (float)bias[col];
+        const float bv = bias ? (float)bias[col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int y = y0 + wave * 4 + mt;
             typedef f16 f16x4 __attribute__((ext_vector_type(4)));
             f16x4 o; f32x4 of;
+            f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+            // out_f32 == 2: ADD to the fp32 values already there (the second pass of a hi + lo operand: launch_conv_out's x_lo)
+            if (out_f32 == 2) prev = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(out) + ((((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[mt][r] + bv;
+                float v = acc[mt][r] + bv + prev[r];
                 if (postprocess) v = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);      // (image / 2 + 0.5).clamp(0, 1), utils.py:29
                 o[r] = (f16)v; of[r] = v;
             }
@@ -537,15 +540,22 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
     return CS_OK;
 }
 
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, int out_f32) {
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, int out_f32, const f16* x_lo) {
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out: null pointer");
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
     if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
         launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s, out_f32);
         CS_CHECK_LAUNCH();
+        if (x_lo) {
+            // W (x + x_lo): the lo plane's product on top of the fp32 result (no bias).  Only where the first pass left fp32 values and the MFMA kernel runs.
+            if (!out_f32 || !tune().conv_out_mfma) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand needs the fp32 output and the MFMA kernel");
+            hipLaunchKernelGGL(conv_out_mfma_kernel<4>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x_lo, Cin, H, W, w, (const f16*)nullptr, out, 0, 2);
+            CS_CHECK_LAUNCH();
+        }
         return CS_OK;
     }
+    if (x_lo) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand is built for the 16 x 16-patch shapes");
     const long M = (long)B * H * W;
     hipLaunchKernelGGL(conv_out_kernel<4>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, x, B, Cin, H, W, w, bias, out, 0, out_f32);
     CS_CHECK_LAUNCH();

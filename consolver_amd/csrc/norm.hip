@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 template <bool SILU, bool SPLIT, int RPT>
 __global__ __launch_bounds__(320) void gn_apply_col_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int c0, int c1,
                                                            int HW, const float* __restrict__ scale_shift, f16* __restrict__ out,
-                                                           const f16* __restrict__ x0_lo, const f16* __restrict__ x1_lo, int CV, int R) {
+                                                           const f16* __restrict__ x0_lo, const f16* __restrict__ x1_lo, int CV, int R, f16* __restrict__ out_lo = nullptr) {
     const int Ctot = c0 + c1;
     const int b = blockIdx.y;
     const int cv = threadIdx.x % CV, rr = threadIdx.x / CV;
@@ -188,15 +188,24 @@ __global__ __launch_bounds__(320) void gn_apply_col_kernel(const f16* __restrict
         const int r = row0 + u * R;
         if (r >= HW) break;
         f16x8 o;
+        float yk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float xv = (float)v[u][k];
             if constexpr (SPLIT) xv += (float)vl[u][k];
             float y = xv * sc[k] + sh[k];
             if (SILU) y = y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
-            o[k] = (f16)y;
+            o[k] = (f16)y; yk[k] = y;
         }
         *reinterpret_cast<f16x8*>(out + ((size_t)b * HW + r) * Ctot + c) = o;
+        if constexpr (SPLIT) {
+            if (out_lo) {                                       // (GroupNormArgs::out_lo: the output head; uniform branch)
+                f16x8 ol;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ol[k] = (f16)(yk[k] - (float)o[k]);
+                *reinterpret_cast<f16x8*>(out_lo + ((size_t)b * HW + r) * Ctot + c) = ol;
+            }
+        }
     }
 }
 
@@ -314,10 +323,11 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
             const dim3 grid((a.HW + R * RPT - 1) / (R * RPT), a.B), block(CV * R);
             const bool split = a.x0_lo || a.x1_lo;
             if (split) {
-                if (a.silu) hipLaunchKernelGGL((gn_apply_col_kernel<true, true, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo, CV, R);
-                else hipLaunchKernelGGL((gn_apply_col_kernel<false, true, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo, CV, R);
+                if (a.silu) hipLaunchKernelGGL((gn_apply_col_kernel<true, true, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo, CV, R, a.out_lo);
+                else hipLaunchKernelGGL((gn_apply_col_kernel<false, true, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, a.x0_lo, a.x1_lo, CV, R, a.out_lo);
             } else {
                 const f16* nul2 = nullptr;
+                if (a.out_lo && hipMemsetAsync(a.out_lo, 0, (size_t)a.B * a.HW * Ctot * sizeof(f16), s) != hipSuccess) CS_FAIL(CS_E_HIP, "group_norm: memset of out_lo");
                 if (a.silu) hipLaunchKernelGGL((gn_apply_col_kernel<true, false, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, nul2, nul2, CV, R);
                 else hipLaunchKernelGGL((gn_apply_col_kernel<false, false, RPT>), grid, block, 0, s, a.x0, a.x1, a.c0, a.c1, a.HW, scale_shift, a.out, nul2, nul2, CV, R);
             }
@@ -325,6 +335,8 @@ int launch_group_norm(const GroupNormArgs& a, hipStream_t s) {
             return CS_OK;
         }
     }
+    // (the general-shape kernel writes one plane: a requested lo plane is zeros there -- hi + 0 is what the consumer multiplies)
+    if (a.out_lo && hipMemsetAsync(a.out_lo, 0, (size_t)a.B * a.HW * Ctot * sizeof(f16), s) != hipSuccess) CS_FAIL(CS_E_HIP, "group_norm: memset of out_lo");
     int chunks = (a.HW * (Ctot / 8) + 256 * GN_VPT - 1) / (256 * GN_VPT);      // ~GN_VPT vectors per thread
     if (chunks < 1) chunks = 1;
     if (chunks > a.HW) chunks = a.HW;

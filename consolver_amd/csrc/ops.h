@@ -43,6 +43,7 @@ struct TuneSet {
     // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
     int conv_in_mfma = 1;
     int up_fold = 1;        // the UNet's upsamplers (nearest x2 + 3x3 conv) in the sub-pixel form on pre-summed taps (IgemmArgs::w_up_sub): 0 never, 1 in forwards on one fp16 plane, 2 always
+    int head_x2 = 1;        // split stream + fp32 output: the UNet's output head keeps its GroupNorm + SiLU output as hi + lo planes and conv_out multiplies both (0: one fp16 plane)
     int conv_out_mfma = 1;  // 1: the 16 x 16-patch conv_out kernels (UNet 320 -> 4, VAE 128 -> 3) on v_mfma_f32_16x16x32_f16 (conv_out_mfma_kernel), 0: the v_dot2 patch kernel
     int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 };
@@ -140,6 +141,8 @@ struct GroupNormArgs {
     const float* stats0; int S0; const float* stats1; int S1;
     // optional: lo planes of split-fp16 sources (value = x + x_lo; IgemmArgs::out_lo), null = plain fp16 source
     const f16* x0_lo; const f16* x1_lo;
+    // optional (split sources): the OUTPUT as two planes too, out_lo = f16(y - float(out)) -- the UNet's output head, whose normalised tensor is conv_out's operand
+    f16* out_lo;
 };
 // statistics of a [B][HW][C] tensor in the producer layout: partial[B][HW/64][C/2][2] (sum, sum of squares of channel pairs per 64-row block)
 int launch_gn_stats64(const f16* x, int B, int HW, int C, float* partial, hipStream_t s);
@@ -175,8 +178,9 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
                    int Cout, f16* out, hipStream_t s, f16* out_lo = nullptr);
 // conv_out: NHWC [B][H][W][Cin] -> NCHW [B][Cout][H][W], 3x3 pad 1 (Cout small)
 // out_f32 != 0: `out` is an fp32 tensor (the same NCHW layout)
+// x_lo (with out_f32, 16 x 16-patch shapes on the MFMA kernel): a lo plane of the operand (value = x + x_lo); a second pass adds its product into the fp32 output
 int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias, int Cout,
-                    f16* out, hipStream_t s, int out_f32 = 0);
+                    f16* out, hipStream_t s, int out_f32 = 0, const f16* x_lo = nullptr);
 
 // ---- transformer (FLUX DiT) ops, f16 or bf16 (dtype = CS_F16 / CS_BF16) -------------------------------------
 struct Gemm2Args {

@@ -24,6 +24,7 @@ static const TuneKnob* tune_knobs(int* n) {
         {"conv_in_mfma", &TuneSet::conv_in_mfma, 0, 1, false}, {"xattn_tile", &TuneSet::xattn_tile, 64, 128, true},
         {"conv_out_mfma", &TuneSet::conv_out_mfma, 0, 1, false},
         {"up_fold", &TuneSet::up_fold, 0, 2, false},
+        {"head_x2", &TuneSet::head_x2, 0, 1, false},
     };
     *n = (int)(sizeof(k) / sizeof(k[0]));
     return k;

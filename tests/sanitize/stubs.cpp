@@ -69,7 +69,7 @@ int launch_gn_stats64(const f16* x, int B, int HW, int C, float* partial, hipStr
 int launch_group_norm(const GroupNormArgs& a, hipStream_t) {
     const size_t M = (size_t)a.B * a.HW; const int C = a.c0 + a.c1, smax = a.splits > 0 ? a.splits : GN_SPLITS;
     rd(a.x0, M * a.c0 * 2); rd(a.x1, M * a.c1 * 2); rd(a.x0_lo, M * a.c0 * 2); rd(a.x1_lo, M * a.c1 * 2); rd(a.gamma, C * 2); rd(a.beta, C * 2);
-    wr(a.partial, (size_t)a.B * (smax + 1) * C * 2 * sizeof(float)); wr(a.out, M * C * 2);
+    wr(a.partial, (size_t)a.B * (smax + 1) * C * 2 * sizeof(float)); wr(a.out, M * C * 2); wr(a.out_lo, M * C * 2);
     if (a.stats0) rd(a.stats0, (size_t)a.B * a.S0 * a.c0 * 4);
     if (a.stats1) rd(a.stats1, (size_t)a.B * a.S1 * a.c1 * 4);
     return CS_OK;
@@ -90,7 +90,7 @@ int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16*, i
 int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, f16* out_lo) {
     rd(lat, (size_t)n_lat * Cin * H * W * 2); wr(out, (size_t)B * H * W * Cout * 2); wr(out_lo, (size_t)B * H * W * Cout * 2); return CS_OK;
 }
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, int out_f32) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * (out_f32 ? 4 : 2)); return CS_OK; }
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, int out_f32, const f16* x_lo) { rd(x, (size_t)B * H * W * Cin * 2); rd(x_lo, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * (out_f32 ? 4 : 2)); return CS_OK; }
 int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, f16* out, int, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * 3 * H * W * 2); return CS_OK; }
 int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * 2); return CS_OK; }
 int launch_pixel_linear_nchw(const f16* x, const f16*, const f16*, f16* out, int B, int C, int HW, float, float, hipStream_t) { rd(x, (size_t)B * C * HW * 2); wr(out, (size_t)B * C * HW * 2); return CS_OK; }

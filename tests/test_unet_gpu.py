@@ -216,6 +216,37 @@ def test_unet_at_sizes_where_only_some_levels_take_the_fused_paths(sample_size, 
     assert torch.isfinite(got).all() and err < bound, err
 
 
+def test_output_head_on_two_planes_with_the_fp32_output():
+    """round 6 (knob head_x2, default 1): with the split stream and the fp32 output (the native engine's configuration) the final GroupNorm + SiLU writes hi + lo planes and
+    conv_out multiplies both -- one fp16 plane of that tensor was the last one-plane station of the stream's value in front of eps.  16 x 16 and 32 x 32 latents (the MFMA
+    conv_out's patch shapes); the fp16 output and the one-plane stream are untouched."""
+    for size in (16, 32):
+        cfg = dict(layers_per_block=1, sample_size=size)
+        u, _ = get_unet(cfg, seed=7)
+        orc = get_oracle(cfg, seed=7)
+        g = torch.Generator().manual_seed(9)
+        lat = torch.randn(1, 4, size, size, generator=g).half()
+        ctx = synthetic_prompt_embeds(2, seed=17).half()
+        t = 999
+        want = orc(torch.cat([lat.float()] * 2), t, ctx.float())
+        run = lambda **kw: u(lat.to(DEV), t, encoder_hidden_states=ctx.to(DEV), dup=2, reuse_kv=False, **kw)[0].clone()
+        try:
+            u.set_tuning("head_x2", 0); one32 = run(out_dtype=torch.float32); one16 = run()
+            u.set_tuning("head_x2", 1); two32 = run(out_dtype=torch.float32); two16 = run()
+            assert torch.equal(run(out_dtype=torch.float32), two32)
+            assert torch.equal(one16, two16)                                   # the model-dtype output keeps the single pass
+            e1, e2 = rel_l2(one32, want), rel_l2(two32, want)
+            print(f"\n{size} x {size}: eps (fp32 output) vs the fp32 oracle: one-plane head {e1:.4e}, hi + lo head {e2:.4e}")
+            assert not torch.equal(one32, two32) and e2 < e1, (e1, e2)
+            assert rel_l2(two32, one32) < 5e-4                                 # (a 2^-12-class correction)
+            u.set_residual_precision("f16")
+            a = run(out_dtype=torch.float32); u.set_tuning("head_x2", 0); b = run(out_dtype=torch.float32)
+            assert torch.equal(a, b)                                           # one-plane stream: no lo plane anywhere
+            u.set_residual_precision("f16x2")
+        finally:
+            u.clear_tuning()
+
+
 def test_upsamplers_in_the_subpixel_form_on_the_one_plane_stream():
     """round 6 (knob up_fold, default 1): in forwards whose residual stream is one fp16 plane the upsamplers run the sub-pixel form on pre-summed taps
     (cs_op_conv_up_sub: 4 / 9 of the multiplies; the summed weights are rounded to fp16 once more).  32 x 32 latents: the 8 x 8 -> 16 x 16 upsampler takes the
