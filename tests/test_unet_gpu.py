@@ -301,7 +301,9 @@ def test_forward_does_not_read_uninitialised_workspace(residual):
 
 def test_fp32_output_is_the_unrounded_fp16_output_and_threads_keep_their_knob_sets():
     """(a) cs_unet_set_output_dtype (round 6): the fp32 eps is the conv_out accumulator the fp16 eps is rounded from -- rounding it gives the fp16 output bit for bit,
-    on both conv_out kernels and on the one-wave-per-pixel fallback; the handle switches back and forth.  (b) per-handle knobs are a per-THREAD set (ops.h, TuneSet): a
+    on both conv_out kernels and on the one-wave-per-pixel fallback; the handle switches back and forth.  (With head_x2, the default on the split stream, the fp32
+    output additionally carries the product with the lo plane of conv_out's operand where the MFMA kernel runs: checked with the knob off, and bounded with it on.)
+    (b) per-handle knobs are a per-THREAD set (ops.h, TuneSet): a
     thread running a handle with overrides does not change what another thread's forwards on a plain handle see."""
     import threading
     from consolver_amd import ops
@@ -311,15 +313,20 @@ def test_fp32_output_is_the_unrounded_fp16_output_and_threads_keep_their_knob_se
         lat = torch.randn(2, 4, S, S, generator=torch.Generator().manual_seed(2)).half().to(DEV)
         ctx = synthetic_prompt_embeds(4, seed=31).half().to(DEV)
         for mfma in (1, 0):
-            ops.set_tuning("conv_out_mfma", mfma)
+            ops.set_tuning("conv_out_mfma", mfma); ops.set_tuning("head_x2", 0)
             try:
                 y16 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
                 y32 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False, out_dtype=torch.float32)[0].clone()
-                again = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0]
+                again = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
+                ops.set_tuning("head_x2", 1)
+                z32 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False, out_dtype=torch.float32)[0].clone()
+                z16 = u(lat, 499, encoder_hidden_states=ctx, dup=2, reuse_kv=False)[0].clone()
             finally:
-                ops.set_tuning("conv_out_mfma", 1)
+                ops.set_tuning("conv_out_mfma", 1); ops.set_tuning("head_x2", 1)
             assert y16.dtype == torch.float16 and y32.dtype == torch.float32 and torch.equal(y32.half(), y16) and torch.equal(again, y16)
             assert float((y32 - y16.float()).abs().max()) > 0             # (the fp32 tensor does carry the bits the fp16 one drops)
+            assert torch.equal(z16, y16) and rel_l2(z32, y32) < 5e-4      # the model-dtype output never changes; the two-plane head is a 2^-12-class correction of the fp32 one
+            assert torch.equal(z32, y32) == (not (mfma == 1 and S % 16 == 0))      # ... applied exactly where the MFMA conv_out runs
     with pytest.raises(ValueError):
         u(lat, 499, encoder_hidden_states=ctx, dup=2, out=torch.empty(4, 4, 8, 8, device=DEV, dtype=torch.bfloat16))
     # ---- (b)
