@@ -23,7 +23,9 @@ reads and writes the unrounded state (CsStepArgs::x_is_f32).  An fp16 state roun
 each, adding in quadrature): 12 steps ended at 1.10e-3 of the fp32 oracle, above north_star's 1e-3 gate.  The
 RETURNED latents are cast back to ``noise.dtype`` -- the tensor the trainer decodes (train_ppo.py:359-365) -- and every record
 (``conds`` / ``probs`` / ``actions`` / ``masks``) has the dtype it has in the reference.  ``solver_state_dtype=None`` carries the
-state in ``noise.dtype`` (the arithmetic class of an all-fp16 loop).
+state in ``noise.dtype`` (the arithmetic class of an all-fp16 loop).  Round 6: with the fp32 state the native denoiser also hands its OUTPUT over in fp32
+(``unet(..., out_dtype=torch.float32)``: conv_out's accumulator unrounded, and the output head's two-plane form) -- the update and the policy's features read it, the
+``conds`` records are its rounding to ``noise.dtype``, the dtype they have in the reference.
 """
 import torch
 
@@ -59,6 +61,9 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
         raise ValueError("solver_state_dtype must be torch.float32 (default) or None (= noise.dtype)")
     # the solver state: fp32 between the steps (see the module docstring); a foreign denoiser gets the tensor in its own dtype below
     latents = noise.to(solver_state_dtype) if (solver_state_dtype is not None and native and noise.dtype != solver_state_dtype) else noise.clone()
+    # the denoiser's output in fp32 next to an fp32 state (module docstring); records keep the model dtype
+    eps_dtype = torch.float32 if (native and latents.dtype == torch.float32 and noise.dtype != torch.float32) else None
+    rec_dtype = noise.dtype
     scheduler.set_timesteps(num_inference_steps, device=device)
     record_prev = scheduler.record_conds
     scheduler.record_conds = True
@@ -78,13 +83,13 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
         for i, t in enumerate(scheduler.timesteps):
             if native and i < shared_steps:
                 # every row carries the same latents: one row through the denoiser, broadcast to the batch
-                e1 = unet(latents[:1], t, encoder_hidden_states=pe1, return_dict=False, dup=2 if do_cfg else 1, reuse_kv=(i > 0))[0]
+                e1 = unet(latents[:1], t, encoder_hidden_states=pe1, return_dict=False, dup=2 if do_cfg else 1, reuse_kv=(i > 0), out_dtype=eps_dtype)[0]
                 noise_pred = (torch.cat([e1[:1].expand(batch_size, -1, -1, -1), e1[1:].expand(batch_size, -1, -1, -1)]) if do_cfg
                               else e1.expand(batch_size, -1, -1, -1)).contiguous()
             elif native:
                 # K/V of the prompt: computed at the first full-batch step of THIS rollout, reused afterwards
                 noise_pred = unet(latents, t, encoder_hidden_states=prompt_embeds, return_dict=False,
-                                  dup=2 if do_cfg else 1, reuse_kv=(i > shared_steps))[0]
+                                  dup=2 if do_cfg else 1, reuse_kv=(i > shared_steps), out_dtype=eps_dtype)[0]
             else:
                 lat_in = torch.cat([latents] * 2) if do_cfg else latents
                 lat_in = scheduler.scale_model_input(lat_in, t)
@@ -97,8 +102,8 @@ def denoise_diffusion(text_encoder, scheduler, unet, noise, text, tokenizer, cfg
                 out = scheduler.step(noise_pred, t, latents, return_dict=False)
             latents, actions, probs, conds, masks = out
             if i > 0:
-                rec["x"].append(conds["x"].unsqueeze(1))
-                rec["epsilon"].append(conds["epsilon"].unsqueeze(1))
+                rec["x"].append(conds["x"].to(rec_dtype).unsqueeze(1))
+                rec["epsilon"].append(conds["epsilon"].to(rec_dtype).unsqueeze(1))
                 rec["probs"].append(probs.unsqueeze(1))
                 rec["actions"].append(actions.unsqueeze(1))
                 rec["masks"].append(masks.unsqueeze(1))
