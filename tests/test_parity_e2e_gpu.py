@@ -361,7 +361,7 @@ def test_gate_holds_under_the_engine_precision_schedule(n, wseed):
 # internally (solver_state_dtype, default); a diffusers user sets `scheduler.prev_sample_dtype = torch.float32` -- what the reference's own
 # latents are from step 2 on with an fp32 policy net.  The all-fp16 state is the explicitly non-default mode: printed, regression-bounded.
 @pytest.mark.timeout(3000)
-@pytest.mark.parametrize("n", [4, 8, 12, 15])
+@pytest.mark.parametrize("n", [2, 3, 4, 8, 12, 15])      # train_ppo.py:345 draws the step count from 2 .. 15
 def test_gate_on_the_rollout_function_and_the_pipeline_loop(n):
     from consolver_amd.rollout import denoise_diffusion
     from tests import fake_diffusers as fd
