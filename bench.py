@@ -509,7 +509,7 @@ def main():
                     help="roofline.traffic: 'live' (N = 1) measures FETCH_SIZE / WRITE_SIZE with two rocprofv3 --pmc child runs of tools/bench_unet.py after the "
                          "timed region (falls back to the newest committed profiles/r*_pmc_traffic.json), 'committed' quotes that file only")
     ap.add_argument("--hi-precision-steps", default="auto", help="the engine's precision schedule of the UNet's residual stream (engine.py): 'auto' (default: the first "
-                    "ceil(n / 4) + 1 forwards of a generation on the split stream, the rest on one fp16 plane), 'all' (every forward in --residual's mode), or an int")
+                    "ceil(n / 4) forwards of a generation on the split stream, the rest on one fp16 plane), 'all' (every forward in --residual's mode), or an int")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the N > 1 barrier / all_reduce(MAX) / per-rank all-gather "
                     "branch even at world size 1 (a one-GPU box exercising the exact code an 8-GPU launch runs; tests/test_engine_gpu.py)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch / rendezvous / sharding / reduction path without touching a GPU")
@@ -755,7 +755,7 @@ def main():
         one(); torch.cuda.synchronize()                    # workspace of the headline mode back in place for the passes below
     modes["note"] = ("residual-stream storage of the UNet executor (include/consolver_hip.h): f16x2 = split-fp16 hi + lo planes, fp32-class adds along "
                      "the stream; f16 = one plane, the reference fp16 pipeline's own arithmetic class (1.2e-3 over 8 steps: above the 1e-3 latent gate).  GEMM operands are "
-                     "fp16 in both.  f16x2_scheduled (the engine's default): the first ceil(n / 4) + 1 forwards of a generation on the split stream -- where the gate's "
+                     "fp16 in both.  f16x2_scheduled (the engine's default): the first ceil(n / 4) forwards of a generation on the split stream -- where the gate's "
                      "budget is spent -- the rest on one plane; every step of the trajectory is under the gate (parity).")
 
     # per-kernel-class HIP-event profile of one forward, in BOTH residual-stream modes (N = 1): what the lo planes cost per class is visible on the driver's box.

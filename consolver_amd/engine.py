@@ -43,9 +43,13 @@ class SDSamplingEngine:
         # the split stream, the rest with ONE fp16 plane -- the reference pipeline's own arithmetic class):
         #     n = 8:   k = 8 (all) 0.732e-3 | k = 4 0.734 | k = 3 0.760 | k = 2 0.834 | k = 1 1.35 (gate missed) | k = 0 1.48
         #     n = 12:  all 0.801 | k = 4 0.802 | k = 3 0.838 | k = 1 0.859;   n = 15:  all 0.518 | k = 5.. 0.53 | k = 3 0.768;   n = 4:  all 0.924 (step 0) | k = 2 0.924
-        # "auto" (default): the first ceil(n / 4) + 1 forwards run the handle's mode (f16x2), the rest `f16` -- 3 of 8, 4 of 12, 5 of 15, 2 of 4: every step of every
-        # trajectory stays under the gate with >= 16 % of air where the all-split schedule has >= 20 % (asserted: tests/test_parity_e2e_gpu.py), and 5 of 8 forwards of
-        # configs[1] skip the lo planes' bytes (-1.9 ms each).  An int fixes k; None / "all" runs every step in the handle's mode.  Inactive on an `f16` handle.
+        # With the round's last kernels (fp32 eps, the output head on two planes, sub-pixel upsamplers in the one-plane forwards; profiles/r06_parity_schedule_final.txt):
+        #     n = 4:   all 0.882 (step 0) | k = 1 0.884;   n = 8:  all 0.676 | k = 3 0.704 | k = 2 0.795 | k = 1 misses the gate;   n = 12:  all 0.767 | k = 4 0.770 | k = 3 0.806;
+        #     n = 15:  all 0.492 | k = 4 0.504;   n = 5 / 6:  k = 2 is the all-split maximum (0.816 / 0.767 at step 0)
+        # "auto" (default): the first ceil(n / 4) forwards run the handle's mode (f16x2), the rest `f16` -- 1 of 4, 2 of 8, 3 of 12, 4 of 15: the tightest numbers (short
+        # trajectories, step 0) are the all-split ones, every longer trajectory keeps >= 19 % of air (asserted at every step: tests/test_parity_e2e_gpu.py), and 6 of 8
+        # forwards of configs[1] run on one plane (-3.0 ms each: no lo planes, sub-pixel upsamplers).  Until the two-plane head the rule was ceil(n / 4) + 1 (3 of 8: 0.757e-3).
+        # An int fixes k; None / "all" runs every step in the handle's mode.  Inactive on an `f16` handle.
         if not (hi_precision_steps is None or hi_precision_steps in ("auto", "all") or (isinstance(hi_precision_steps, int) and hi_precision_steps >= 0)):
             raise ValueError("hi_precision_steps must be 'auto', 'all' / None, or a non-negative int")
         self.hi_precision_steps = hi_precision_steps
@@ -87,7 +91,7 @@ class SDSamplingEngine:
         h = self.hi_precision_steps
         if h is None or h == "all" or n is None:
             return None
-        return min(n, -(-n // 4) + 1) if h == "auto" else min(n, int(h))
+        return min(n, max(1, -(-n // 4))) if h == "auto" else min(n, int(h))
 
     def _loop(self, ctx, bufs, n, B, do_cfg):
         sch, unet = self.scheduler, self.unet

@@ -331,7 +331,7 @@ def test_gate_holds_at_other_step_counts_and_weights(n, wseed):
     assert max(drift) <= GATE, drift
 
 
-# The ENGINE'S DEFAULT: a precision schedule of the residual stream (engine.py, `hi_precision_steps="auto"`): the first ceil(n / 4) + 1 forwards of a generation on the
+# The ENGINE'S DEFAULT: a precision schedule of the residual stream (engine.py, `hi_precision_steps="auto"`): the first ceil(n / 4) forwards of a generation on the
 # split (hi + lo) stream, the rest on one fp16 plane -- the gate's budget is spent in the first steps (profiles/r06_parity_schedule.txt).  Every step of every trajectory
 # the defaults produce is held to the gate here, and the engine's own output is the loop's, bit for bit.
 @pytest.mark.timeout(3000)

@@ -1,7 +1,7 @@
 """Precision SCHEDULE of the denoiser's residual stream along a trajectory: the first k forwards with the split (hi + lo) stream, the rest with one fp16 plane.
 Per-step latent drift against the fp32 oracle on the full UNet for n = 4 / 8 / 12 / 15 and k = 0 .. n, one oracle trajectory per n:   python tools/parity_schedule.py
 Other weight seeds / batch sizes: CS_SCHED_SEED=8 CS_SCHED_B=2 CS_SCHED_NS=4,8 CS_SCHED_KS=auto python tools/parity_schedule.py ("auto" = all-split, all one-plane, and
-the engine's default ceil(n / 4) + 1 with its two neighbours)"""
+the engine's default ceil(n / 4) with its two neighbours)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,7 @@ ux2, _ = T.build_full(seed=wseed, residual="f16x2")
 for n in NS:
     c = T._oracle_case(n, wseed, g, B)
     sch, idx, noise, ctx_d = c["sch"], c["idx"], c["noise"], c["ctx"].to(T.DEV)
-    ka = min(n, -(-n // 4) + 1)
+    ka = min(n, max(1, -(-n // 4)))
     for k in ([n, 0] + [v for v in (ka - 1, ka, ka + 1) if 0 < v < n] if AUTO else [n, 0, 1, 2, 3, 4, 6][: (7 if n > 4 else 5)]):
         sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(T.DEV) for i in idx]
         sch.set_timesteps(n, device=T.DEV)
