@@ -343,7 +343,7 @@ def test_gate_holds_under_the_engine_precision_schedule(n, wseed):
     ux2, _ = build_full(seed=wseed, residual="f16x2")
     eng = SDSamplingEngine(ux2, sch, guidance_scale=g)
     k = eng.hi_steps(n)
-    assert k == {4: 2, 8: 3, 12: 4, 15: 5}[n] and eng.hi_precision_steps == "auto"
+    assert k == {4: 1, 8: 2, 12: 3, 15: 4}[n] and eng.hi_precision_steps == "auto"
     traj = _hip_trajectory(ux2, sch, idx, noise, ctx.to(DEV), B, n, g, hi_steps=k)
     drift = [rel_l2(traj[i], c["traj"][i]) for i in range(n)]
     sch.factor_net.forced_action_idx = [torch.from_numpy(i).to(DEV) for i in idx]
