@@ -447,8 +447,8 @@ struct Run {
         a.splitk_ws = sk_ws; a.splitk_ws_bytes = sk_bytes;
         // an upsampler in its sub-pixel form: pre-summed taps are one more fp16 rounding of the weights (~2^-12 of the output, straight onto the stream):
         // in the forwards that run on one fp16 plane, whose stream is rounded to fp16 sixty times anyway; the split stream keeps the exact filter
-        const bool sub = up && c.w_sub && (v_up_fold == 2 || (v_up_fold == 1 && !split)) && !res.hi && !temb &&
-                         ((Hi == 8 && Wi == 8) || (Hi % 16 == 0 && Wi % 16 == 0));
+        const bool sub = up && c.w_sub && (v_up_fold == 2 || (v_up_fold == 1 && !split)) && !res.hi && !temb && tune().conv_lw != 0 && !(tune().debug & 16384) &&
+                         ((Hi == 8 && Wi == 8) || (Hi % 16 == 0 && Wi % 16 == 0));      // (launch_igemm_impl's own conditions for the sub-pixel kernel: the executed-FLOP count follows them)
         if (sub) a.w_up_sub = c.w_sub;
         const double M = (double)B * Ho * Wo;
         const double bytes = 2.0 * (M * (c0 + c1) + (double)c.cout * c.taps * (c0 + c1) + M * c.cout * ((res.hi ? 2 : 1) + (res.lo ? 1 : 0) + (out.lo ? 1 : 0)));
