@@ -56,6 +56,30 @@ def oracle_run(sd, cfg, w, noise, pe, ne, idx, n, guidance, use_conv=False, prob
     return x
 
 
+def test_captured_generation_follows_the_default_precision_schedule():
+    """the hipGraph replay of a generation under the engine's DEFAULT schedule (hi_precision_steps="auto": split stream for the first ceil(n / 4) forwards, then one plane
+    with the sub-pixel upsamplers; fp32 eps with the two-plane output head) is the eager loop bit for bit, the schedule is part of the graph's key, and the handle comes
+    back in its own mode.  32 x 32 latents: both sub-pixel kernel forms and the MFMA conv_out run."""
+    unet, sd, sch, w = make(dict(layers_per_block=1, sample_size=32))
+    B, n, g = 2, 8, 3.0
+    one = torch.from_numpy(np.random.default_rng(9).integers(0, 11, size=(B, 3))).to(DEV)
+    pe, ne = synthetic_prompt_embeds(B, seed=1011).half().to(DEV), synthetic_prompt_embeds(B, seed=1012).half().to(DEV)
+    noise = torch.randn(B, 4, 32, 32, generator=torch.Generator().manual_seed(47)).half().to(DEV)
+    eng = SDSamplingEngine(unet, sch, guidance_scale=g)
+    assert eng.hi_precision_steps == "auto" and eng.hi_steps(n) == 2
+    sch.factor_net.forced_action_idx = one                                  # (one index set for every step: what a capture bakes)
+    eager = eng.generate(pe, ne, latents=noise, num_inference_steps=n).clone()
+    graph = eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=True).clone()
+    again = eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=True).clone()
+    assert torch.equal(eager, graph) and torch.equal(graph, again) and unet.residual == "f16x2"
+    eng.hi_precision_steps = "all"
+    allsplit = eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=True).clone()
+    assert not torch.equal(allsplit, graph)                                  # another schedule is another graph
+    eng.hi_precision_steps = "auto"
+    assert torch.equal(eng.generate(pe, ne, latents=noise, num_inference_steps=n, use_graph=True), graph)
+    sch.factor_net.forced_action_idx = None
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_engine_trajectory_reduced_unet(use_graph):
     unet, sd, sch, w = make(dict(layers_per_block=1, sample_size=16))
