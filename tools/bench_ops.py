@@ -130,6 +130,15 @@ if os.environ.get("CS_SHAPES_JSON"):
     import json
     json.dump(shapes, open(os.environ["CS_SHAPES_JSON"], "w"), indent=1)
 print(f"{'op':40s} {'M':>8s} {'K':>8s} {'N':>6s} {'ms':>9s} {'TFLOP/s':>9s}")
+if which in ("upsub",):
+    # the UNet's three upsamplers, batch 32: fused-upsample kernel and the sub-pixel form (tools/pmc_up_sub.sh reads the SQ counters of both)
+    for H, C in ((8, 1280), (16, 1280), (32, 640)):
+        x = rnd(B, H, H, C); w = ops.pack_conv_weight(rnd(C, C, 3, 3, scale=(9 * C) ** -0.5)); b = rnd(C)
+        ws = ops.conv_up_fold_pack(w).to(dev)
+        fl = 2.0 * B * 4 * H * H * 9 * C * C
+        for name, fn in (("fused-upsample", lambda: ops.conv2d(x, w, b, upsample=True)), ("sub-pixel", lambda: ops.conv_up_sub(x, w, ws, b))):
+            ms = timeit(fn)
+            rows.append((f"upsampler {H}->{2 * H} {name}", B * 4 * H * H, 9 * C, C, ms, fl / ms / 1e9))
 if which in ("convgn",):
     # cost of the GroupNorm-statistics epilogue: the same conv / 1x1 with and without gn_stats
     for H, cin, cout, taps, res, tag in [(64, 320, 320, 9, True, "L0 conv2"), (64, 960, 320, 9, False, "L0 up conv1"), (32, 640, 640, 9, True, "L1 conv2"),
