@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void conv_out_patch_kernel(const f16* __restri
 // of the chunk being multiplied (register prefetch, single LDS buffer: 41.5 KB, three workgroups per CU).  What remains is the streaming read.
 template <int COUT>
 __global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __restrict__ x, int Cin, int H, int W, const f16* __restrict__ w,
-                                                            const f16* __restrict__ bias, f16* __restrict__ out, int postprocess, int out_f32) {
+                                                            const f16* __restrict__ bias, f16* __restrict__ out, int postprocess, int out_f32,
+                                                            const float* __restrict__ acc_in = nullptr) {
     static_assert(COUT >= 1 && COUT <= 16, "one 16-column MFMA tile");
     __shared__ __attribute__((aligned(16))) f16 halo[324 * 64];
     __shared__ __attribute__((aligned(16))) f16 wts[COUT * 9 * 64];      // this chunk's filters [COUT][tap][64]: staged with the halo, so that the fragment reads wait on lgkmcnt --
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256, 3) void conv_out_mfma_kernel(const f16* __rest
             typedef f16 f16x4 __attribute__((ext_vector_type(4)));
             f16x4 o; f32x4 of;
             f32x4 prev = {0.f, 0.f, 0.f, 0.f};
-            // out_f32 == 2: ADD to the fp32 values already there (the second pass of a hi + lo operand: launch_conv_out's x_lo)
-            if (out_f32 == 2) prev = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(out) + ((((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4));
+            // acc_in: ADD the fp32 values of a first pass (the second pass of a hi + lo operand: launch_conv_out's x_lo; acc_in may be `out` itself)
+            if (acc_in) prev = *reinterpret_cast<const f32x4*>(acc_in + ((((size_t)b * COUT + col) * H + y) * W + x0 + kq * 4));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[mt][r] + bv + prev[r];
@@ -540,19 +541,27 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
     return CS_OK;
 }
 
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, int out_f32, const f16* x_lo) {
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w, const f16* bias, int Cout, f16* out, hipStream_t s, int out_f32, const f16* x_lo,
+                    float* scratch32) {
     if (!x || !w || !bias || !out) CS_FAIL(CS_E_ARG, "conv_out: null pointer");
     if (Cout != 4 || Cin % 8) CS_FAIL(CS_E_UNSUPPORTED, "conv_out: built for 4 output channels (got %d)", Cout);
     if (B <= 0) return CS_OK;
     if (H % 16 == 0 && W % 16 == 0 && Cin % 64 == 0) {
+        if (x_lo) {
+            // W (x + x_lo) + b: the hi plane's product (+ bias) in fp32 -- into `out` when that is fp32, into scratch32 otherwise -- then the lo plane's product on top of it,
+            // written in the output's dtype: ONE rounding of the fp32-class value.  MFMA kernel only.
+            if (!tune().conv_out_mfma) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand needs the MFMA kernel");
+            if (!out_f32 && !scratch32) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand with a 16-bit output needs scratch32 [B][Cout][H][W]");
+            float* first = out_f32 ? reinterpret_cast<float*>(out) : scratch32;
+            const dim3 grid((H / 16) * (W / 16), B);
+            hipLaunchKernelGGL(conv_out_mfma_kernel<4>, grid, dim3(256), 0, s, x, Cin, H, W, w, bias, reinterpret_cast<f16*>(first), 0, 1, (const float*)nullptr);
+            CS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(conv_out_mfma_kernel<4>, grid, dim3(256), 0, s, x_lo, Cin, H, W, w, (const f16*)nullptr, out, 0, out_f32 ? 1 : 0, (const float*)first);
+            CS_CHECK_LAUNCH();
+            return CS_OK;
+        }
         launch_conv_out_patch<4>(x, B, Cin, H, W, w, bias, out, 0, s, out_f32);
         CS_CHECK_LAUNCH();
-        if (x_lo) {
-            // W (x + x_lo): the lo plane's product on top of the fp32 result (no bias).  Only where the first pass left fp32 values and the MFMA kernel runs.
-            if (!out_f32 || !tune().conv_out_mfma) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand needs the fp32 output and the MFMA kernel");
-            hipLaunchKernelGGL(conv_out_mfma_kernel<4>, dim3((H / 16) * (W / 16), B), dim3(256), 0, s, x_lo, Cin, H, W, w, (const f16*)nullptr, out, 0, 2);
-            CS_CHECK_LAUNCH();
-        }
         return CS_OK;
     }
     if (x_lo) CS_FAIL(CS_E_ARG, "conv_out: a lo plane of the operand is built for the 16 x 16-patch shapes");

@@ -43,7 +43,7 @@ struct TuneSet {
     // GroupNorm statistics of its output from the conv epilogue.  0: conv_in_kernel (one thread per pixel, 640-byte strided stores: 111 us at batch 32 = 0.75 TB/s).
     int conv_in_mfma = 1;
     int up_fold = 1;        // the UNet's upsamplers (nearest x2 + 3x3 conv) in the sub-pixel form on pre-summed taps (IgemmArgs::w_up_sub): 0 never, 1 in forwards on one fp16 plane, 2 always
-    int head_x2 = 1;        // split stream + fp32 output: the UNet's output head keeps its GroupNorm + SiLU output as hi + lo planes and conv_out multiplies both (0: one fp16 plane)
+    int head_x2 = 1;        // split stream: the UNet's output head keeps its GroupNorm + SiLU output as hi + lo planes and conv_out multiplies both (0: one fp16 plane)
     int conv_out_mfma = 1;  // 1: the 16 x 16-patch conv_out kernels (UNet 320 -> 4, VAE 128 -> 3) on v_mfma_f32_16x16x32_f16 (conv_out_mfma_kernel), 0: the v_dot2 patch kernel
     int xattn_tile = 64;    // 64: xattn64_kernel, 64-row tiles at two workgroups per CU; 128: xattn_block_kernel (one 160 KB workgroup per CU)
 };
@@ -178,9 +178,10 @@ int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, cons
                    int Cout, f16* out, hipStream_t s, f16* out_lo = nullptr);
 // conv_out: NHWC [B][H][W][Cin] -> NCHW [B][Cout][H][W], 3x3 pad 1 (Cout small)
 // out_f32 != 0: `out` is an fp32 tensor (the same NCHW layout)
-// x_lo (with out_f32, 16 x 16-patch shapes on the MFMA kernel): a lo plane of the operand (value = x + x_lo); a second pass adds its product into the fp32 output
+// x_lo (16 x 16-patch shapes on the MFMA kernel): a lo plane of the operand (value = x + x_lo); the hi plane's product is kept in fp32 (in `out` when out_f32, else in
+// scratch32 [B][Cout][H][W]) and a second pass adds the lo plane's product and writes the output's dtype
 int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16* w /*[Cout][9][Cin]*/, const f16* bias, int Cout,
-                    f16* out, hipStream_t s, int out_f32 = 0, const f16* x_lo = nullptr);
+                    f16* out, hipStream_t s, int out_f32 = 0, const f16* x_lo = nullptr, float* scratch32 = nullptr);
 
 // ---- transformer (FLUX DiT) ops, f16 or bf16 (dtype = CS_F16 / CS_BF16) -------------------------------------
 struct Gemm2Args {

@@ -214,8 +214,8 @@ int cs_op_attention_bias(const void* q, int q_stride, const void* k, int k_strid
  *                0 an fp16 one;
  *   "up_fold": the UNet's three upsamplers in the sub-pixel form (cs_op_conv_up_sub: 16 instead of 36 multiplies per input pixel, taps summed on the host and
  *                rounded to fp16 once more): 0 never, 1 (default) in forwards whose residual stream is one fp16 plane, 2 also on the split stream;
- *   "head_x2": 1 (default) with the split stream and the fp32 output the UNet's output head keeps its GroupNorm + SiLU output as hi + lo planes and conv_out multiplies
- *                both (a second pass over the lo plane into the fp32 result), 0 one fp16 plane as in round 5;
+ *   "head_x2": 1 (default) with the split stream the UNet's output head keeps its GroupNorm + SiLU output as hi + lo planes and conv_out multiplies both (a second
+ *                pass over the lo plane on top of the first pass's fp32 result; the output, fp32 or the model dtype, is rounded from that once), 0 one fp16 plane as in round 5;
  *   "conv_out_mfma": 1 (default) the 16 x 16-patch conv_out kernels (cs_op_conv_out) on the matrix cores, 0 the v_dot2 patch kernel;
  *   "conv_in_mfma": 1 (default) the UNet's conv_in runs on the MFMA conv kernel over latents zero-padded to 64 channels, 0 the scalar conv_in kernel;
  *   "ln_fold":   1 (default) the transformer blocks' LayerNorms are folded into the linear layers that consume them inside cs_unet_forward (cs_op_linear_ln),

@@ -90,7 +90,7 @@ int launch_rowvec_linear(const f16* x, int R, int K, const f16* w, const f16*, i
 int launch_conv_in(const f16* lat, int n_lat, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, f16* out_lo) {
     rd(lat, (size_t)n_lat * Cin * H * W * 2); wr(out, (size_t)B * H * W * Cout * 2); wr(out_lo, (size_t)B * H * W * Cout * 2); return CS_OK;
 }
-int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, int out_f32, const f16* x_lo) { rd(x, (size_t)B * H * W * Cin * 2); rd(x_lo, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * (out_f32 ? 4 : 2)); return CS_OK; }
+int launch_conv_out(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t, int out_f32, const f16* x_lo, float* scratch32) { rd(x, (size_t)B * H * W * Cin * 2); rd(x_lo, (size_t)B * H * W * Cin * 2); wr(scratch32, (size_t)B * Cout * H * W * 4); wr(out, (size_t)B * Cout * H * W * (out_f32 ? 4 : 2)); return CS_OK; }
 int launch_conv_out3(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, f16* out, int, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * 3 * H * W * 2); return CS_OK; }
 int launch_conv_out_small(const f16* x, int B, int Cin, int H, int W, const f16*, const f16*, int Cout, f16* out, hipStream_t) { rd(x, (size_t)B * H * W * Cin * 2); wr(out, (size_t)B * Cout * H * W * 2); return CS_OK; }
 int launch_pixel_linear_nchw(const f16* x, const f16*, const f16*, f16* out, int B, int C, int HW, float, float, hipStream_t) { rd(x, (size_t)B * C * HW * 2); wr(out, (size_t)B * C * HW * 2); return CS_OK; }
