@@ -207,6 +207,17 @@ static void flux_part() {
         EXPECT(cs_flux_forward(f, hid.data(), B, Lq + Li, enc.data(), T, pooled.data(), ts.data(), gd.data(), rc.data(), rs.data(), out.data(), ws, wsb, nullptr) == CS_OK);
         EXPECT(cs_flux_forward(f, hid.data(), B, Lq + Li, enc.data(), T, pooled.data(), ts.data(), gd.data(), rc.data(), rs.data(), out.data(), ws, wsb / 3, nullptr) != CS_OK);
         free(ws);
+        // round 6: the fp32 output (the output head's two planes summed; split stream only): its own workspace query, an fp32 `out`, refused on the one-plane stream
+        EXPECT(cs_flux_set_output_dtype(f, 77) != CS_OK && cs_flux_set_output_dtype(f, CS_F32) == CS_OK && cs_flux_get_output_dtype(f) == CS_F32);
+        {
+            const size_t wsb32 = cs_flux_workspace_bytes(f, B, T, Lq + Li);
+            char* ws32 = (char*)malloc(wsb32);
+            std::vector<char> out32((size_t)B * (Lq + Li) * 64 * 4);
+            const int rc32 = cs_flux_forward_joint(f, lat.data(), Lq, img.data(), Li, B, enc.data(), T, pooled.data(), ts.data(), gd.data(), rc.data(), rs.data(), out32.data(), ws32, wsb32, nullptr);
+            EXPECT((rc32 == CS_OK) == (mode == CS_RESIDUAL_F16X2));
+            free(ws32);
+        }
+        EXPECT(cs_flux_set_output_dtype(f, c.dtype) == CS_OK && cs_flux_get_output_dtype(f) == c.dtype);
     }
     cs_flux_destroy(f);
 }
