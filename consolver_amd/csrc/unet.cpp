@@ -799,10 +799,11 @@ int run_forward(CsUNet* u, bool dry, const f16* latents, int n_lat, int dup, con
     // split stream (knob head_x2): the head's GroupNorm + SiLU output is conv_out's operand -- one fp16 plane of it was the last one-plane station of the stream's value
     // in front of eps (3.5 % of the per-forward error, tools/sim_precision_head.py).  Two planes, conv_out multiplies both: a second 25 us pass over the lo plane on top of
     // the first pass's fp32 result; the output (fp32 for the native engine, the model dtype for the plain protocol) is rounded from that once.
-    const bool head2 = R.split && tune().head_x2 != 0 && tune().conv_out_mfma != 0 && H % 16 == 0 && W % 16 == 0 && ch % 64 == 0;
-    f16* n_lo = head2 ? R.alloc((size_t)B * H * W * ch) : nullptr;
-    // (a 16-bit output: the first pass's fp32 result lives in scratch; reserved by the workspace query whatever output dtype is set at that moment)
-    float* head32 = (head2 && (u->out_dtype != CS_F32 || dry)) ? (float*)R.alloc((size_t)B * H * W * c.out_channels * 2) : nullptr;
+    const bool head2_shape = R.split && H % 16 == 0 && W % 16 == 0 && ch % 64 == 0;
+    const bool head2 = head2_shape && tune().head_x2 != 0 && tune().conv_out_mfma != 0;
+    // (the workspace query -- dry -- reserves the head's lo plane and the 16-bit output's fp32 scratch whatever the knobs and the output dtype are at that moment)
+    f16* n_lo = (head2 || (dry && head2_shape)) ? R.alloc((size_t)B * H * W * ch) : nullptr;
+    float* head32 = ((head2 && u->out_dtype != CS_F32) || (dry && head2_shape)) ? (float*)R.alloc((size_t)B * H * W * c.out_channels * 2) : nullptr;
     R.group_norm(u->norm_out, h, ch, St(), 0, H * W, true, n, head2 ? n_lo : nullptr);
     R.srelease(h);
     R.launch(P_MISC, 2.0 * B * H * W * 9.0 * ch * c.out_channels * ((head2 && R.count_executed) ? 2.0 : 1.0), 2.0 * B * H * W * ch * (head2 ? 2.0 : 1.0),
